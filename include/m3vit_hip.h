@@ -1,0 +1,218 @@
+/* m3vit_hip.h - C ABI of libm3vit_hip.so: the MI355X (gfx950) implementation of the
+ * M3ViT MoE-ViT forward/backward hot path.
+ *
+ * This is the drop-in boundary described in SURVEY.md section 8(b).  The reference
+ * reaches this path through the python package `fmoe` (laekov/fastmoe, absent from
+ * /root/reference) whose native half is the `fmoe_cuda` extension; the entry points
+ * below are what a binding for that layer would call.  Each one cites the reference
+ * call site (path:line relative to the reference root) whose work it replaces.
+ *
+ * Conventions
+ *   - plain C, no torch types: device pointers, sizes, an opaque hipStream_t (void*).
+ *   - every call is asynchronous on `stream`, allocates nothing, takes no locks and
+ *     never synchronises the device; the caller owns all buffers and workspaces.
+ *   - return value: 0 = ok, negative = M3_ERR_* ; m3_last_error() gives the text of
+ *     the last failure on the calling thread.  Shape/alignment violations are
+ *     rejected on the host before anything is launched.
+ *   - dtype codes (M3_F32, M3_F16) describe ACTIVATION storage; accumulation is
+ *     always fp32; parameters/gradients of parameters are fp32.
+ *   - indices are int32 on the device-internal path and int64 where the reference
+ *     API exposes them (gate_top_k_idx from torch.topk).
+ */
+#ifndef M3VIT_HIP_H
+#define M3VIT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M3_F32 0
+#define M3_F16 1
+
+#define M3_OK 0
+#define M3_ERR_ARG (-1)      /* bad shape / alignment / null pointer */
+#define M3_ERR_LAUNCH (-2)   /* hipLaunch failed (text in m3_last_error) */
+#define M3_ERR_UNSUPPORTED (-3)
+
+#define M3_ACT_NONE 0
+#define M3_ACT_GELU 1        /* exact erf GELU, nn.GELU(): vision_transformer_moe.py:409-412 */
+
+int m3_version(void);
+const char *m3_last_error(void);
+/* fills name[0..len) with the gcnArchName of the current device; returns CU count or <0 */
+int m3_device_query(char *name, int len);
+
+/* ---------------------------------------------------------------- gate (a1-a3)
+ * NoisyGate_VMoE.forward, models/moe/ckpt/noisy_gate_vmoe.py:91-93,168,197-207:
+ *   logit = x @ w_gate (+ logit_bias) ; noisy = logit + noise*noise_std ;
+ *   p = softmax(noisy) ; top-(k+1) ; score/idx = first k (not renormalised).
+ * x [T,D] (x_dtype, row stride ldx elements), w_gate [D,E] fp32 row-major,
+ * logit_bias [E] fp32 or NULL (task-conditioned term tsf @ w_gate[D:], the
+ * cat at custom_moe_layer.py:176-179 folded into a bias), noise [T,E] fp32 or NULL.
+ * Outputs: idx i64 [T,k], score f32 [T,k], top_logits f32 [T,min(k+1,E)];
+ * optional dense clean/noisy/gates f32 [T,E] (NULL to skip), optional
+ * idx32 i32 [T,k] copy for the routing kernels.
+ * part_importance f32 [nblk,E], part_load i32 [nblk,E] with nblk =
+ * m3_gate_num_blocks(T): per-block partial sums of gates.sum(0) and (gates>0).sum(0)
+ * (vision_transformer_moe.py:453-459), reduced in fixed order by m3_gate_reduce.
+ * E in {2..64}, k < = 8, k <= E. */
+int m3_gate_num_blocks(int64_t T);
+int m3_gate_dw_blocks(int64_t T);
+int m3_gate_fwd(const void *x, int x_dtype, int64_t T, int D, int64_t ldx,
+                const float *w_gate, int E, const float *logit_bias,
+                const float *noise, float noise_std, int k,
+                int64_t *idx, int32_t *idx32, float *score, float *top_logits,
+                float *clean, float *noisy, float *gates,
+                float *part_importance, int32_t *part_load, void *stream);
+/* importance f32 [E], load i64 [E] from the per-block partials */
+int m3_gate_reduce(const float *part_importance, const int32_t *part_load, int nblk, int E,
+                   float *importance, int64_t *load, void *stream);
+/* Backward of the gate: d_score [T,k] (from the combine) and d_importance [E]
+ * (from cv_squared(importance), vision_transformer_moe.py:540) -> d_logits f32 [T,E]
+ * through the scatter (:206-207) and the softmax (:197).  probs are recomputed from
+ * `noisy` [T,E]. */
+int m3_gate_bwd_logits(const float *noisy, const int64_t *idx, const float *d_score,
+                       const float *d_importance, int64_t T, int E, int k,
+                       float *d_logits, void *stream);
+/* d_w_gate[D,E] (+)= x^T d_logits ; dx[T,D] (+)= d_logits w_gate^T  (noisy_gate_vmoe.py:91).
+ * part_dw f32 [m3_gate_dw_blocks(T), D, E] workspace; dx fp32 accumulate (beta_dx 0/1). */
+int m3_gate_bwd_params(const void *x, int x_dtype, int64_t T, int D, int64_t ldx,
+                       const float *w_gate, int E, const float *d_logits,
+                       float *part_dw, float *d_w_gate, int beta_dw,
+                       float *dx, int64_t lddx, int beta_dx, void *stream);
+
+/* ------------------------------------------------------- dispatch metadata (a5)
+ * What fastmoe's prepare_forward (count_by_gate + assign_pos) computes behind
+ * _fmoe_general_global_forward, models/moe/ckpt/custom_moe_layer.py:263-265, with a
+ * stable slot order.  idx32 [n] flat (n = T*k) expert ids in [0,E).
+ * Outputs (all device): counts i32 [E], offsets i32 [E+1], pos i32 [n] (slot of flat
+ * entry i), row_of_slot i32 [n] (inverse), tile_starts i32 [E+1] (prefix of
+ * ceil(count/128) m-tiles per expert, read by the grouped GEMMs),
+ * counts64 i64 [E] (optional, fwd_expert_count as the reference API exposes it).
+ * ws i32 [m3_route_ws_elems(n,E)] scratch. */
+int64_t m3_route_ws_elems(int64_t n, int E);
+int m3_route_build(const int32_t *idx32, int64_t n, int E, int32_t *counts, int32_t *offsets,
+                   int32_t *pos, int32_t *row_of_slot, int32_t *tile_starts, int64_t *counts64,
+                   int32_t *ws, void *stream);
+
+/* -------------------------------------------------- GEMM family (a6, a8, a10)
+ * C[m, n] = epilogue( sum_k A[arow(m), k] * B[g(m)][n, k] )      ("NT": both K-contiguous)
+ *   FMoELinear fwd/dgrad: custom_moe_layer.py:32-33,41,43; qkv/proj Linear:
+ *   vision_transformer_moe.py:295,297,303,311; Mlp fc1/fc2 :255-261; PatchEmbed :330-341.
+ * Dense call: G = 1, group_offsets = tile_starts = NULL, rows 0..M-1.
+ * Grouped call: rows are expert-major slots, group g owns rows
+ *   [group_offsets[g], group_offsets[g+1]); tile_starts as produced by m3_route_build;
+ *   M = upper bound on rows (T*k); B group stride = N*ldb elements.
+ * a_row_idx (i32, optional): source row of A for slot m is a_row_idx[m] / a_row_div
+ *   (gather fused into the operand load: MOEScatter).  c_row_idx (optional): destination
+ *   row of C for slot m (MOEGather back to token-major).
+ * Epilogue, in this order: + bias[g][n] (fp32) ; store pre-activation to pre_out (act
+ * dtype) if non-NULL ; act (GELU) ; * gelu'(gelu_grad_pre[m,n]) if non-NULL ;
+ * + residual[m,n] (fp32) if non-NULL ; store as c_dtype (M3_F32 or the act dtype).
+ * Requirements: K*sizeof(elem) % 16 == 0, lda/ldb rows 16-byte aligned, N % 4 == 0. */
+typedef struct {
+  const void *A; int64_t lda;
+  const int32_t *a_row_idx; int32_t a_row_div;
+  const void *B; int64_t ldb;
+  void *C; int64_t ldc; int32_t c_dtype;
+  const int32_t *c_row_idx;
+  const float *bias;               /* [G][N] or NULL */
+  void *pre_out; int64_t ld_pre;   /* act dtype, or NULL */
+  const void *gelu_grad_pre; int64_t ld_gpre;
+  const float *residual; int64_t ld_res;
+  int32_t act;
+  int64_t M; int32_t N; int32_t K;
+  int32_t G;
+  const int32_t *group_offsets;    /* [G+1] device, or NULL for dense */
+  const int32_t *tile_starts;      /* [G+1] device, or NULL for dense */
+  int32_t dtype;                   /* M3_F32 / M3_F16: element type of A, B, pre */
+} m3_gemm_args;
+int m3_gemm_nt(const m3_gemm_args *args, void *stream);
+
+/* Weight gradient ("TN", contraction over rows):
+ *   dW[g][n, k] (+)= sum_{m in group g} dC[crow(m), n] * A[arow(m), k]
+ *   FMoELinear backward (fastmoe linear_backward behind custom_moe_layer.py:32-33) and
+ *   nn.Linear weight grads.  dC [*, N], A [*, K] in the act dtype; dW fp32 [G][N][K].
+ * Deterministic split over rows: `splits` partial slabs in ws (fp32
+ * [splits][G][N][K]) then m3_wgrad_reduce sums them in order (beta = 1 accumulates
+ * into dW, as the joint multi-task backward does: train/train_utils.py:449-457). */
+typedef struct {
+  const void *dC; int64_t lddc; const int32_t *c_row_idx;
+  const void *A; int64_t lda; const int32_t *a_row_idx; int32_t a_row_div;
+  int64_t M; int32_t N; int32_t K; int32_t G;
+  const int32_t *group_offsets;    /* [G+1] device or NULL (dense: rows 0..M-1) */
+  int32_t splits;
+  float *ws;                       /* [splits][G][N][K] */
+  int32_t dtype;
+} m3_wgrad_args;
+int m3_wgrad_tn(const m3_wgrad_args *args, void *stream);
+int m3_wgrad_reduce(const float *ws, int splits, int64_t elems, float *dW, int beta, void *stream);
+/* Column sums for bias grads: db[g][n] (+)= sum_{m in group g} dC[crow(m), n].
+ * ws fp32 [m3_colsum_ws_elems(M, N, G)]. */
+int64_t m3_colsum_ws_elems(int64_t M, int N, int G);
+int m3_colsum(const void *dC, int dtype, int64_t lddc, const int32_t *c_row_idx, int64_t M, int N,
+              int G, const int32_t *group_offsets, float *ws, float *db, int beta, void *stream);
+
+/* ------------------------------------------------------------- combine (a7)
+ * out[t,:] = residual[t,:] + sum_j score[t,j] * y[t*k+j,:]
+ *   bmm(gate_score[T,1,k], moe_outp[T,k,D]), custom_moe_layer.py:298-305, fused with
+ *   the residual add at vision_transformer_moe.py:450.  y [T*k, D] act dtype (token
+ *   major), residual/out fp32 [T, D] (residual may be NULL). */
+int m3_combine_fwd(const void *y, int dtype, const float *score, const float *residual,
+                   int64_t T, int k, int D, float *out, void *stream);
+/* dy[t*k+j,:] = score[t,j] * dout[t,:] (act dtype) ; dscore[t,j] = <dout[t,:], y[t*k+j,:]> */
+int m3_combine_bwd(const float *dout, const void *y, int dtype, const float *score,
+                   int64_t T, int k, int D, void *dy, float *dscore, void *stream);
+
+/* ----------------------------------------------------------- LayerNorm (a9)
+ * nn.LayerNorm(D, eps) on the fp32 residual stream, output in the act dtype
+ * (vision_transformer_moe.py:441-442, eps 1e-6 :567).  Saves mean/rstd fp32 [T]. */
+int m3_layernorm_fwd(const float *x, int64_t T, int D, const float *gamma, const float *beta,
+                     float eps, void *y, int y_dtype, float *mean, float *rstd, void *stream);
+/* dx[t,:] = dx_res[t,:] + LN'(dy[t,:]) ; dgamma/dbeta via per-block partials in ws
+ * (fp32 [2][m3_ln_bwd_blocks(T)][D]) reduced in fixed order (beta = accumulate). */
+int m3_ln_bwd_blocks(int64_t T);
+int m3_layernorm_bwd(const void *dy, int dy_dtype, const float *x, const float *mean,
+                     const float *rstd, const float *gamma, const float *dx_res,
+                     int64_t T, int D, float *dx, float *ws, float *dgamma, float *dbeta,
+                     int beta, void *stream);
+
+/* ----------------------------------------------------------- attention (a8)
+ * softmax(q k^T * dh^-0.5) v over the packed qkv activations written by the qkv
+ * Linear, Attention.forward vision_transformer_moe.py:299-313.
+ * qkv [B*N, 3*C] act dtype laid out [token][3][heads][dh]; o [B*N, C]; lse f32 [B,heads,N].
+ * dh in {32, 64}. */
+int m3_attention_fwd(const void *qkv, int dtype, int B, int N, int heads, int dh,
+                     void *o, float *lse, void *stream);
+/* dqkv [B*N, 3*C] from do [B*N, C]; N <= 256 in this release (all keys of one
+ * (image, head) in one workgroup). */
+int m3_attention_bwd(const void *qkv, const void *o, const void *d_o, const float *lse,
+                     int dtype, int B, int N, int heads, int dh, void *dqkv, void *stream);
+
+/* ------------------------------------------------------------- elementwise
+ * cast / transpose helpers for parameters (fp32 master -> act dtype operand copies):
+ *   dst[g][c][r] = (T) src[g][r][c]  when transpose, else dst = (T) src. */
+int m3_cast_matrix(const float *src, int G, int rows, int cols, int transpose,
+                   void *dst, int dst_dtype, void *stream);
+/* dst(T)[i] = src(f32)[i] ; n elements */
+int m3_cast_f32(const float *src, int64_t n, void *dst, int dst_dtype, void *stream);
+/* patchify: images [B,3,H,W] fp32 NCHW -> rows [B*(H/P)*(W/P), 3*P*P] act dtype in
+ * conv-weight order (c, py, px): PatchEmbed conv16/16, vision_transformer_moe.py:330-341 */
+int m3_im2row(const float *img, int B, int Cin, int H, int W, int P, void *rows, int dtype,
+              void *stream);
+/* tokens[b,0,:] = cls + pos[0] ; tokens[b,1+i,:] = patch[b*np+i,:] + pos[1+i]  (fp32 out)
+ * forward_features :782-791.  patch fp32 [B*np, D]. */
+int m3_assemble_tokens(const float *patch, const float *cls, const float *pos, int B, int np_,
+                       int D, float *tokens, void *stream);
+
+/* backward of m3_assemble_tokens: dpatch (act dtype, may be NULL) [B*np, D] = dtok[:,1:,:];
+ * dpos f32 [np+1, D] (+)= sum_b dtok[b] ; dcls f32 [D] (+)= sum_b dtok[b,0]  (beta 0/1). */
+int m3_tokens_bwd(const float *dtok, int B, int np_, int D, void *dpatch, int dtype, float *dpos,
+                  float *dcls, int beta, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M3VIT_HIP_H */

@@ -1,0 +1,112 @@
+"""ctypes loader for libm3vit_hip.so (the C ABI declared in include/m3vit_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails the
+error is raised, never papered over by a torch/CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libm3vit_hip.so")
+
+M3_F32, M3_F16 = 0, 1
+M3_ACT_NONE, M3_ACT_GELU = 0, 1
+
+
+class M3Error(RuntimeError):
+    pass
+
+
+class GemmArgs(Structure):
+    _fields_ = [
+        ("A", c_void_p), ("lda", c_int64),
+        ("a_row_idx", c_void_p), ("a_row_div", c_int32),
+        ("B", c_void_p), ("ldb", c_int64),
+        ("C", c_void_p), ("ldc", c_int64), ("c_dtype", c_int32),
+        ("c_row_idx", c_void_p),
+        ("bias", c_void_p),
+        ("pre_out", c_void_p), ("ld_pre", c_int64),
+        ("gelu_grad_pre", c_void_p), ("ld_gpre", c_int64),
+        ("residual", c_void_p), ("ld_res", c_int64),
+        ("act", c_int32),
+        ("M", c_int64), ("N", c_int32), ("K", c_int32),
+        ("G", c_int32),
+        ("group_offsets", c_void_p),
+        ("tile_starts", c_void_p),
+        ("dtype", c_int32),
+    ]
+
+
+class WgradArgs(Structure):
+    _fields_ = [
+        ("dC", c_void_p), ("lddc", c_int64), ("c_row_idx", c_void_p),
+        ("A", c_void_p), ("lda", c_int64), ("a_row_idx", c_void_p), ("a_row_div", c_int32),
+        ("M", c_int64), ("N", c_int32), ("K", c_int32), ("G", c_int32),
+        ("group_offsets", c_void_p),
+        ("splits", c_int32),
+        ("ws", c_void_p),
+        ("dtype", c_int32),
+    ]
+
+
+_V, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+
+# name -> (restype, argtypes); every symbol include/m3vit_hip.h declares
+SIGNATURES = {
+    "m3_version": (c_int, []),
+    "m3_last_error": (c_char_p, []),
+    "m3_device_query": (c_int, [c_char_p, _I]),
+    "m3_gate_num_blocks": (c_int, [_L]),
+    "m3_gate_dw_blocks": (c_int, [_L]),
+    "m3_gate_fwd": (c_int, [_V, _I, _L, _I, _L, _V, _I, _V, _V, _F, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V]),
+    "m3_gate_reduce": (c_int, [_V, _V, _I, _I, _V, _V, _V]),
+    "m3_gate_bwd_logits": (c_int, [_V, _V, _V, _V, _L, _I, _I, _V, _V]),
+    "m3_gate_bwd_params": (c_int, [_V, _I, _L, _I, _L, _V, _I, _V, _V, _V, _I, _V, _L, _I, _V]),
+    "m3_route_ws_elems": (c_int64, [_L, _I]),
+    "m3_route_build": (c_int, [_V, _L, _I, _V, _V, _V, _V, _V, _V, _V, _V]),
+    "m3_gemm_nt": (c_int, [POINTER(GemmArgs), _V]),
+    "m3_wgrad_tn": (c_int, [POINTER(WgradArgs), _V]),
+    "m3_wgrad_reduce": (c_int, [_V, _I, _L, _V, _I, _V]),
+    "m3_colsum_ws_elems": (c_int64, [_L, _I, _I]),
+    "m3_colsum": (c_int, [_V, _I, _L, _V, _L, _I, _I, _V, _V, _V, _I, _V]),
+    "m3_combine_fwd": (c_int, [_V, _I, _V, _V, _L, _I, _I, _V, _V]),
+    "m3_combine_bwd": (c_int, [_V, _V, _I, _V, _L, _I, _I, _V, _V, _V]),
+    "m3_layernorm_fwd": (c_int, [_V, _L, _I, _V, _V, _F, _V, _I, _V, _V, _V]),
+    "m3_ln_bwd_blocks": (c_int, [_L]),
+    "m3_layernorm_bwd": (c_int, [_V, _I, _V, _V, _V, _V, _V, _L, _I, _V, _V, _V, _V, _I, _V]),
+    "m3_attention_fwd": (c_int, [_V, _I, _I, _I, _I, _I, _V, _V, _V]),
+    "m3_attention_bwd": (c_int, [_V, _V, _V, _V, _I, _I, _I, _I, _I, _V, _V]),
+    "m3_cast_matrix": (c_int, [_V, _I, _I, _I, _I, _V, _I, _V]),
+    "m3_cast_f32": (c_int, [_V, _L, _V, _I, _V]),
+    "m3_im2row": (c_int, [_V, _I, _I, _I, _I, _I, _V, _I, _V]),
+    "m3_assemble_tokens": (c_int, [_V, _V, _V, _I, _I, _I, _V, _V]),
+    "m3_tokens_bwd": (c_int, [_V, _I, _I, _I, _V, _I, _V, _V, _I, _V]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the library once.  Raises M3Error if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise M3Error(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C m3vit_amd/csrc` (hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)       # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().m3_last_error()
+        raise M3Error(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

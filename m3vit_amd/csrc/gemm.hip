@@ -1,0 +1,244 @@
+// Grouped / dense "NT" GEMM for gfx950:  C[m,n] = epi( sum_k A[arow(m),k] * B[g][n,k] ).
+//
+// Replaces the per-expert cuBLAS loop behind FMoELinear (reference call sites
+// models/moe/ckpt/custom_moe_layer.py:32-33,41,43), the row gather/scatter of
+// MOEScatter/MOEGather (custom_moe_layer.py:263-265) which is fused into the operand
+// load / the store, and the nn.Linear GEMMs of the attention block and the dense Mlp
+// (models/moe/ckpt/vision_transformer_moe.py:255-261,295-313).
+//
+// Structure (one 128x128 output tile per 256-thread workgroup, 2x2 waves of 64x64):
+//   - both operands are K-contiguous, staged global -> VGPR -> LDS in 128-byte row
+//     slices (BK = 32 f32 / 64 f16), double-buffered, one barrier per K step;
+//   - LDS image is XOR-swizzled at 16-byte granularity (chunk ^= (row>>1)&7) so that the
+//     ds_read_b128 fragment reads of 16 different rows are bank-conflict free;
+//   - MFMA 16x16x32 f16 / 16x16x4 f32 (exact), fp32 accumulate; the weight tile is the
+//     MFMA "A" operand so that every lane ends up with 4 consecutive n of one row m
+//     and the epilogue uses 8/16-byte vector accesses;
+//   - grouped mode: workgroup -> (expert, m-tile) through the device-resident
+//     tile_starts prefix (no host sync), rows past the expert's end are zero-filled and
+//     never stored;
+//   - tile ids are remapped so that the n-tiles of one m-tile run on the same XCD (A rows
+//     come from HBM once, then from that XCD's L2).
+#include "common.h"
+
+namespace m3 {
+
+constexpr int BM = 128, BN = 128, ROWB = 128;  // ROWB: bytes of K per row per step
+constexpr int GEMM_THREADS = 256;
+
+struct GemmDev {
+  const char *A; int64_t lda_b;                 // byte strides
+  const int32_t *a_row_idx; int32_t a_row_div;
+  const char *B; int64_t ldb_b; int64_t b_group_b;
+  char *C; int64_t ldc; int32_t c_f32;
+  const int32_t *c_row_idx;
+  const float *bias;
+  char *pre_out; int64_t ld_pre;
+  const char *gpre; int64_t ld_gpre;
+  const float *residual; int64_t ld_res;
+  int32_t act;
+  int64_t M; int32_t N; int32_t K;
+  int32_t G;
+  const int32_t *group_offsets;
+  const int32_t *tile_starts;
+  int32_t n_tiles;
+  int32_t m_tiles_max;
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <typename T>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev p) {
+  typedef Mma<T> MM;
+  typedef typename MM::frag frag;
+  constexpr int BK = ROWB / (int)sizeof(T);
+  constexpr int CHUNKS = ROWB / 64;   // 64-byte fragments groups per row slice = 2
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [buf][A|B][128 rows * 128 B]
+  auto sA = [&](int buf) -> char * { return smem + buf * (2 * BM * ROWB); };
+  auto sB = [&](int buf) -> char * { return smem + buf * (2 * BM * ROWB) + BM * ROWB; };
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // ---- which tile
+  const int nwg = gridDim.x;
+  const int t = xcd_remap(blockIdx.x, nwg);
+  const int mt = t / p.n_tiles, nt = t - mt * p.n_tiles;
+  int g = 0;
+  int64_t m_begin, m_end;
+  if (p.tile_starts) {
+    const int total = p.tile_starts[p.G];
+    if (mt >= total) return;
+    while (g + 1 < p.G && p.tile_starts[g + 1] <= mt) ++g;
+    m_begin = (int64_t)p.group_offsets[g] + (int64_t)(mt - p.tile_starts[g]) * BM;
+    m_end = p.group_offsets[g + 1];
+  } else {
+    m_begin = (int64_t)mt * BM;
+    m_end = p.M;
+    if (m_begin >= m_end) return;
+  }
+  const int n0 = nt * BN;
+
+  // ---- per-thread staging assignment: 4 x 16-byte chunks per operand per step
+  // chunk q = tid + 256*i -> row = q >> 3 (0..127), c = q & 7
+  const char *a_src[4];
+  const char *b_src[4];
+  bool a_ok[4], b_ok[4];
+  const int c_stage = tid & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (tid >> 3) + 32 * i;
+    const int64_t m = m_begin + row;
+    a_ok[i] = m < m_end;
+    int64_t src = m;
+    if (a_ok[i] && p.a_row_idx) src = (int64_t)(p.a_row_idx[m] / p.a_row_div);
+    a_src[i] = p.A + (a_ok[i] ? src : 0) * p.lda_b + c_stage * 16;
+    const int n = n0 + row;
+    b_ok[i] = n < p.N;
+    b_src[i] = p.B + (int64_t)g * p.b_group_b + (int64_t)(b_ok[i] ? n : 0) * p.ldb_b + c_stage * 16;
+  }
+  const int kbytes = p.K * (int)sizeof(T);
+  const int nk = (kbytes + ROWB - 1) / ROWB;
+
+  u32x4 ra[4], rb[4];
+  auto load_global = [&](int ks) {
+    const int kb = ks * ROWB + c_stage * 16;
+    const bool kin = kb < kbytes;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = (a_ok[i] && kin) ? *(const u32x4 *)(a_src[i] + (int64_t)ks * ROWB) : u32x4{0u, 0u, 0u, 0u};
+      rb[i] = (b_ok[i] && kin) ? *(const u32x4 *)(b_src[i] + (int64_t)ks * ROWB) : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid >> 3) + 32 * i;
+      *(u32x4 *)(sA(buf) + lds_off(row, c_stage)) = ra[i];
+      *(u32x4 *)(sB(buf) + lds_off(row, c_stage)) = rb[i];
+    }
+  };
+
+  f32x4 acc[4][4];   // [ni][mi]: rows of the MFMA tile = n, cols = m
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_global(0);
+  store_lds(0);
+  __syncthreads();
+
+  for (int ks = 0; ks < nk; ++ks) {
+    const int buf = ks & 1;
+    if (ks + 1 < nk) load_global(ks + 1);
+#pragma unroll
+    for (int kc = 0; kc < CHUNKS; ++kc) {
+      frag fa[4], fb[4];
+      const int chunk = kc * 4 + lg;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rowa = wr * 64 + i * 16 + li;
+        const int rowb = wc * 64 + i * 16 + li;
+        fa[i] = *(const frag *)(sA(buf) + lds_off(rowa, chunk));
+        fb[i] = *(const frag *)(sB(buf) + lds_off(rowb, chunk));
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = MM::mma(fb[ni], fa[mi], acc[ni][mi]);
+    }
+    if (ks + 1 < nk) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds for tile (ni, mi): n = nb + 4*lg + r (r = 0..3), m = mb + li
+  const float *bias = p.bias ? p.bias + (int64_t)g * p.N : nullptr;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int64_t m = m_begin + wr * 64 + mi * 16 + li;
+    if (m >= m_end) continue;
+    const int64_t crow = p.c_row_idx ? (int64_t)p.c_row_idx[m] : m;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wc * 64 + ni * 16 + 4 * lg;
+      if (n >= p.N) continue;
+      f32x4 v = acc[ni][mi];
+      if (bias) {
+        const f32x4 bv = *(const f32x4 *)(bias + n);
+        v += bv;
+      }
+      if (p.pre_out) Vec4<T>::store((T *)p.pre_out + crow * p.ld_pre + n, v);
+      if (p.act == M3_ACT_GELU) {
+        v[0] = gelu_f(v[0]); v[1] = gelu_f(v[1]); v[2] = gelu_f(v[2]); v[3] = gelu_f(v[3]);
+      }
+      if (p.gpre) {
+        const f32x4 pr = Vec4<T>::load((const T *)p.gpre + crow * p.ld_gpre + n);
+        v[0] *= gelu_grad_f(pr[0]); v[1] *= gelu_grad_f(pr[1]);
+        v[2] *= gelu_grad_f(pr[2]); v[3] *= gelu_grad_f(pr[3]);
+      }
+      if (p.residual) v += *(const f32x4 *)(p.residual + crow * p.ld_res + n);
+      if (p.c_f32) *(f32x4 *)((float *)p.C + crow * p.ldc + n) = v;
+      else Vec4<T>::store((T *)p.C + crow * p.ldc + n, v);
+    }
+  }
+}
+
+}  // namespace m3
+
+using namespace m3;
+
+extern "C" int m3_gemm_nt(const m3_gemm_args *a, void *stream) {
+  M3_REQUIRE(a && a->A && a->B && a->C, "m3_gemm_nt: null operand");
+  M3_REQUIRE(a->dtype == M3_F32 || a->dtype == M3_F16, "m3_gemm_nt: bad dtype %d", a->dtype);
+  const int es = dtype_size(a->dtype);
+  M3_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0, "m3_gemm_nt: bad shape M=%lld N=%d K=%d", (long long)a->M, a->N, a->K);
+  M3_REQUIRE((a->K * es) % 16 == 0, "m3_gemm_nt: K*elem (%d) must be a multiple of 16 bytes", a->K * es);
+  M3_REQUIRE((a->lda * es) % 16 == 0 && (a->ldb * es) % 16 == 0, "m3_gemm_nt: lda/ldb rows must be 16-byte aligned");
+  M3_REQUIRE(((uintptr_t)a->A % 16) == 0 && ((uintptr_t)a->B % 16) == 0 && ((uintptr_t)a->C % 16) == 0,
+             "m3_gemm_nt: operands must be 16-byte aligned");
+  M3_REQUIRE(a->N % 4 == 0 && a->ldc % 4 == 0, "m3_gemm_nt: N and ldc must be multiples of 4");
+  M3_REQUIRE(a->lda >= a->K && a->ldb >= a->K && a->ldc >= a->N, "m3_gemm_nt: leading dimension too small");
+  M3_REQUIRE(a->c_dtype == M3_F32 || a->c_dtype == a->dtype, "m3_gemm_nt: c_dtype must be f32 or the operand dtype");
+  M3_REQUIRE(a->G >= 1, "m3_gemm_nt: G must be >= 1");
+  M3_REQUIRE((a->group_offsets == nullptr) == (a->tile_starts == nullptr), "m3_gemm_nt: group_offsets/tile_starts go together");
+  M3_REQUIRE(a->G == 1 || a->group_offsets, "m3_gemm_nt: grouped call needs group_offsets");
+  M3_REQUIRE(!a->a_row_idx || a->a_row_div >= 1, "m3_gemm_nt: a_row_div must be >= 1");
+  M3_REQUIRE(!a->pre_out || a->ld_pre % 4 == 0, "m3_gemm_nt: ld_pre % 4");
+  M3_REQUIRE(!a->gelu_grad_pre || a->ld_gpre % 4 == 0, "m3_gemm_nt: ld_gpre % 4");
+  M3_REQUIRE(!a->residual || a->ld_res % 4 == 0, "m3_gemm_nt: ld_res % 4");
+  if (a->M == 0) return M3_OK;
+
+  GemmDev d;
+  d.A = (const char *)a->A; d.lda_b = a->lda * es;
+  d.a_row_idx = a->a_row_idx; d.a_row_div = a->a_row_idx ? a->a_row_div : 1;
+  d.B = (const char *)a->B; d.ldb_b = a->ldb * es; d.b_group_b = (int64_t)a->N * a->ldb * es;
+  d.C = (char *)a->C; d.ldc = a->ldc; d.c_f32 = (a->c_dtype == M3_F32) ? 1 : 0;
+  d.c_row_idx = a->c_row_idx;
+  d.bias = a->bias;
+  d.pre_out = (char *)a->pre_out; d.ld_pre = a->ld_pre;
+  d.gpre = (const char *)a->gelu_grad_pre; d.ld_gpre = a->ld_gpre;
+  d.residual = a->residual; d.ld_res = a->ld_res;
+  d.act = a->act;
+  d.M = a->M; d.N = a->N; d.K = a->K; d.G = a->G;
+  d.group_offsets = a->group_offsets; d.tile_starts = a->tile_starts;
+  d.n_tiles = (a->N + BN - 1) / BN;
+  const int64_t mt = (a->M + BM - 1) / BM + (a->group_offsets ? a->G : 0);
+  M3_REQUIRE(mt * d.n_tiles < (int64_t)1 << 30, "m3_gemm_nt: grid too large");
+  d.m_tiles_max = (int)mt;
+  const dim3 grid((unsigned)(mt * d.n_tiles)), block(GEMM_THREADS);
+  const size_t lds = 4 * BM * ROWB;  // 64 KiB
+  hipStream_t s = (hipStream_t)stream;
+  if (a->dtype == M3_F16) {
+    hipLaunchKernelGGL(gemm_nt_kernel<half_t>, grid, block, lds, s, d);
+  } else {
+    hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, block, lds, s, d);
+  }
+  return check_launch("m3_gemm_nt");
+}

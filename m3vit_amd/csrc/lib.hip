@@ -1,0 +1,42 @@
+// Host-side plumbing of libm3vit_hip.so: error text, version, device query.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace m3 {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return M3_ERR_LAUNCH;
+  }
+  return M3_OK;
+}
+
+}  // namespace m3
+
+extern "C" int m3_version(void) { return 100; }   // 0.1.0
+
+extern "C" const char *m3_last_error(void) { return m3::g_err; }
+
+extern "C" int m3_device_query(char *name, int len) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { m3::set_error("m3_device_query: no HIP device"); return M3_ERR_LAUNCH; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { m3::set_error("m3_device_query: hipGetDeviceProperties failed"); return M3_ERR_LAUNCH; }
+  if (name && len > 0) {
+    strncpy(name, prop.gcnArchName, (size_t)len - 1);
+    name[len - 1] = 0;
+  }
+  return prop.multiProcessorCount;
+}

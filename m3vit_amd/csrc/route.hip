@@ -1,0 +1,132 @@
+// Dispatch metadata for top-k routing on gfx950: per-expert counts, exclusive offsets,
+// a STABLE slot for every (token, j) entry and the m-tile prefix the grouped GEMMs read.
+//
+// Replaces fastmoe's count_by_gate / assign_pos (prepare_forward) behind
+// _fmoe_general_global_forward, models/moe/ckpt/custom_moe_layer.py:263-265; same
+// information as compute_gating, models/moe/moe.py:19-64.  Everything stays on the
+// device (the reference syncs to the host for the counts); the order inside an expert is
+// increasing flat entry index, so results are run-to-run identical (fastmoe's is
+// atomics-ordered).
+//
+// Three tiny launches: block histograms -> one-block scan -> block-local stable ranks
+// (wave ballots; 64-wide).  Integer work, bit-exact against oracle/gate_route.c.
+#include "common.h"
+
+namespace m3 {
+
+constexpr int RT_THREADS = 256;
+constexpr int RT_PASSES = 4;
+constexpr int RT_BLOCK = RT_THREADS * RT_PASSES;   // entries per workgroup
+constexpr int RT_MAX_E = 256;
+
+__global__ __launch_bounds__(RT_THREADS) void route_hist_kernel(const int32_t *idx, int64_t n, int E,
+                                                                int32_t *blk_counts) {
+  __shared__ int32_t h[RT_MAX_E];
+  for (int e = threadIdx.x; e < E; e += RT_THREADS) h[e] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RT_BLOCK;
+#pragma unroll
+  for (int p = 0; p < RT_PASSES; ++p) {
+    const int64_t i = base + p * RT_THREADS + threadIdx.x;
+    if (i < n) {
+      const int e = idx[i];
+      if (e >= 0 && e < E) atomicAdd(&h[e], 1);
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += RT_THREADS) blk_counts[(int64_t)blockIdx.x * E + e] = h[e];
+}
+
+__global__ void route_scan_kernel(const int32_t *blk_counts, int nblk, int E, int32_t *blk_base, int32_t *counts,
+                                  int32_t *offsets, int32_t *tile_starts, int64_t *counts64) {
+  __shared__ int32_t tot[RT_MAX_E];
+  const int e = threadIdx.x;
+  if (e < E) {
+    int32_t run = 0;
+    for (int b = 0; b < nblk; ++b) {
+      blk_base[(int64_t)b * E + e] = run;
+      run += blk_counts[(int64_t)b * E + e];
+    }
+    tot[e] = run;
+    counts[e] = run;
+    if (counts64) counts64[e] = run;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t o = 0, ts = 0;
+    for (int i = 0; i < E; ++i) {
+      offsets[i] = o;
+      tile_starts[i] = ts;
+      o += tot[i];
+      ts += (tot[i] + 127) / 128;
+    }
+    offsets[E] = o;
+    tile_starts[E] = ts;
+  }
+}
+
+__global__ __launch_bounds__(RT_THREADS) void route_assign_kernel(const int32_t *idx, int64_t n, int E,
+                                                                  const int32_t *blk_base, const int32_t *offsets,
+                                                                  int32_t *pos, int32_t *row_of_slot) {
+  __shared__ int32_t run[RT_MAX_E];          // entries of expert e seen in earlier passes of this block
+  __shared__ int32_t wcnt[4][RT_MAX_E];      // per-wave counts of the current pass
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int e = threadIdx.x; e < E; e += RT_THREADS)
+    run[e] = offsets[e] + blk_base[(int64_t)blockIdx.x * E + e];
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RT_BLOCK;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int p = 0; p < RT_PASSES; ++p) {
+    const int64_t i = base + p * RT_THREADS + threadIdx.x;
+    int my = -1;
+    if (i < n) {
+      my = idx[i];
+      if (my < 0 || my >= E) my = -1;
+    }
+    int rank = 0;
+    for (int e = 0; e < E; ++e) {
+      const unsigned long long m = __ballot(my == e);
+      if (my == e) rank = __popcll(m & lt);
+      if (lane == 0) wcnt[wave][e] = __popcll(m);
+    }
+    __syncthreads();
+    if (my >= 0) {
+      int s = run[my] + rank;
+      for (int w = 0; w < wave; ++w) s += wcnt[w][my];
+      pos[i] = s;
+      row_of_slot[s] = (int32_t)i;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += RT_THREADS) run[e] += wcnt[0][e] + wcnt[1][e] + wcnt[2][e] + wcnt[3][e];
+    __syncthreads();
+  }
+}
+
+}  // namespace m3
+
+using namespace m3;
+
+static int64_t route_blocks(int64_t n) { return (n + RT_BLOCK - 1) / RT_BLOCK; }
+
+extern "C" int64_t m3_route_ws_elems(int64_t n, int E) { return 2 * route_blocks(n > 0 ? n : 1) * (int64_t)E; }
+
+extern "C" int m3_route_build(const int32_t *idx32, int64_t n, int E, int32_t *counts, int32_t *offsets, int32_t *pos,
+                              int32_t *row_of_slot, int32_t *tile_starts, int64_t *counts64, int32_t *ws,
+                              void *stream) {
+  M3_REQUIRE(idx32 && counts && offsets && pos && row_of_slot && tile_starts && ws, "m3_route_build: null operand");
+  M3_REQUIRE(E >= 1 && E <= RT_MAX_E, "m3_route_build: E=%d outside [1,%d]", E, RT_MAX_E);
+  M3_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), "m3_route_build: n out of range");
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = (int)route_blocks(n > 0 ? n : 1);
+  int32_t *blk_counts = ws, *blk_base = ws + (int64_t)nblk * E;
+  hipLaunchKernelGGL(route_hist_kernel, dim3(nblk), dim3(RT_THREADS), 0, s, idx32, n, E, blk_counts);
+  int rc = check_launch("m3_route_build(hist)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(route_scan_kernel, dim3(1), dim3(RT_MAX_E), 0, s, blk_counts, nblk, E, blk_base, counts, offsets,
+                     tile_starts, counts64);
+  rc = check_launch("m3_route_build(scan)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(route_assign_kernel, dim3(nblk), dim3(RT_THREADS), 0, s, idx32, n, E, blk_base, offsets, pos,
+                     row_of_slot);
+  return check_launch("m3_route_build(assign)");
+}

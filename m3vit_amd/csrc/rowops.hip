@@ -1,0 +1,398 @@
+// HBM-bound row kernels of the MoE-ViT block for gfx950: weighted combine of the k expert
+// outputs (+ residual), LayerNorm forward/backward on the fp32 residual stream, and the
+// small cast / patchify helpers.  One wave owns one token row; every access is a
+// 16-byte (fp32) or 8-byte (f16) vector per lane, fully coalesced along D.
+//
+//   combine : bmm(gate_score[T,1,k], moe_outp[T,k,D]), models/moe/ckpt/custom_moe_layer.py:298-305,
+//             fused with x = x + moe_output, models/moe/ckpt/vision_transformer_moe.py:450
+//   layernorm: norm1/norm2 = nn.LayerNorm(eps 1e-6), vision_transformer_moe.py:441-442,567
+//   im2row / assemble_tokens: PatchEmbed + cls/pos, vision_transformer_moe.py:330-341,782-791
+#include "common.h"
+
+namespace m3 {
+
+constexpr int ROW_THREADS = 256;   // 4 waves = 4 rows per workgroup
+
+// ------------------------------------------------------------------- combine
+template <typename T>
+__global__ __launch_bounds__(ROW_THREADS) void combine_fwd_kernel(const T *__restrict__ y, const float *__restrict__ score,
+                                                                  const float *__restrict__ residual, int64_t T_,
+                                                                  int k, int D, float *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
+  if (t >= T_) return;
+  const float *sc = score + t * k;
+  for (int d = lane * 4; d < D; d += 256) {
+    f32x4 acc = residual ? *(const f32x4 *)(residual + t * D + d) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < k; ++j) {
+      const f32x4 v = Vec4<T>::load(y + (t * k + j) * D + d);
+      const float s = sc[j];
+      acc[0] = __builtin_fmaf(s, v[0], acc[0]); acc[1] = __builtin_fmaf(s, v[1], acc[1]);
+      acc[2] = __builtin_fmaf(s, v[2], acc[2]); acc[3] = __builtin_fmaf(s, v[3], acc[3]);
+    }
+    *(f32x4 *)(out + t * D + d) = acc;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(ROW_THREADS) void combine_bwd_kernel(const float *__restrict__ dout, const T *__restrict__ y,
+                                                                  const float *__restrict__ score, int64_t T_, int k,
+                                                                  int D, T *__restrict__ dy, float *__restrict__ dscore) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
+  if (t >= T_) return;
+  for (int j = 0; j < k; ++j) {
+    const float s = score[t * k + j];
+    float dot = 0.f;
+    for (int d = lane * 4; d < D; d += 256) {
+      const f32x4 g = *(const f32x4 *)(dout + t * D + d);
+      const f32x4 v = Vec4<T>::load(y + (t * k + j) * D + d);
+      dot += g[0] * v[0] + g[1] * v[1] + g[2] * v[2] + g[3] * v[3];
+      Vec4<T>::store(dy + (t * k + j) * D + d, f32x4{s * g[0], s * g[1], s * g[2], s * g[3]});
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) dscore[t * k + j] = dot;
+  }
+}
+
+// ----------------------------------------------------------------- layernorm
+template <typename T>
+__global__ __launch_bounds__(ROW_THREADS) void layernorm_fwd_kernel(const float *__restrict__ x, int64_t T_, int D,
+                                                                    const float *__restrict__ gamma,
+                                                                    const float *__restrict__ beta, float eps,
+                                                                    T *__restrict__ y, float *__restrict__ mean,
+                                                                    float *__restrict__ rstd) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
+  if (t >= T_) return;
+  const float *xr = x + t * D;
+  // D <= 1024: at most 4 vectors per lane, kept in registers between the passes
+  f32x4 v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int d = lane * 4 + i * 256;
+    v[i] = (d < D) ? *(const f32x4 *)(xr + d) : f32x4{0.f, 0.f, 0.f, 0.f};
+    s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int d = lane * 4 + i * 256;
+    if (d < D) {
+      const f32x4 c = v[i] - mu;
+      q += c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3];
+    }
+  }
+  const float var = wave_sum(q) / (float)D;
+  const float rs = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int d = lane * 4 + i * 256;
+    if (d < D) {
+      const f32x4 g = *(const f32x4 *)(gamma + d), b = *(const f32x4 *)(beta + d);
+      const f32x4 o = (v[i] - mu) * rs * g + b;
+      Vec4<T>::store(y + t * D + d, o);
+    }
+  }
+  if (lane == 0) { mean[t] = mu; rstd[t] = rs; }
+}
+
+// dx = dx_res + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)); per-block partial
+// dgamma/dbeta (rows of a block summed in row order).
+constexpr int LNB_ROWS = 32;   // rows per workgroup in the backward (4 waves x 8 rows)
+
+template <typename T>
+__global__ __launch_bounds__(ROW_THREADS) void layernorm_bwd_kernel(const T *__restrict__ dy, const float *__restrict__ x,
+                                                                    const float *__restrict__ mean,
+                                                                    const float *__restrict__ rstd,
+                                                                    const float *__restrict__ gamma,
+                                                                    const float *__restrict__ dx_res, int64_t T_, int D,
+                                                                    float *__restrict__ dx, float *__restrict__ part) {
+  extern __shared__ float sred[];   // [4 waves][2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nblk = gridDim.x;
+  f32x4 dg[4], db[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { dg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; db[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int r = 0; r < LNB_ROWS / 4; ++r) {
+    const int64_t t = (int64_t)blockIdx.x * LNB_ROWS + wave * (LNB_ROWS / 4) + r;
+    if (t >= T_) break;
+    const float mu = mean[t], rs = rstd[t];
+    f32x4 gdy[4], xh[4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = lane * 4 + i * 256;
+      if (d < D) {
+        const f32x4 g = *(const f32x4 *)(gamma + d);
+        const f32x4 dyv = Vec4<T>::load(dy + t * D + d);
+        xh[i] = (*(const f32x4 *)(x + t * D + d) - mu) * rs;
+        gdy[i] = dyv * g;
+        s1 += gdy[i][0] + gdy[i][1] + gdy[i][2] + gdy[i][3];
+        s2 += gdy[i][0] * xh[i][0] + gdy[i][1] * xh[i][1] + gdy[i][2] * xh[i][2] + gdy[i][3] * xh[i][3];
+        dg[i] += dyv * xh[i];
+        db[i] += dyv;
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = lane * 4 + i * 256;
+      if (d < D) {
+        f32x4 o = (gdy[i] - m1 - xh[i] * m2) * rs;
+        if (dx_res) o += *(const f32x4 *)(dx_res + t * D + d);
+        *(f32x4 *)(dx + t * D + d) = o;
+      }
+    }
+  }
+  // block partials: waves in order
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int d = lane * 4 + i * 256;
+    if (d < D) {
+      *(f32x4 *)(sred + (wave * 2 + 0) * D + d) = dg[i];
+      *(f32x4 *)(sred + (wave * 2 + 1) * D + d) = db[i];
+    }
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += ROW_THREADS) {
+    float a = 0.f, b = 0.f;
+    for (int w = 0; w < 4; ++w) { a += sred[(w * 2 + 0) * D + d]; b += sred[(w * 2 + 1) * D + d]; }
+    part[(int64_t)blockIdx.x * D + d] = a;
+    part[((int64_t)nblk + blockIdx.x) * D + d] = b;
+  }
+}
+
+__global__ void ln_param_reduce_kernel(const float *part, int nblk, int D, float *dgamma, float *dbeta, int beta) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  float a = beta ? dgamma[d] : 0.f, b = beta ? dbeta[d] : 0.f;
+  for (int i = 0; i < nblk; ++i) { a += part[(int64_t)i * D + d]; b += part[((int64_t)nblk + i) * D + d]; }
+  dgamma[d] = a;
+  dbeta[d] = b;
+}
+
+// ------------------------------------------------------------------ cast helpers
+template <typename T>
+__global__ void cast_matrix_kernel(const float *__restrict__ src, int rows, int cols, int transpose, T *__restrict__ dst) {
+  // grid.z = group; tile 32x32 through LDS when transposing
+  __shared__ float tile[32][33];
+  const int64_t goff = (int64_t)blockIdx.z * rows * cols;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  if (!transpose) {
+    for (int i = ty; i < 32; i += 8) {
+      const int r = r0 + i, c = c0 + tx;
+      if (r < rows && c < cols) dst[goff + (int64_t)r * cols + c] = (T)src[goff + (int64_t)r * cols + c];
+    }
+    return;
+  }
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? src[goff + (int64_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;   // dst[c][r]
+    if (r < rows && c < cols) dst[goff + (int64_t)c * rows + r] = (T)tile[tx][i];
+  }
+}
+
+template <typename T>
+__global__ void cast_f32_kernel(const float *__restrict__ src, int64_t n4, T *__restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  Vec4<T>::store(dst + i * 4, *(const f32x4 *)(src + i * 4));
+}
+
+// rows[(b*hp + py)*wp + px][c*P*P + iy*P + ix] = img[b][c][py*P+iy][px*P+ix]
+template <typename T>
+__global__ void im2row_kernel(const float *__restrict__ img, int B, int Cin, int H, int W, int P, T *__restrict__ rows) {
+  const int hp = H / P, wp = W / P;
+  const int K = Cin * P * P;
+  const int64_t total4 = (int64_t)B * hp * wp * K / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i * 4;
+    const int64_t row = e / K;
+    const int kk = (int)(e - row * K);
+    const int c = kk / (P * P), rem = kk - c * P * P, iy = rem / P, ix = rem - iy * P;   // ix % 4 == 0 (P % 4 == 0)
+    const int px = (int)(row % wp), py = (int)((row / wp) % hp), b = (int)(row / ((int64_t)wp * hp));
+    const float *s = img + (((int64_t)b * Cin + c) * H + (py * P + iy)) * W + px * P + ix;
+    Vec4<T>::store(rows + e, *(const f32x4 *)s);
+  }
+}
+
+__global__ void assemble_tokens_kernel(const float *__restrict__ patch, const float *__restrict__ cls,
+                                       const float *__restrict__ pos, int B, int np_, int D, float *__restrict__ tok) {
+  const int N = np_ + 1;
+  const int64_t total4 = (int64_t)B * N * D / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i * 4;
+    const int d = (int)(e % D);
+    const int64_t r = e / D;
+    const int n = (int)(r % N), b = (int)(r / N);
+    const f32x4 p = *(const f32x4 *)(pos + (int64_t)n * D + d);
+    const f32x4 v = (n == 0) ? *(const f32x4 *)(cls + d) : *(const f32x4 *)(patch + ((int64_t)b * np_ + (n - 1)) * D + d);
+    *(f32x4 *)(tok + e) = v + p;
+  }
+}
+
+}  // namespace m3
+
+using namespace m3;
+
+static inline unsigned row_blocks(int64_t T) { return (unsigned)((T + 3) / 4); }
+
+extern "C" int m3_combine_fwd(const void *y, int dtype, const float *score, const float *residual, int64_t T, int k,
+                              int D, float *out, void *stream) {
+  M3_REQUIRE(y && score && out, "m3_combine_fwd: null operand");
+  M3_REQUIRE(dtype == M3_F32 || dtype == M3_F16, "m3_combine_fwd: bad dtype");
+  M3_REQUIRE(D % 4 == 0 && D > 0 && k >= 1, "m3_combine_fwd: D must be a multiple of 4");
+  if (T == 0) return M3_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == M3_F16)
+    hipLaunchKernelGGL(combine_fwd_kernel<half_t>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, (const half_t *)y,
+                       score, residual, T, k, D, out);
+  else
+    hipLaunchKernelGGL(combine_fwd_kernel<float>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, (const float *)y, score,
+                       residual, T, k, D, out);
+  return check_launch("m3_combine_fwd");
+}
+
+extern "C" int m3_combine_bwd(const float *dout, const void *y, int dtype, const float *score, int64_t T, int k, int D,
+                              void *dy, float *dscore, void *stream) {
+  M3_REQUIRE(dout && y && score && dy && dscore, "m3_combine_bwd: null operand");
+  M3_REQUIRE(dtype == M3_F32 || dtype == M3_F16, "m3_combine_bwd: bad dtype");
+  M3_REQUIRE(D % 4 == 0 && D > 0 && k >= 1, "m3_combine_bwd: D must be a multiple of 4");
+  if (T == 0) return M3_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == M3_F16)
+    hipLaunchKernelGGL(combine_bwd_kernel<half_t>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, dout,
+                       (const half_t *)y, score, T, k, D, (half_t *)dy, dscore);
+  else
+    hipLaunchKernelGGL(combine_bwd_kernel<float>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, dout, (const float *)y,
+                       score, T, k, D, (float *)dy, dscore);
+  return check_launch("m3_combine_bwd");
+}
+
+extern "C" int m3_layernorm_fwd(const float *x, int64_t T, int D, const float *gamma, const float *beta, float eps,
+                                void *y, int y_dtype, float *mean, float *rstd, void *stream) {
+  M3_REQUIRE(x && gamma && beta && y && mean && rstd, "m3_layernorm_fwd: null operand");
+  M3_REQUIRE(y_dtype == M3_F32 || y_dtype == M3_F16, "m3_layernorm_fwd: bad dtype");
+  M3_REQUIRE(D % 4 == 0 && D > 0 && D <= 1024, "m3_layernorm_fwd: D must be a multiple of 4 and <= 1024 (got %d)", D);
+  if (T == 0) return M3_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (y_dtype == M3_F16)
+    hipLaunchKernelGGL(layernorm_fwd_kernel<half_t>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, x, T, D, gamma, beta,
+                       eps, (half_t *)y, mean, rstd);
+  else
+    hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, x, T, D, gamma, beta,
+                       eps, (float *)y, mean, rstd);
+  return check_launch("m3_layernorm_fwd");
+}
+
+extern "C" int m3_ln_bwd_blocks(int64_t T) { return (int)((T + LNB_ROWS - 1) / LNB_ROWS); }
+
+extern "C" int m3_layernorm_bwd(const void *dy, int dy_dtype, const float *x, const float *mean, const float *rstd,
+                                const float *gamma, const float *dx_res, int64_t T, int D, float *dx, float *ws,
+                                float *dgamma, float *dbeta, int beta, void *stream) {
+  M3_REQUIRE(dy && x && mean && rstd && gamma && dx && ws && dgamma && dbeta, "m3_layernorm_bwd: null operand");
+  M3_REQUIRE(dy_dtype == M3_F32 || dy_dtype == M3_F16, "m3_layernorm_bwd: bad dtype");
+  M3_REQUIRE(D % 4 == 0 && D > 0 && D <= 1024, "m3_layernorm_bwd: D must be a multiple of 4 and <= 1024");
+  if (T == 0) return M3_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = m3_ln_bwd_blocks(T);
+  const size_t lds = (size_t)8 * D * sizeof(float);
+  if (dy_dtype == M3_F16)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<half_t>, dim3(nblk), dim3(ROW_THREADS), lds, s, (const half_t *)dy, x, mean,
+                       rstd, gamma, dx_res, T, D, dx, ws);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nblk), dim3(ROW_THREADS), lds, s, (const float *)dy, x, mean,
+                       rstd, gamma, dx_res, T, D, dx, ws);
+  int rc = check_launch("m3_layernorm_bwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((D + 255) / 256), dim3(256), 0, s, ws, nblk, D, dgamma, dbeta, beta);
+  return check_launch("m3_layernorm_bwd(reduce)");
+}
+
+extern "C" int m3_cast_matrix(const float *src, int G, int rows, int cols, int transpose, void *dst, int dst_dtype,
+                              void *stream) {
+  M3_REQUIRE(src && dst && G >= 1 && rows > 0 && cols > 0, "m3_cast_matrix: bad args");
+  M3_REQUIRE(dst_dtype == M3_F32 || dst_dtype == M3_F16, "m3_cast_matrix: bad dtype");
+  const dim3 grid((cols + 31) / 32, (rows + 31) / 32, G), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dst_dtype == M3_F16) hipLaunchKernelGGL(cast_matrix_kernel<half_t>, grid, block, 0, s, src, rows, cols, transpose, (half_t *)dst);
+  else hipLaunchKernelGGL(cast_matrix_kernel<float>, grid, block, 0, s, src, rows, cols, transpose, (float *)dst);
+  return check_launch("m3_cast_matrix");
+}
+
+extern "C" int m3_cast_f32(const float *src, int64_t n, void *dst, int dst_dtype, void *stream) {
+  M3_REQUIRE(src && dst && n >= 0 && n % 4 == 0, "m3_cast_f32: n must be a multiple of 4");
+  M3_REQUIRE(dst_dtype == M3_F32 || dst_dtype == M3_F16, "m3_cast_f32: bad dtype");
+  if (n == 0) return M3_OK;
+  const int64_t n4 = n / 4;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)((n4 + 255) / 256)), block(256);
+  if (dst_dtype == M3_F16) hipLaunchKernelGGL(cast_f32_kernel<half_t>, grid, block, 0, s, src, n4, (half_t *)dst);
+  else hipLaunchKernelGGL(cast_f32_kernel<float>, grid, block, 0, s, src, n4, (float *)dst);
+  return check_launch("m3_cast_f32");
+}
+
+extern "C" int m3_im2row(const float *img, int B, int Cin, int H, int W, int P, void *rows, int dtype, void *stream) {
+  M3_REQUIRE(img && rows, "m3_im2row: null operand");
+  M3_REQUIRE(dtype == M3_F32 || dtype == M3_F16, "m3_im2row: bad dtype");
+  M3_REQUIRE(P % 4 == 0 && H % P == 0 && W % P == 0 && W % 4 == 0, "m3_im2row: P, W must be multiples of 4; H, W multiples of P");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == M3_F16) hipLaunchKernelGGL(im2row_kernel<half_t>, dim3(2048), dim3(256), 0, s, img, B, Cin, H, W, P, (half_t *)rows);
+  else hipLaunchKernelGGL(im2row_kernel<float>, dim3(2048), dim3(256), 0, s, img, B, Cin, H, W, P, (float *)rows);
+  return check_launch("m3_im2row");
+}
+
+extern "C" int m3_assemble_tokens(const float *patch, const float *cls, const float *pos, int B, int np_, int D,
+                                  float *tokens, void *stream) {
+  M3_REQUIRE(patch && cls && pos && tokens && D % 4 == 0, "m3_assemble_tokens: bad args");
+  hipLaunchKernelGGL(assemble_tokens_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, patch, cls, pos, B, np_, D,
+                     tokens);
+  return check_launch("m3_assemble_tokens");
+}
+
+// ---- backward of assemble_tokens: dpatch (act dtype) = dtok[:,1:,:] ; dpos (+)= sum_b dtok ;
+// dcls (+)= sum_b dtok[:,0,:]
+namespace m3 {
+template <typename T>
+__global__ void tokens_bwd_kernel(const float *__restrict__ dtok, int B, int np_, int D, T *__restrict__ dpatch,
+                                  float *__restrict__ dpos, float *__restrict__ dcls, int beta) {
+  const int N = np_ + 1;
+  const int64_t total4 = (int64_t)N * D / 4;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int64_t e = i * 4;
+  const int n = (int)(e / D), d = (int)(e - (int64_t)n * D);
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < B; ++b) {
+    const f32x4 g = *(const f32x4 *)(dtok + ((int64_t)b * N + n) * D + d);
+    s += g;
+    if (n > 0 && dpatch) Vec4<T>::store(dpatch + ((int64_t)b * np_ + (n - 1)) * D + d, g);
+  }
+  f32x4 *pp = (f32x4 *)(dpos + e);
+  *pp = beta ? (*pp + s) : s;
+  if (n == 0) {
+    f32x4 *pc = (f32x4 *)(dcls + d);
+    *pc = beta ? (*pc + s) : s;
+  }
+}
+}  // namespace m3
+
+extern "C" int m3_tokens_bwd(const float *dtok, int B, int np_, int D, void *dpatch, int dtype, float *dpos,
+                             float *dcls, int beta, void *stream) {
+  M3_REQUIRE(dtok && dpos && dcls && D % 4 == 0, "m3_tokens_bwd: bad args");
+  M3_REQUIRE(dtype == M3_F32 || dtype == M3_F16, "m3_tokens_bwd: bad dtype");
+  const int64_t total4 = (int64_t)(np_ + 1) * D / 4;
+  const dim3 grid((unsigned)((total4 + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == M3_F16) hipLaunchKernelGGL(m3::tokens_bwd_kernel<m3::half_t>, grid, block, 0, s, dtok, B, np_, D, (m3::half_t *)dpatch, dpos, dcls, beta);
+  else hipLaunchKernelGGL(m3::tokens_bwd_kernel<float>, grid, block, 0, s, dtok, B, np_, D, (float *)dpatch, dpos, dcls, beta);
+  return m3::check_launch("m3_tokens_bwd");
+}

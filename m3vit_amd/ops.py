@@ -1,0 +1,280 @@
+"""Tensor-level wrappers over the C ABI (include/m3vit_hip.h).
+
+torch is used here only as the owner of device memory and streams: every function
+hands raw device pointers + sizes to libm3vit_hip.so and launches on torch's current
+HIP stream.  No function in this module computes anything with torch ops.
+"""
+from __future__ import annotations
+
+from ctypes import byref, c_void_p
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import M3_ACT_GELU, M3_ACT_NONE, M3_F16, M3_F32, GemmArgs, WgradArgs, check, lib
+
+_DT = {torch.float32: M3_F32, torch.float16: M3_F16}
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise _lib.M3Error(f"unsupported activation dtype {dtype}; use float32 or float16")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t: torch.Tensor, dtype=None, name="tensor"):
+    if not t.is_cuda:
+        raise _lib.M3Error(f"{name} must live on the GPU (no CPU path)")
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.M3Error(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.M3Error(f"{name} must be contiguous")
+    return t
+
+
+# ----------------------------------------------------------------------------- gate
+def gate_fwd(x, w_gate, k, logit_bias=None, noise=None, noise_std=0.0, dense=True, want_idx32=True):
+    """x [T,D] f32/f16, w_gate [D,E] f32 (rows beyond D are ignored: pass w_gate[:D] + bias for
+    task conditioning).  Returns dict with idx i64 [T,k], idx32, score, top_logits, clean, noisy,
+    gates (dense only), importance f32 [E], load i64 [E]."""
+    _req(x, name="x"); _req(w_gate, torch.float32, "w_gate")
+    T, D = x.shape
+    E = w_gate.shape[1]
+    assert w_gate.shape[0] == D
+    dev = x.device
+    kp = min(k + 1, E)
+    idx = torch.empty((T, k), dtype=torch.int64, device=dev)
+    idx32 = torch.empty((T, k), dtype=torch.int32, device=dev) if want_idx32 else None
+    score = torch.empty((T, k), dtype=torch.float32, device=dev)
+    top = torch.empty((T, kp), dtype=torch.float32, device=dev)
+    clean = torch.empty((T, E), dtype=torch.float32, device=dev) if dense else None
+    noisy = torch.empty((T, E), dtype=torch.float32, device=dev) if dense else None
+    gates = torch.empty((T, E), dtype=torch.float32, device=dev) if dense else None
+    nblk = lib().m3_gate_num_blocks(T)
+    pi = torch.empty((max(nblk, 1), E), dtype=torch.float32, device=dev)
+    pl = torch.empty((max(nblk, 1), E), dtype=torch.int32, device=dev)
+    imp = torch.empty(E, dtype=torch.float32, device=dev)
+    load = torch.empty(E, dtype=torch.int64, device=dev)
+    if logit_bias is not None:
+        _req(logit_bias, torch.float32, "logit_bias")
+    if noise is not None:
+        _req(noise, torch.float32, "noise")
+    check(lib().m3_gate_fwd(_p(x), dt_code(x.dtype), T, D, x.stride(0), _p(w_gate), E, _p(logit_bias), _p(noise),
+                            float(noise_std), k, _p(idx), _p(idx32), _p(score), _p(top), _p(clean), _p(noisy),
+                            _p(gates), _p(pi), _p(pl), _stream()), "m3_gate_fwd")
+    check(lib().m3_gate_reduce(_p(pi), _p(pl), nblk, E, _p(imp), _p(load), _stream()), "m3_gate_reduce")
+    return dict(idx=idx, idx32=idx32, score=score, top_logits=top, clean=clean, noisy=noisy, gates=gates,
+                importance=imp, load=load)
+
+
+def gate_bwd_logits(noisy, idx, d_score, d_importance, k):
+    T, E = noisy.shape
+    dl = torch.empty_like(noisy)
+    check(lib().m3_gate_bwd_logits(_p(noisy), _p(idx), _p(d_score), _p(d_importance), T, E, k, _p(dl), _stream()),
+          "m3_gate_bwd_logits")
+    return dl
+
+
+def gate_bwd_params(x, w_gate, d_logits, d_w_gate=None, beta_dw=0, dx=None, beta_dx=0, part_dw=None):
+    T, D = x.shape
+    E = w_gate.shape[1]
+    if d_w_gate is not None and part_dw is None:
+        part_dw = torch.empty((lib().m3_gate_dw_blocks(T), D, E), dtype=torch.float32, device=x.device)
+    check(lib().m3_gate_bwd_params(_p(x), dt_code(x.dtype), T, D, x.stride(0), _p(w_gate), E, _p(d_logits),
+                                   _p(part_dw) if d_w_gate is not None else None, _p(d_w_gate), beta_dw,
+                                   _p(dx), dx.stride(0) if dx is not None else 0, beta_dx, _stream()),
+          "m3_gate_bwd_params")
+
+
+# ---------------------------------------------------------------------------- route
+class Route:
+    """Device-resident dispatch metadata (no host sync)."""
+    __slots__ = ("counts", "offsets", "pos", "row_of_slot", "tile_starts", "counts64", "n", "E", "k")
+
+
+def route_build(idx32: torch.Tensor, E: int, want_counts64=False) -> Route:
+    _req(idx32, torch.int32, "idx32")
+    n = idx32.numel()
+    dev = idx32.device
+    r = Route()
+    r.n, r.E, r.k = n, E, idx32.shape[-1] if idx32.dim() > 1 else 1
+    r.counts = torch.empty(E, dtype=torch.int32, device=dev)
+    r.offsets = torch.empty(E + 1, dtype=torch.int32, device=dev)
+    r.pos = torch.empty(n, dtype=torch.int32, device=dev)
+    r.row_of_slot = torch.empty(n, dtype=torch.int32, device=dev)
+    r.tile_starts = torch.empty(E + 1, dtype=torch.int32, device=dev)
+    r.counts64 = torch.empty(E, dtype=torch.int64, device=dev) if want_counts64 else None
+    ws = torch.empty(int(lib().m3_route_ws_elems(n, E)), dtype=torch.int32, device=dev)
+    check(lib().m3_route_build(_p(idx32), n, E, _p(r.counts), _p(r.offsets), _p(r.pos), _p(r.row_of_slot),
+                               _p(r.tile_starts), _p(r.counts64), _p(ws), _stream()), "m3_route_build")
+    return r
+
+
+# ----------------------------------------------------------------------------- GEMM
+def gemm_nt(A, B, C, *, M=None, bias=None, act=M3_ACT_NONE, pre_out=None, gelu_grad_pre=None, residual=None,
+            a_row_idx=None, a_row_div=1, c_row_idx=None, group_offsets=None, tile_starts=None):
+    """C[m,n] = epi(sum_k A[arow(m),k] B[g][n,k]).  A [rows,K]; B [N,K] or [G,N,K]; C [rows,N] (f32 or A.dtype)."""
+    _req(A, name="A"); _req(B, A.dtype, "B"); _req(C, name="C")
+    G = 1 if B.dim() == 2 else B.shape[0]
+    N, K = B.shape[-2], B.shape[-1]
+    a = GemmArgs()
+    a.A = A.data_ptr(); a.lda = A.stride(0)
+    a.a_row_idx = a_row_idx.data_ptr() if a_row_idx is not None else None
+    a.a_row_div = a_row_div
+    a.B = B.data_ptr(); a.ldb = B.stride(-2)
+    a.C = C.data_ptr(); a.ldc = C.stride(0); a.c_dtype = dt_code(C.dtype)
+    a.c_row_idx = c_row_idx.data_ptr() if c_row_idx is not None else None
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.pre_out = pre_out.data_ptr() if pre_out is not None else None
+    a.ld_pre = pre_out.stride(0) if pre_out is not None else 0
+    a.gelu_grad_pre = gelu_grad_pre.data_ptr() if gelu_grad_pre is not None else None
+    a.ld_gpre = gelu_grad_pre.stride(0) if gelu_grad_pre is not None else 0
+    a.residual = residual.data_ptr() if residual is not None else None
+    a.ld_res = residual.stride(0) if residual is not None else 0
+    a.act = act
+    if M is None:
+        M = a_row_idx.numel() if a_row_idx is not None else A.shape[0]
+    a.M = M; a.N = N; a.K = K; a.G = G
+    a.group_offsets = group_offsets.data_ptr() if group_offsets is not None else None
+    a.tile_starts = tile_starts.data_ptr() if tile_starts is not None else None
+    a.dtype = dt_code(A.dtype)
+    if bias is not None:
+        _req(bias, torch.float32, "bias")
+    if residual is not None:
+        _req(residual, torch.float32, "residual")
+    check(lib().m3_gemm_nt(byref(a), _stream()), "m3_gemm_nt")
+    return C
+
+
+def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None, a_row_idx=None, a_row_div=1,
+             group_offsets=None):
+    """dW[g][n,k] (+)= sum_m dC[crow(m),n] A[arow(m),k].  dW f32 [N,K] or [G,N,K]."""
+    _req(dC, name="dC"); _req(A, dC.dtype, "A"); _req(dW, torch.float32, "dW")
+    G = 1 if dW.dim() == 2 else dW.shape[0]
+    N, K = dW.shape[-2], dW.shape[-1]
+    if M is None:
+        M = dC.shape[0]
+    if splits is None:
+        splits = default_wgrad_splits(M, N, K, G)
+    if ws is None:
+        ws = torch.empty(splits * G * N * K, dtype=torch.float32, device=dW.device)
+    assert ws.numel() >= splits * G * N * K
+    a = WgradArgs()
+    a.dC = dC.data_ptr(); a.lddc = dC.stride(0)
+    a.c_row_idx = c_row_idx.data_ptr() if c_row_idx is not None else None
+    a.A = A.data_ptr(); a.lda = A.stride(0)
+    a.a_row_idx = a_row_idx.data_ptr() if a_row_idx is not None else None
+    a.a_row_div = a_row_div
+    a.M = M; a.N = N; a.K = K; a.G = G
+    a.group_offsets = group_offsets.data_ptr() if group_offsets is not None else None
+    a.splits = splits
+    a.ws = ws.data_ptr()
+    a.dtype = dt_code(dC.dtype)
+    check(lib().m3_wgrad_tn(byref(a), _stream()), "m3_wgrad_tn")
+    check(lib().m3_wgrad_reduce(_p(ws), splits, G * N * K, _p(dW), beta, _stream()), "m3_wgrad_reduce")
+    return dW
+
+
+def default_wgrad_splits(M, N, K, G):
+    tiles = ((N + 127) // 128) * ((K + 127) // 128) * G
+    steps = max(1, (M // max(G, 1) + 31) // 32)
+    s = max(1, min(steps, (768 + tiles - 1) // tiles))
+    return int(s)
+
+
+def colsum(dC, db, *, M=None, beta=0, c_row_idx=None, group_offsets=None, ws=None):
+    _req(dC, name="dC"); _req(db, torch.float32, "db")
+    G = 1 if db.dim() == 1 else db.shape[0]
+    N = db.shape[-1]
+    if M is None:
+        M = dC.shape[0]
+    need = int(lib().m3_colsum_ws_elems(M, N, G))
+    if ws is None:
+        ws = torch.empty(need, dtype=torch.float32, device=dC.device)
+    assert ws.numel() >= need
+    check(lib().m3_colsum(_p(dC), dt_code(dC.dtype), dC.stride(0), _p(c_row_idx), M, N, G, _p(group_offsets),
+                          _p(ws), _p(db), beta, _stream()), "m3_colsum")
+    return db
+
+
+# -------------------------------------------------------------------- combine / LN
+def combine_fwd(y, score, residual, out):
+    T, k = score.shape
+    D = y.shape[-1]
+    check(lib().m3_combine_fwd(_p(y), dt_code(y.dtype), _p(score), _p(residual), T, k, D, _p(out), _stream()),
+          "m3_combine_fwd")
+    return out
+
+
+def combine_bwd(dout, y, score, dy, dscore):
+    T, k = score.shape
+    D = y.shape[-1]
+    check(lib().m3_combine_bwd(_p(dout), _p(y), dt_code(y.dtype), _p(score), T, k, D, _p(dy), _p(dscore), _stream()),
+          "m3_combine_bwd")
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps=1e-6):
+    T, D = x.shape
+    check(lib().m3_layernorm_fwd(_p(x), T, D, _p(gamma), _p(beta), float(eps), _p(y), dt_code(y.dtype), _p(mean),
+                                 _p(rstd), _stream()), "m3_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx_res, dx, dgamma, dbeta, beta=0, ws=None):
+    T, D = x.shape
+    nblk = lib().m3_ln_bwd_blocks(T)
+    if ws is None:
+        ws = torch.empty(2 * nblk * D, dtype=torch.float32, device=x.device)
+    check(lib().m3_layernorm_bwd(_p(dy), dt_code(dy.dtype), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx_res), T, D,
+                                 _p(dx), _p(ws), _p(dgamma), _p(dbeta), beta, _stream()), "m3_layernorm_bwd")
+
+
+# ------------------------------------------------------------------------ attention
+def attention_fwd(qkv, B, N, heads, dh, o, lse):
+    check(lib().m3_attention_fwd(_p(qkv), dt_code(qkv.dtype), B, N, heads, dh, _p(o), _p(lse), _stream()),
+          "m3_attention_fwd")
+
+
+def attention_bwd(qkv, o, d_o, lse, B, N, heads, dh, dqkv):
+    check(lib().m3_attention_bwd(_p(qkv), _p(o), _p(d_o), _p(lse), dt_code(qkv.dtype), B, N, heads, dh, _p(dqkv),
+                                 _stream()), "m3_attention_bwd")
+
+
+# ---------------------------------------------------------------------- elementwise
+def cast_matrix(src, dst, transpose=False):
+    """src f32 [G,R,C] or [R,C] -> dst (act dtype) same shape, or [G,C,R] when transpose."""
+    G = 1 if src.dim() == 2 else src.shape[0]
+    R, C = src.shape[-2], src.shape[-1]
+    check(lib().m3_cast_matrix(_p(src), G, R, C, 1 if transpose else 0, _p(dst), dt_code(dst.dtype), _stream()),
+          "m3_cast_matrix")
+    return dst
+
+
+def cast_f32(src, dst):
+    check(lib().m3_cast_f32(_p(src), src.numel(), _p(dst), dt_code(dst.dtype), _stream()), "m3_cast_f32")
+    return dst
+
+
+def im2row(img, P, rows):
+    B, Cin, H, W = img.shape
+    check(lib().m3_im2row(_p(img), B, Cin, H, W, P, _p(rows), dt_code(rows.dtype), _stream()), "m3_im2row")
+    return rows
+
+
+def assemble_tokens(patch, cls, pos, B, np_, D, tokens):
+    check(lib().m3_assemble_tokens(_p(patch), _p(cls), _p(pos), B, np_, D, _p(tokens), _stream()), "m3_assemble_tokens")
+    return tokens
+
+
+def tokens_bwd(dtok, B, np_, D, dpatch, dpos, dcls, beta=0):
+    check(lib().m3_tokens_bwd(_p(dtok), B, np_, D, _p(dpatch), dt_code(dpatch.dtype) if dpatch is not None else M3_F32,
+                              _p(dpos), _p(dcls), beta, _stream()), "m3_tokens_bwd")

@@ -1,0 +1,389 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): every HIP kernel, called through
+the C ABI (m3vit_amd.ops -> libm3vit_hip.so), against
+  * the oracle's C restatement for index/slot work (bit-exact),
+  * the committed golden vectors from the reference's pure-torch twins,
+  * a plain torch fp64 reference of the same op on the same (dtype-rounded) inputs.
+Tolerances: fp32 path 2e-5 relative L2; fp16 storage path 1e-3 relative L2 (north_star:
+"outputs within 1e-3 rel-err", bit-exact top-k indices)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.float16]
+TOL = {torch.float32: 2e-5, torch.float16: 1e-3}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from m3vit_amd import ops as _ops
+    return _ops
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a = a.double().flatten()
+    b = b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev())
+
+
+def gelu64(x):
+    return 0.5 * x * (1 + torch.erf(x / 2 ** 0.5))
+
+
+def gelu_grad64(x):
+    return 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * np.pi) ** 0.5
+
+
+# ------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(300, 384, 384), (197, 1152, 384), (128, 128, 64), (1000, 384, 1536), (5, 8, 8)])
+def test_gemm_dense_plain(ops, dtype, M, N, K):
+    A, B = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, scale=0.05, seed=2)
+    C = torch.full((M, N), float("nan"), dtype=dtype, device=dev())
+    ops.gemm_nt(A, B, C)
+    ref = A.double() @ B.double().t()
+    assert rel(C, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(ops, dtype):
+    M, N, K = 333, 256, 192
+    A, B = rnd(M, K, dtype=dtype, seed=3), rnd(N, K, dtype=dtype, scale=0.08, seed=4)
+    bias = rnd(N, seed=5, scale=0.1)
+    res = rnd(M, N, seed=6)
+    gpre = rnd(M, N, dtype=dtype, seed=7)
+    lin = A.double() @ B.double().t() + bias.double()
+    # bias + GELU, pre-activation saved
+    C = torch.empty(M, N, dtype=dtype, device=dev()); pre = torch.empty_like(C)
+    ops.gemm_nt(A, B, C, bias=bias, act=ops.M3_ACT_GELU, pre_out=pre)
+    assert rel(pre, lin) < TOL[dtype]
+    assert rel(C, gelu64(lin)) < TOL[dtype]
+    # bias + residual, fp32 out
+    C32 = torch.empty(M, N, dtype=torch.float32, device=dev())
+    ops.gemm_nt(A, B, C32, bias=bias, residual=res)
+    assert rel(C32, lin + res.double()) < TOL[dtype]
+    # dgrad epilogue: * gelu'(pre)
+    C2 = torch.empty(M, N, dtype=dtype, device=dev())
+    ops.gemm_nt(A, B, C2, gelu_grad_pre=gpre)
+    assert rel(C2, (A.double() @ B.double().t()) * gelu_grad64(gpre.double())) < TOL[dtype]
+
+
+def _golden(name):
+    from conftest import GOLDEN
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_grouped_linear_golden_parallel_linear(ops, dtype):
+    """FMoELinear fwd / dgrad / wgrad / bias-grad against the reference's ParallelLinear (g4):
+    ragged counts with an empty expert."""
+    g = _golden("g4_grouped_linear")
+    counts = torch.tensor(g["counts"])
+    E = len(counts)
+    x = torch.tensor(g["x"]).to(dtype).to(dev())
+    W = torch.tensor(g["w_in_out"]).transpose(1, 2).contiguous().to(dtype).to(dev())    # [E,out,in]
+    b = torch.tensor(g["b"]).to(dev())
+    gy = torch.tensor(g["gy"]).to(dtype).to(dev())
+    # routing that yields exactly these expert-major rows
+    idx32 = torch.repeat_interleave(torch.arange(E), counts).to(torch.int32).to(dev()).view(-1, 1)
+    r = ops.route_build(idx32, E)
+    assert r.counts.cpu().tolist() == counts.tolist()
+    R, Dout = x.shape[0], W.shape[1]
+    y = torch.empty(R, Dout, dtype=dtype, device=dev())
+    ops.gemm_nt(x, W, y, M=R, bias=b, group_offsets=r.offsets, tile_starts=r.tile_starts)
+    tol = TOL[dtype] * (3 if dtype == torch.float16 else 1)
+    assert rel(y, torch.tensor(g["y"])) < tol
+    # dgrad: dx = gy @ W  (NT with the transposed weight copy)
+    Wt = W.transpose(1, 2).contiguous()
+    dx = torch.empty_like(x)
+    ops.gemm_nt(gy, Wt, dx, M=R, group_offsets=r.offsets, tile_starts=r.tile_starts)
+    assert rel(dx, torch.tensor(g["dx"])) < tol
+    dW = torch.empty(E, Dout, x.shape[1], dtype=torch.float32, device=dev())
+    ops.wgrad_tn(gy, x, dW, M=R, group_offsets=r.offsets, splits=3)
+    assert rel(dW, torch.tensor(g["dw_in_out"]).transpose(1, 2)) < tol
+    db = torch.empty(E, Dout, dtype=torch.float32, device=dev())
+    ops.colsum(gy, db, M=R, group_offsets=r.offsets)
+    assert rel(db, torch.tensor(g["db"])) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_grouped_gemm_gather_scatter(ops, dtype):
+    T, k, D, H, E = 700, 4, 384, 384, 16
+    g = torch.Generator().manual_seed(11)
+    idx = torch.stack([torch.randperm(E, generator=g)[:k] for _ in range(T)]).to(torch.int32).to(dev())
+    x = rnd(T, D, dtype=dtype, seed=12)
+    W = rnd(E, H, D, dtype=dtype, scale=0.05, seed=13)
+    b = rnd(E, H, scale=0.1, seed=14)
+    r = ops.route_build(idx, E)
+    R = T * k
+    hid = torch.full((R, H), float("nan"), dtype=dtype, device=dev())
+    ops.gemm_nt(x, W, hid, M=R, bias=b, a_row_idx=r.row_of_slot, a_row_div=k, group_offsets=r.offsets,
+                tile_starts=r.tile_starts)
+    ros = r.row_of_slot.long()
+    e_of_slot = idx.flatten().long()[ros]
+    ref = torch.einsum("rd,rhd->rh", x.double()[ros // k], W.double()[e_of_slot]) + b.double()[e_of_slot]
+    assert rel(hid, ref) < TOL[dtype]
+    # token-major scatter of the output
+    out = torch.full((R, H), float("nan"), dtype=dtype, device=dev())
+    ops.gemm_nt(x, W, out, M=R, bias=b, a_row_idx=r.row_of_slot, a_row_div=k, c_row_idx=r.row_of_slot,
+                group_offsets=r.offsets, tile_starts=r.tile_starts)
+    ref_tm = torch.empty_like(ref); ref_tm[ros] = ref
+    assert rel(out, ref_tm) < TOL[dtype]
+    # grouped wgrad with gathers on both operands
+    gy = rnd(R, H, dtype=dtype, seed=15)            # token-major grads
+    dW = torch.empty(E, H, D, dtype=torch.float32, device=dev())
+    ops.wgrad_tn(gy, x, dW, M=R, c_row_idx=r.row_of_slot, a_row_idx=r.row_of_slot, a_row_div=k,
+                 group_offsets=r.offsets)
+    ref_dw = torch.zeros(E, H, D, dtype=torch.float64, device=dev())
+    ref_dw.index_add_(0, idx.flatten().long(), torch.einsum("rh,rd->rhd", gy.double(), x.double().repeat_interleave(k, 0)))
+    assert rel(dW, ref_dw) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wgrad_dense_and_colsum(ops, dtype):
+    M, N, K = 2000, 384, 256
+    dC, A = rnd(M, N, dtype=dtype, seed=21), rnd(M, K, dtype=dtype, seed=22)
+    dW = rnd(N, K, seed=23)
+    base = dW.clone()
+    ops.wgrad_tn(dC, A, dW, beta=1)
+    assert rel(dW, base.double() + dC.double().t() @ A.double()) < TOL[dtype]
+    db = torch.empty(N, dtype=torch.float32, device=dev())
+    ops.colsum(dC, db)
+    assert rel(db, dC.double().sum(0)) < TOL[dtype]
+
+
+# ------------------------------------------------------------------------------ gate
+@pytest.mark.parametrize("name", ["g1_gate_e16", "g1_gate_e64", "g2b_gate_noise"])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gate_golden(ops, name, dtype):
+    from oracle import c_oracle
+    g = _golden(name)
+    k = int(g["k"])
+    x = torch.tensor(g["x"]).to(dtype).to(dev())
+    w = torch.tensor(g["w_gate"]).to(dev())
+    noise = torch.tensor(g["noise"]).to(dev()) if "noise" in g else None
+    std = float(g["std"]) / w.shape[1] if "noise" in g else 0.0
+    out = ops.gate_fwd(x, w, k, noise=noise, noise_std=std)
+    c = c_oracle.gate_fwd(x.float().cpu().numpy(), g["w_gate"], k, noise=g.get("noise"), std=std)
+    assert np.array_equal(out["idx"].cpu().numpy(), c["idx"])            # bit-exact vs the oracle
+    assert np.array_equal(out["clean"].cpu().numpy(), c["clean"])        # same fma chain
+    np.testing.assert_allclose(out["score"].cpu().numpy(), c["score"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(out["top_logits"].cpu().numpy(), c["top_logits"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(out["gates"].cpu().numpy(), c["gates"], rtol=1e-5, atol=1e-7)
+    if dtype == torch.float32:                                           # and vs the reference twin
+        assert np.array_equal(out["idx"].cpu().numpy(), g["idx"])
+        np.testing.assert_allclose(out["score"].cpu().numpy(), g["score"], rtol=2e-5, atol=1e-7)
+    imp = torch.tensor(c["gates"]).sum(0)
+    np.testing.assert_allclose(out["importance"].cpu().numpy(), imp.numpy(), rtol=1e-5)
+    assert out["load"].cpu().tolist() == (torch.tensor(c["gates"]) > 0).sum(0).tolist()
+
+
+def test_gate_task_conditioned_bias_form(ops):
+    from oracle import c_oracle
+    g = _golden("g2_gate_taskcond")
+    k = int(g["k"]); D = g["x"].shape[1]
+    x = torch.tensor(g["x"]).to(dev())
+    w = torch.tensor(g["w_gate"]).to(dev())
+    bias_np = c_oracle.gate_fwd(g["tsf"][None, :], g["w_gate"][D:], 1)["clean"][0]
+    out = ops.gate_fwd(x, w[:D].contiguous(), k, logit_bias=torch.tensor(bias_np).to(dev()))
+    assert np.array_equal(out["idx"].cpu().numpy(), g["idx"])
+    np.testing.assert_allclose(out["score"].cpu().numpy(), g["score"], rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gate_full_size_bit_exact_and_route(ops, dtype):
+    """BASELINE config 2 size: T = 128*197 tokens, D = 384, E = 16, k = 4."""
+    from oracle import c_oracle
+    T, D, E, k = 128 * 197, 384, 16, 4
+    x = rnd(T, D, dtype=dtype, seed=31)
+    w = (torch.rand(D, E, generator=torch.Generator().manual_seed(32)) - 0.5).mul(0.1).to(dev())
+    out = ops.gate_fwd(x, w, k, dense=False)
+    c = c_oracle.gate_fwd(x.float().cpu().numpy(), w.cpu().numpy(), k, dense=False)
+    assert np.array_equal(out["idx"].cpu().numpy(), c["idx"])
+    assert np.array_equal(out["idx32"].cpu().numpy(), c["idx"].astype(np.int32))
+    r = ops.route_build(out["idx32"], E, want_counts64=True)
+    cc, co, cp, cr = c_oracle.route_build(c["idx"], E)
+    assert np.array_equal(r.counts.cpu().numpy(), cc) and np.array_equal(r.counts64.cpu().numpy(), cc)
+    assert np.array_equal(r.offsets.cpu().numpy(), co)
+    assert np.array_equal(r.pos.cpu().numpy(), cp)
+    assert np.array_equal(r.row_of_slot.cpu().numpy(), cr)
+    ts = np.concatenate([[0], np.cumsum((cc + 127) // 128)])
+    assert np.array_equal(r.tile_starts.cpu().numpy(), ts)
+    assert out["load"].cpu().numpy().sum() == T * k
+
+
+def test_route_edge_cases(ops):
+    from oracle import c_oracle
+    for n, E in [(1, 4), (255, 3), (1024, 64), (1025, 16), (5000, 1)]:
+        idx = torch.randint(0, E, (n, 1), generator=torch.Generator().manual_seed(n)).to(torch.int32)
+        if E > 2:
+            idx[idx == 1] = 0                      # an empty expert
+        r = ops.route_build(idx.to(dev()), E)
+        cc, co, cp, cr = c_oracle.route_build(idx.numpy(), E)
+        assert np.array_equal(r.counts.cpu().numpy(), cc)
+        assert np.array_equal(r.pos.cpu().numpy(), cp)
+        assert np.array_equal(r.row_of_slot.cpu().numpy(), cr)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gate_backward(ops, dtype):
+    T, D, E, k = 1000, 384, 16, 4
+    x = rnd(T, D, dtype=dtype, seed=41)
+    w = rnd(D, E, scale=0.05, seed=42)
+    out = ops.gate_fwd(x, w, k)
+    d_score = rnd(T, k, seed=43)
+    d_imp = rnd(E, seed=44)
+    dl = ops.gate_bwd_logits(out["noisy"], out["idx"], d_score, d_imp, k)
+    xr = x.double().requires_grad_()
+    wr = w.double().requires_grad_()
+    p = torch.softmax(xr @ wr, 1)
+    sc = p.gather(1, out["idx"])
+    gates = torch.zeros_like(p).scatter(1, out["idx"], sc)
+    loss = (sc * d_score.double()).sum() + (gates.sum(0) * d_imp.double()).sum()
+    logits = (xr @ wr)
+    dl_ref, = torch.autograd.grad(loss, [p], retain_graph=True)
+    loss.backward()
+    # reference d_logits through softmax
+    pd = p.detach()
+    dl_ref_logits = pd * (dl_ref - (dl_ref * pd).sum(1, keepdim=True))
+    assert rel(dl, dl_ref_logits) < 1e-4
+    dw = torch.empty(D, E, dtype=torch.float32, device=dev())
+    dx = rnd(T, D, seed=45)
+    dx0 = dx.clone()
+    ops.gate_bwd_params(x, w, dl, d_w_gate=dw, dx=dx, beta_dx=1)
+    assert rel(dw, wr.grad) < 1e-4
+    assert rel(dx - dx0, xr.grad) < 1e-4
+
+
+# ----------------------------------------------------------------- combine / layernorm
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_combine_fwd_bwd(ops, dtype):
+    T, k, D = 1003, 4, 384
+    y = rnd(T * k, D, dtype=dtype, seed=51)
+    score = torch.rand(T, k, generator=torch.Generator().manual_seed(52)).to(dev())
+    res = rnd(T, D, seed=53)
+    out = torch.empty(T, D, dtype=torch.float32, device=dev())
+    ops.combine_fwd(y, score, res, out)
+    ref = torch.bmm(score.double().view(T, 1, k), y.double().view(T, k, D)).view(T, D) + res.double()
+    assert rel(out, ref) < 1e-6
+    dout = rnd(T, D, seed=54)
+    dy = torch.empty_like(y); ds = torch.empty_like(score)
+    ops.combine_bwd(dout, y, score, dy, ds)
+    assert rel(dy, (score.double().view(T, k, 1) * dout.double().view(T, 1, D)).view(T * k, D)) < TOL[dtype]
+    assert rel(ds, (y.double().view(T, k, D) * dout.double().view(T, 1, D)).sum(-1)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("D", [384, 768, 192])
+def test_layernorm_fwd_bwd(ops, dtype, D):
+    T = 517
+    x = rnd(T, D, seed=61) * 2 + 0.3
+    gamma, beta = 1 + rnd(D, seed=62, scale=0.1), rnd(D, seed=63, scale=0.1)
+    y = torch.empty(T, D, dtype=dtype, device=dev())
+    mean = torch.empty(T, device=dev()); rstd = torch.empty(T, device=dev())
+    ops.layernorm_fwd(x, gamma, beta, y, mean, rstd)
+    xr = x.double().requires_grad_(); gr = gamma.double().requires_grad_(); br = beta.double().requires_grad_()
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    assert rel(y, ref) < TOL[dtype]
+    dy = rnd(T, D, dtype=dtype, seed=64)
+    dres = rnd(T, D, seed=65)
+    ref.backward(dy.double())
+    dx = torch.empty_like(x); dg = rnd(D, seed=66); db = rnd(D, seed=67)
+    dg0, db0 = dg.clone(), db.clone()
+    ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, dg, db, beta=1)
+    assert rel(dx, xr.grad + dres.double()) < 2e-5
+    assert rel(dg - dg0, gr.grad) < 1e-4
+    assert rel(db - db0, br.grad) < 1e-4
+
+
+# ------------------------------------------------------------------------- attention
+def _attn_ref(qkv, B, N, h, dh):
+    q, k, v = qkv.view(B, N, 3, h, dh).permute(2, 0, 3, 1, 4)
+    a = torch.softmax((q @ k.transpose(-2, -1)) * dh ** -0.5, dim=-1)
+    return (a @ v).transpose(1, 2).reshape(B * N, h * dh), a
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,N,h,dh", [(2, 197, 12, 32), (1, 50, 3, 32), (1, 256, 2, 64), (2, 65, 4, 64)])
+def test_attention_fwd_bwd(ops, dtype, B, N, h, dh):
+    C = h * dh
+    qkv = rnd(B * N, 3 * C, dtype=dtype, seed=71)
+    o = torch.full((B * N, C), float("nan"), dtype=dtype, device=dev())
+    lse = torch.empty(B, h, N, device=dev())
+    ops.attention_fwd(qkv, B, N, h, dh, o, lse)
+    qr = qkv.double().requires_grad_()
+    ref, a = _attn_ref(qr, B, N, h, dh)
+    assert rel(o, ref) < TOL[dtype]
+    q, k, _ = qr.detach().view(B, N, 3, h, dh).permute(2, 0, 3, 1, 4)
+    lse_ref = torch.logsumexp((q @ k.transpose(-2, -1)) * dh ** -0.5, dim=-1)
+    assert rel(lse, lse_ref) < 1e-5
+    d_o = rnd(B * N, C, dtype=dtype, seed=72)
+    ref.backward(d_o.double())
+    dqkv = torch.full_like(qkv, float("nan"))
+    ops.attention_bwd(qkv, o, d_o, lse, B, N, h, dh, dqkv)
+    tol = TOL[dtype] * (2 if dtype == torch.float16 else 1)
+    assert rel(dqkv, qr.grad) < tol
+
+
+def test_attention_fwd_long_sequence(ops):
+    B, N, h, dh = 1, 1201, 3, 64          # cfg-5 sequence length (480x640)
+    qkv = rnd(B * N, 3 * h * dh, dtype=torch.float16, seed=73)
+    o = torch.empty(B * N, h * dh, dtype=torch.float16, device=dev())
+    lse = torch.empty(B, h, N, device=dev())
+    ops.attention_fwd(qkv, B, N, h, dh, o, lse)
+    ref, _ = _attn_ref(qkv.double(), B, N, h, dh)
+    assert rel(o, ref) < 1e-3
+
+
+# ----------------------------------------------------------------------- elementwise
+def test_cast_and_patchify(ops):
+    src = rnd(3, 70, 45, seed=81)
+    dst = torch.empty(3, 45, 70, dtype=torch.float16, device=dev())
+    ops.cast_matrix(src, dst, transpose=True)
+    assert torch.equal(dst, src.transpose(1, 2).to(torch.float16))
+    dst2 = torch.empty(3, 70, 45, dtype=torch.float32, device=dev())
+    ops.cast_matrix(src, dst2)
+    assert torch.equal(dst2, src)
+    img = rnd(2, 3, 32, 48, seed=82)
+    P = 16
+    rows = torch.empty(2 * 2 * 3, 3 * P * P, dtype=torch.float32, device=dev())
+    ops.im2row(img, P, rows)
+    w = rnd(24, 3, P, P, seed=83, scale=0.05)
+    conv = torch.nn.functional.conv2d(img.double(), w.double(), stride=P).flatten(2).transpose(1, 2).reshape(-1, 24)
+    assert rel(rows.double() @ w.double().view(24, -1).t(), conv) < 1e-12
+    cls, pos = rnd(24, seed=84), rnd(7, 24, seed=85)
+    patch = rnd(12, 24, seed=86)
+    tok = torch.empty(2, 7, 24, device=dev())
+    ops.assemble_tokens(patch, cls, pos, 2, 6, 24, tok)
+    ref = torch.cat((cls.view(1, 1, 24).expand(2, 1, 24), patch.view(2, 6, 24)), 1) + pos
+    assert torch.allclose(tok, ref)
+    dtok = rnd(2, 7, 24, seed=87)
+    dpatch = torch.empty(12, 24, device=dev()); dpos = torch.empty(7, 24, device=dev()); dcls = torch.empty(24, device=dev())
+    ops.tokens_bwd(dtok, 2, 6, 24, dpatch, dpos, dcls)
+    assert torch.allclose(dpatch.view(2, 6, 24), dtok[:, 1:])
+    assert torch.allclose(dpos, dtok.sum(0), atol=1e-6) and torch.allclose(dcls, dtok[:, 0].sum(0), atol=1e-6)
+
+
+def test_errors_are_loud(ops):
+    from m3vit_amd._lib import M3Error
+    A = rnd(8, 6, seed=1); B = rnd(8, 6, seed=2); C = torch.empty(8, 8, device=dev())
+    with pytest.raises(M3Error):
+        ops.gemm_nt(A, B, C)                        # K*4 = 24 bytes: not a multiple of 16
+    with pytest.raises(M3Error):
+        ops.gate_fwd(rnd(4, 8, seed=1), rnd(8, 100, seed=2), 2)   # E > 64
+    with pytest.raises(M3Error):
+        ops.gemm_nt(A.cpu(), B, C)                  # no CPU path
