@@ -31,7 +31,7 @@ def dev():
 
 def rel(a, b):
     a = a.double().flatten()
-    b = b.double().flatten()
+    b = b.double().flatten().to(a.device)
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
