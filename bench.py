@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec, forward+backward, ViT-S/16 + MoE (E=16, top-k=4, multi-gate),
+224x224, batch 128 per GPU (BASELINE.json configs[1]), synthetic data, random-init weights.
+
+    python bench.py --gpus N --steps K --warmup W [--dtype f16|f32] [--batch 128]
+
+One "step" = what one reference training iteration does to the backbone for one batch
+(train/train_utils.py:423-457, multi_gate joint path; models/models.py:299-301): refresh the
+operand copies of the weights, then for EACH of the 2 tasks one full backbone forward (task's
+gate) and one full backward (d tokens + 0.01 * cv_loss), gradients accumulated; for N > 1 the
+gradients are then all-reduced over RCCL (replicated-experts data parallel, the reference's
+--moe_data_distributed mode, utils/common_config.py:179-181).  Decoder heads / losses are out
+of scope: d tokens is a fixed synthetic tensor.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK = {"f16": 2500.0, "f32": 157.3}      # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+CV_WEIGHT = 0.01                           # moe_noisy_gate_loss_weight (CLAUDE.md:66-70)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", choices=["f16", "f32"], default="f16")
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    return ap.parse_args()
+
+
+class GemmTimer:
+    """HIP-event timing of every m3_gemm_nt launch (events on the launch stream)."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.orig = ops.gemm_nt
+        self.records = []       # (start, end, flops, grouped)
+
+    def __enter__(self):
+        def timed(A, B, C, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = self.orig(A, B, C, **kw)
+            e.record()
+            M = kw.get("M")
+            if M is None:
+                M = kw["a_row_idx"].numel() if kw.get("a_row_idx") is not None else A.shape[0]
+            self.records.append((s, e, 2.0 * M * B.shape[-2] * B.shape[-1], kw.get("group_offsets") is not None))
+            return r
+        self.ops.gemm_nt = timed
+        return self
+
+    def __exit__(self, *a):
+        self.ops.gemm_nt = self.orig
+
+    def summary(self):
+        tot_ms = tot_fl = g_ms = g_fl = 0.0
+        for s, e, fl, grouped in self.records:
+            ms = s.elapsed_time(e)
+            tot_ms += ms; tot_fl += fl
+            if grouped:
+                g_ms += ms; g_fl += fl
+        n = len(self.records)
+        return dict(launches=n, avg_us=1e3 * tot_ms / max(n, 1), tflops=tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0,
+                    flops_per_launch=tot_fl / max(n, 1),
+                    grouped_launches=sum(1 for r in self.records if r[3]),
+                    grouped_tflops=g_fl / (g_ms * 1e-3) / 1e12 if g_ms else 0.0)
+
+
+def cpu_baseline(cfg_kwargs, batch, threads):
+    """Oracle (torch fp32 CPU restatement, 'port') timed on the host cores for one step on a bounded
+    sample (`batch` images, both task passes, fwd+bwd)."""
+    from oracle import ref_torch as R
+    torch.set_num_threads(threads)
+    cfg = R.BackboneCfg(**cfg_kwargs)
+    P = {k: v.requires_grad_() for k, v in R.init_backbone_params(cfg, seed=1).items()}
+    img = torch.randn(batch, 3, *cfg.img_size)
+    dtok = torch.randn(batch, cfg.num_tokens, cfg.embed_dim)
+
+    def step():
+        loss = 0.0
+        for task in range(cfg.num_tasks):
+            tok, cv, _ = R.backbone_forward(P, cfg, img, task)
+            loss = loss + (tok * dtok).sum() + CV_WEIGHT * cv
+        loss.backward()
+        for p in P.values():
+            p.grad = None
+    step()                                  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 2 or time.perf_counter() - t0 < 10.0:
+        step(); n += 1
+    dt = (time.perf_counter() - t0) / n
+    return batch / dt, n
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from m3vit_amd import ops
+    from m3vit_amd.config import VIT_SMALL_MOE, BackboneConfig, init_params
+    from m3vit_amd.engine import BackboneEngine
+
+    cfg = BackboneConfig(**VIT_SMALL_MOE)
+    dtype = torch.float16 if args.dtype == "f16" else torch.float32
+    params = init_params(cfg, seed=1)                       # same weights on every rank
+    eng = BackboneEngine(cfg, params, batch=args.batch, dtype=dtype, device=str(dev))
+    g = torch.Generator().manual_seed(1000 + rank)          # each rank its own images
+    images = torch.randn(args.batch, 3, *cfg.img_size, generator=g).to(dev)
+    dtok = (torch.randn(args.batch, cfg.num_tokens, cfg.embed_dim, generator=g) * 0.05).to(dev)
+    ntasks = cfg.num_tasks
+
+    flat = None
+    if world > 1:
+        # one flat fp32 gradient bucket so the data-parallel sync is a single RCCL all-reduce
+        total = sum(v.numel() for v in eng.grads.values())
+        flat = torch.zeros(total, device=dev)
+        o = 0
+        for n_, v in list(eng.grads.items()):
+            eng.grads[n_] = flat[o:o + v.numel()].view_as(v)
+            o += v.numel()
+
+    def step():
+        eng.prepare_weights()
+        eng.zero_grad()
+        for task in range(ntasks):
+            eng.forward(images, task)
+            eng.backward(dtok, cv_weight=CV_WEIGHT)
+        if world > 1:
+            dist.all_reduce(flat)
+            flat.div_(world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    log("engine ready")
+    for i in range(args.warmup):
+        step()
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ms_per_step = 1e3 * dt / args.steps
+    log(f"timed region done: {ms_per_step:.2f} ms/step")
+    value = world * args.batch * args.steps / dt
+
+    # ---- roofline of the dominant kernel (gemm_nt_kernel: every Linear / FMoELinear fwd + dgrad),
+    # measured with HIP events around each launch in a few extra instrumented steps
+    with GemmTimer(ops) as gt:
+        for _ in range(min(3, args.steps)):
+            step()
+        torch.cuda.synchronize()
+    gs = gt.summary()
+    peak = PEAK[args.dtype]
+    roofline = {"kernel": "gemm_nt_kernel", "bound": "mfma", "achieved": round(gs["tflops"], 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(gs["tflops"] / peak, 4), "traffic": None,
+                "avg_launch_us": round(gs["avg_us"], 2), "launches_per_step": gs["launches"] // min(3, args.steps),
+                "flops_per_launch": gs["flops_per_launch"],
+                "expert_grouped_gemm_tflops": round(gs["grouped_tflops"], 2),
+                "expert_grouped_gemm_frac": round(gs["grouped_tflops"] / peak, 4)}
+
+    step_flops = 3.0 * cfg.fwd_flops_per_image() * args.batch * ntasks
+    out = {
+        "metric": "images/sec fwd+bwd ViT-S/16 MoE(E=16,k=4) 224^2 bs=128",
+        "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "configs[1]: ViT-Small/16 + MoE E=16 top-k=4 multi_gate, synthetic 224x224",
+                   "batch_per_gpu": args.batch, "global_batch": args.batch * world, "task_passes": ntasks,
+                   "tokens_per_image": cfg.num_tokens, "cv_loss_weight": CV_WEIGHT,
+                   "parallelism": "single" if world == 1 else f"dp{world} (replicated experts, RCCL all-reduce)"},
+        "model_tflops": round(step_flops * args.steps / dt / 1e12 * world, 2),
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        cores = max(1, min(cores, 16))          # the GPU box gives one GPU a 16-core share
+        v, n = cpu_baseline(VIT_SMALL_MOE, args.cpu_batch, cores)
+        out["cpu_baseline"] = {"value": round(v, 3), "unit": "images/s", "cores": cores, "kind": "port",
+                               "sample": f"{n} full steps (2 task passes fwd+bwd, fp32 torch CPU oracle) at batch "
+                                         f"{args.cpu_batch}, scaled per image"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,314 @@
+"""Fused forward/backward executor for the MoE-ViT backbone hot path on one MI355X.
+
+Host-side mirror of VisionTransformerMoE.forward_features / Block / Attention /
+FMoETransformerMLP (models/moe/ckpt/vision_transformer_moe.py:283-313,438-487,780-880,
+models/moe/ckpt/custom_moe_layer.py:161-322) as a straight-line sequence of HIP kernel
+launches on one stream, with no host synchronisation anywhere (the reference has ~9
+`.item()` syncs per MoE block plus fastmoe's count `.cpu()`):
+
+  * fp32 master parameters (reference state_dict names/shapes), fp32 residual stream,
+    activations feeding MFMA stored in the activation dtype (fp16 or fp32);
+  * every Linear is the hand-written NT GEMM; dgrads use transposed operand copies of
+    the weights that are refreshed once per step by `prepare_weights()`;
+  * the MoE MLP is gate -> route_build -> grouped FC1 (+bias+GELU, row gather fused into
+    the A load) -> grouped FC2 (+bias, scatter to token-major fused into the store) ->
+    combine (+residual);
+  * activations needed by the backward are kept resident (288 GB HBM: a whole ViT-S pass
+    at batch 128 is ~5 GB), nothing is recomputed (the reference's
+    --use_checkpointing False mode, run_exps.sh:17).
+
+torch is used for buffer ownership and for the O(E) cv-loss arithmetic only.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .ops import M3_ACT_GELU
+
+
+class _Cfg:
+    """Duck-typed config: any object with the attribute names of oracle.BackboneCfg /
+    the VisionTransformerMoE ctor works (img_size, patch_size, in_chans, embed_dim, depth,
+    num_heads, mlp_ratio, moe_mlp_ratio, moe_experts, moe_top_k, gate_dim, multi_gate,
+    gate_task_specific_dim, vmoe_noisy_std)."""
+
+
+def cv_squared(x: torch.Tensor) -> torch.Tensor:
+    """cv_squared, models/moe/ckpt/vision_transformer_moe.py:73-87 (O(E) scalar math)."""
+    if x.shape[0] == 1:
+        return torch.zeros((), device=x.device)
+    x = x.float()
+    return x.var() / (x.mean() ** 2 + 1e-10)
+
+
+def cv_squared_grad(x: torch.Tensor) -> torch.Tensor:
+    """d cv_squared(x) / dx, closed form (unbiased variance)."""
+    E = x.shape[0]
+    if E == 1:
+        return torch.zeros_like(x)
+    m = x.mean()
+    v = x.var()
+    den = m * m + 1e-10
+    return 2.0 * (x - m) / ((E - 1) * den) - v * (2.0 * m / E) / (den * den)
+
+
+class BackboneEngine:
+    def __init__(self, cfg, params: Dict[str, torch.Tensor], batch: int, dtype=torch.float16,
+                 device="cuda:0"):
+        self.cfg = cfg
+        self.dev = torch.device(device)
+        self.dt = dtype
+        self.B = batch
+        self.D = cfg.embed_dim
+        self.heads = cfg.num_heads
+        self.dh = self.D // self.heads
+        self.P = cfg.patch_size
+        self.hp, self.wp = cfg.img_size[0] // self.P, cfg.img_size[1] // self.P
+        self.np_ = self.hp * self.wp
+        self.N = self.np_ + 1
+        self.T = self.B * self.N
+        self.E = cfg.moe_experts
+        self.k = cfg.moe_top_k
+        self.Hd = int(self.D * cfg.mlp_ratio)
+        self.Hm = int(self.D * cfg.moe_mlp_ratio)
+        self.R = self.T * self.k
+        self.depth = cfg.depth
+        self.params = {n: p.to(self.dev, torch.float32).contiguous() for n, p in params.items()}
+        self.grads = {n: torch.zeros_like(p) for n, p in self.params.items()}
+        self.is_moe = [i % 2 == 1 for i in range(self.depth)]
+        self._alloc()
+        self.prepare_weights()
+
+    # ------------------------------------------------------------------ buffers
+    def _e(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.dt, device=self.dev)
+
+    def _alloc(self):
+        T, D, R = self.T, self.D, self.R
+        f32 = torch.float32
+        self.act = []
+        for i in range(self.depth):
+            a = {}
+            a["x_in"] = None                                   # alias of previous block's output
+            a["mean1"], a["rstd1"] = self._e(T, dtype=f32), self._e(T, dtype=f32)
+            a["h1"] = self._e(T, D)
+            a["qkv"] = self._e(T, 3 * D)
+            a["o"] = self._e(T, D)
+            a["lse"] = self._e(self.B, self.heads, self.N, dtype=f32)
+            a["x1"] = self._e(T, D, dtype=f32)
+            a["mean2"], a["rstd2"] = self._e(T, dtype=f32), self._e(T, dtype=f32)
+            a["h2"] = self._e(T, D)
+            if self.is_moe[i]:
+                a["hid_pre"] = self._e(R, self.Hm)
+                a["hid"] = self._e(R, self.Hm)
+                a["y"] = self._e(R, D)
+            else:
+                a["pre"] = self._e(T, self.Hd)
+                a["u"] = self._e(T, self.Hd)
+            a["x2"] = self._e(T, D, dtype=f32)
+            self.act.append(a)
+        Kp = self.cfg.in_chans * self.P * self.P
+        self.rows = self._e(self.B * self.np_, Kp)
+        self.patch = self._e(self.B * self.np_, D, dtype=f32)
+        self.x0 = self._e(T, D, dtype=f32)
+        # backward scratch (reused by every block)
+        Hmax = max(self.Hd, self.Hm)
+        self.s_dxa = self._e(T, D, dtype=f32)
+        self.s_dxb = self._e(T, D, dtype=f32)
+        self.s_dx_t = self._e(T, D)
+        self.s_dpre = self._e(max(T * self.Hd, R * self.Hm))
+        self.s_dh = self._e(T, D)
+        self.s_dh32 = self._e(T, D, dtype=f32)
+        self.s_do = self._e(T, D)
+        self.s_dqkv = self._e(T, 3 * D)
+        self.s_dy = self._e(R, D)
+        self.s_dxe = self._e(R, D)
+        self.s_dscore = self._e(T, self.k, dtype=f32)
+        self.s_dpatch = self._e(self.B * self.np_, D)
+        self.ones_k = torch.ones(T, self.k, dtype=f32, device=self.dev)
+        # shared workspaces
+        wg = 0
+        for (M, N, K, G) in [(T, self.Hd, D, 1), (T, D, self.Hd, 1), (T, 3 * D, D, 1), (T, D, D, 1),
+                             (R, self.Hm, D, self.E), (R, D, self.Hm, self.E), (self.B * self.np_, D, Kp, 1)]:
+            wg = max(wg, ops.default_wgrad_splits(M, N, K, G) * G * N * K)
+        self.ws_wgrad = self._e(wg, dtype=f32)
+        cs = max(int(ops.lib().m3_colsum_ws_elems(T, 3 * D, 1)), int(ops.lib().m3_colsum_ws_elems(T, self.Hd, 1)),
+                 int(ops.lib().m3_colsum_ws_elems(R, max(self.Hm, D), self.E)))
+        self.ws_colsum = self._e(cs, dtype=f32)
+        self.ws_ln = self._e(2 * ops.lib().m3_ln_bwd_blocks(T) * D, dtype=f32)
+        self.ws_gate_dw = self._e(ops.lib().m3_gate_dw_blocks(T) * self.cfg_d_gate() * self.E, dtype=f32)
+
+    def cfg_d_gate(self):
+        g = self.cfg.gate_task_specific_dim
+        return self.D if g < 0 else self.D + g
+
+    # ------------------------------------------------------------- weight copies
+    def _linear_names(self):
+        names = ["patch_embed.proj"]
+        for i in range(self.depth):
+            b = f"blocks.{i}."
+            names += [b + "attn.qkv", b + "attn.proj"]
+            if self.is_moe[i]:
+                names += [b + "mlp.experts.htoh4", b + "mlp.experts.h4toh"]
+            else:
+                names += [b + "mlp.fc1", b + "mlp.fc2"]
+        return names
+
+    def prepare_weights(self):
+        """Refresh the activation-dtype operand copies W [.., N, K] and W^T [.., K, N] of every
+        Linear / FMoELinear weight from the fp32 masters (once per optimizer step)."""
+        if not hasattr(self, "wc"):
+            self.wc, self.wt = {}, {}
+            for n in self._linear_names():
+                w = self.params[n + ".weight"]
+                w2 = w.reshape(w.shape[0], -1) if n == "patch_embed.proj" else w
+                self.wc[n] = w2 if self.dt == torch.float32 else torch.empty_like(w2, dtype=self.dt)
+                if n != "patch_embed.proj":
+                    self.wt[n] = torch.empty(*w2.shape[:-2], w2.shape[-1], w2.shape[-2], dtype=self.dt, device=self.dev)
+        for n in self._linear_names():
+            w = self.params[n + ".weight"]
+            w2 = w.reshape(w.shape[0], -1) if n == "patch_embed.proj" else w
+            if self.dt != torch.float32:
+                ops.cast_matrix(w2, self.wc[n], transpose=False)
+            if n in self.wt:
+                ops.cast_matrix(w2, self.wt[n], transpose=True)
+
+    def zero_grad(self):
+        for g in self.grads.values():
+            g.zero_()
+
+    # ------------------------------------------------------------------ forward
+    def _gate_weight(self, i, task_id):
+        b = f"blocks.{i}.mlp.gate."
+        if self.cfg.multi_gate:
+            return b + f"{task_id}.w_gate"           # custom_moe_layer.py:213-214
+        return b + "w_gate"
+
+    def forward(self, images: torch.Tensor, task_id: Optional[int], tsf_bias=None, noises=None):
+        """Returns (tokens fp32 [B,N,D], total_cv_loss).  tsf_bias: per-MoE-block logit bias for the
+        task-conditioned gate (tsf @ w_gate[D:]); noises: {block: [T,E]} caller-supplied N(0,1)."""
+        P_, p = self.P, self.params
+        B, T, D = self.B, self.T, self.D
+        ops.im2row(images, P_, self.rows)
+        ops.gemm_nt(self.rows, self.wc["patch_embed.proj"], self.patch, bias=p["patch_embed.proj.bias"])
+        ops.assemble_tokens(self.patch, p["cls_token"], p["pos_embed"], B, self.np_, D, self.x0)
+        x = self.x0
+        total_cv = torch.zeros((), device=self.dev)
+        self.task_id = task_id
+        for i in range(self.depth):
+            a = self.act[i]
+            b = f"blocks.{i}."
+            a["x_in"] = x
+            ops.layernorm_fwd(x, p[b + "norm1.weight"], p[b + "norm1.bias"], a["h1"], a["mean1"], a["rstd1"])
+            ops.gemm_nt(a["h1"], self.wc[b + "attn.qkv"], a["qkv"], bias=p[b + "attn.qkv.bias"])
+            ops.attention_fwd(a["qkv"], B, self.N, self.heads, self.dh, a["o"], a["lse"])
+            ops.gemm_nt(a["o"], self.wc[b + "attn.proj"], a["x1"], bias=p[b + "attn.proj.bias"], residual=x)
+            ops.layernorm_fwd(a["x1"], p[b + "norm2.weight"], p[b + "norm2.bias"], a["h2"], a["mean2"], a["rstd2"])
+            if not self.is_moe[i]:
+                ops.gemm_nt(a["h2"], self.wc[b + "mlp.fc1"], a["u"], bias=p[b + "mlp.fc1.bias"], act=M3_ACT_GELU,
+                            pre_out=a["pre"])
+                ops.gemm_nt(a["u"], self.wc[b + "mlp.fc2"], a["x2"], bias=p[b + "mlp.fc2.bias"], residual=a["x1"])
+            else:
+                wname = self._gate_weight(i, task_id)
+                a["wname"] = wname
+                wg = p[wname]
+                wg_tok = wg if wg.shape[0] == D else wg[:D]
+                noise = None if noises is None else noises.get(i)
+                std = (self.cfg.vmoe_noisy_std / self.E) if noise is not None else 0.0
+                g = ops.gate_fwd(a["h2"], wg_tok, self.k, logit_bias=None if tsf_bias is None else tsf_bias[i],
+                                 noise=noise, noise_std=std, dense=True)
+                a["gate"] = g
+                r = ops.route_build(g["idx32"], self.E)
+                a["route"] = r
+                ops.gemm_nt(a["h2"], self.wc[b + "mlp.experts.htoh4"], a["hid"], M=self.R,
+                            bias=p[b + "mlp.experts.htoh4.bias"], act=M3_ACT_GELU, pre_out=a["hid_pre"],
+                            a_row_idx=r.row_of_slot, a_row_div=self.k, group_offsets=r.offsets,
+                            tile_starts=r.tile_starts)
+                ops.gemm_nt(a["hid"], self.wc[b + "mlp.experts.h4toh"], a["y"], M=self.R,
+                            bias=p[b + "mlp.experts.h4toh.bias"], c_row_idx=r.row_of_slot, group_offsets=r.offsets,
+                            tile_starts=r.tile_starts)
+                ops.combine_fwd(a["y"], g["score"], a["x1"], a["x2"])
+                # cv_loss = cv^2(importance) + cv^2(load)   (vision_transformer_moe.py:453-459,540)
+                total_cv = total_cv + cv_squared(g["importance"]) + cv_squared(g["load"].float())
+            x = a["x2"]
+        return x.view(B, self.N, D), total_cv
+
+    # ----------------------------------------------------------------- backward
+    def _wgrad(self, dC, A, name, M=None, **kw):
+        ops.wgrad_tn(dC, A, self.grads[name], M=M, beta=1, ws=self.ws_wgrad, **kw)
+
+    def backward(self, d_tokens: torch.Tensor, cv_weight: float = 0.0):
+        """Accumulates parameter gradients of  <tokens, d_tokens> + cv_weight * total_cv_loss
+        into self.grads (beta = 1: the joint multi-task backward, train/train_utils.py:437-457)."""
+        p, gr = self.params, self.grads
+        B, T, D, R, k = self.B, self.T, self.D, self.R, self.k
+        dx = self.s_dxa
+        dx.copy_(d_tokens.reshape(T, D))
+        other = self.s_dxb
+        for i in reversed(range(self.depth)):
+            a = self.act[i]
+            b = f"blocks.{i}."
+            if not self.is_moe[i]:
+                ops.cast_f32(dx, self.s_dx_t)
+                dpre = self.s_dpre[: T * self.Hd].view(T, self.Hd)
+                self._wgrad(self.s_dx_t, a["u"], b + "mlp.fc2.weight")
+                ops.colsum(self.s_dx_t, gr[b + "mlp.fc2.bias"], beta=1, ws=self.ws_colsum)
+                ops.gemm_nt(self.s_dx_t, self.wt[b + "mlp.fc2"], dpre, gelu_grad_pre=a["pre"])
+                self._wgrad(dpre, a["h2"], b + "mlp.fc1.weight")
+                ops.colsum(dpre, gr[b + "mlp.fc1.bias"], beta=1, ws=self.ws_colsum)
+                ops.gemm_nt(dpre, self.wt[b + "mlp.fc1"], self.s_dh)
+                dh2 = self.s_dh
+            else:
+                g, r = a["gate"], a["route"]
+                ops.combine_bwd(dx, a["y"], g["score"], self.s_dy, self.s_dscore)
+                dhp = self.s_dpre[: R * self.Hm].view(R, self.Hm)
+                self._wgrad(self.s_dy, a["hid"], b + "mlp.experts.h4toh.weight", M=R, c_row_idx=r.row_of_slot,
+                            group_offsets=r.offsets)
+                ops.colsum(self.s_dy, gr[b + "mlp.experts.h4toh.bias"], M=R, beta=1, c_row_idx=r.row_of_slot,
+                           group_offsets=r.offsets, ws=self.ws_colsum)
+                ops.gemm_nt(self.s_dy, self.wt[b + "mlp.experts.h4toh"], dhp, M=R, gelu_grad_pre=a["hid_pre"],
+                            a_row_idx=r.row_of_slot, a_row_div=1, group_offsets=r.offsets, tile_starts=r.tile_starts)
+                self._wgrad(dhp, a["h2"], b + "mlp.experts.htoh4.weight", M=R, a_row_idx=r.row_of_slot, a_row_div=k,
+                            group_offsets=r.offsets)
+                ops.colsum(dhp, gr[b + "mlp.experts.htoh4.bias"], M=R, beta=1, group_offsets=r.offsets,
+                           ws=self.ws_colsum)
+                ops.gemm_nt(dhp, self.wt[b + "mlp.experts.htoh4"], self.s_dxe, M=R, c_row_idx=r.row_of_slot,
+                            group_offsets=r.offsets, tile_starts=r.tile_starts)
+                ops.combine_fwd(self.s_dxe, self.ones_k, None, self.s_dh32)       # dh2 = sum_j dxe[t,j]
+                # gate: d score from the combine, d importance from the cv loss
+                d_imp = cv_squared_grad(g["importance"]) * cv_weight if cv_weight != 0.0 else None
+                dl = ops.gate_bwd_logits(g["noisy"], g["idx"], self.s_dscore, d_imp, k)
+                wg = p[a["wname"]]
+                if wg.shape[0] == D:
+                    ops.gate_bwd_params(a["h2"], wg, dl, d_w_gate=gr[a["wname"]], beta_dw=1, dx=self.s_dh32,
+                                        beta_dx=1, part_dw=self.ws_gate_dw)
+                else:   # task-conditioned: only the token rows of w_gate here; tsf rows via d(logit_bias)
+                    dwt = torch.zeros(D, self.E, device=self.dev)
+                    ops.gate_bwd_params(a["h2"], wg[:D].contiguous(), dl, d_w_gate=dwt, beta_dw=0, dx=self.s_dh32,
+                                        beta_dx=1, part_dw=self.ws_gate_dw)
+                    gr[a["wname"]][:D] += dwt
+                    a["d_logit_bias"] = dl.sum(0)
+                dh2 = self.s_dh32
+            ops.layernorm_bwd(dh2, a["x1"], a["mean2"], a["rstd2"], p[b + "norm2.weight"], dx, other,
+                              gr[b + "norm2.weight"], gr[b + "norm2.bias"], beta=1, ws=self.ws_ln)
+            dx, other = other, dx                                        # dx = d x1
+            ops.cast_f32(dx, self.s_dx_t)
+            self._wgrad(self.s_dx_t, a["o"], b + "attn.proj.weight")
+            ops.colsum(self.s_dx_t, gr[b + "attn.proj.bias"], beta=1, ws=self.ws_colsum)
+            ops.gemm_nt(self.s_dx_t, self.wt[b + "attn.proj"], self.s_do)
+            ops.attention_bwd(a["qkv"], a["o"], self.s_do, a["lse"], B, self.N, self.heads, self.dh, self.s_dqkv)
+            self._wgrad(self.s_dqkv, a["h1"], b + "attn.qkv.weight")
+            ops.colsum(self.s_dqkv, gr[b + "attn.qkv.bias"], beta=1, ws=self.ws_colsum)
+            ops.gemm_nt(self.s_dqkv, self.wt[b + "attn.qkv"], self.s_dh)
+            ops.layernorm_bwd(self.s_dh, a["x_in"], a["mean1"], a["rstd1"], p[b + "norm1.weight"], dx, other,
+                              gr[b + "norm1.weight"], gr[b + "norm1.bias"], beta=1, ws=self.ws_ln)
+            dx, other = other, dx
+        # patch embedding / cls / pos
+        ops.tokens_bwd(dx, B, self.np_, D, self.s_dpatch, gr["pos_embed"].view(self.N, D), gr["cls_token"].view(D), beta=1)
+        gw = gr["patch_embed.proj.weight"].view(D, -1)
+        ops.wgrad_tn(self.s_dpatch, self.rows, gw, beta=1, ws=self.ws_wgrad)
+        ops.colsum(self.s_dpatch, gr["patch_embed.proj.bias"], beta=1, ws=self.ws_colsum)
+        return dx
