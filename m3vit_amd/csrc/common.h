@@ -135,6 +135,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
+int launch_reduce_rows_f32(const float *part, int nrows, int N, int G, int64_t gstride, float *out, int beta,
+                           hipStream_t s);
+int launch_reduce_rows_i32(const int32_t *part, int nrows, int N, int G, int64_t gstride, int64_t *out, int beta,
+                           hipStream_t s);
+
 static inline int dtype_size(int dt) { return dt == M3_F16 ? 2 : 4; }
 
 }  // namespace m3

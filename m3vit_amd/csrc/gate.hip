@@ -25,7 +25,7 @@ constexpr int GATE_TOK = 64;       // tokens per workgroup (one wave)
 constexpr int GATE_DW_TOK = 128;   // tokens per workgroup in the dW kernel
 constexpr int GATE_ROWB = 128;     // bytes of a token row staged per step
 
-template <typename T, int EPAD>
+template <typename T, int EPAD, bool EXACT>
 __global__ __launch_bounds__(GATE_TOK) void gate_fwd_kernel(
     const char *__restrict__ x, int64_t T_, int D, int64_t ldx_b, const float *__restrict__ w, int E,
     const float *__restrict__ bias, const float *__restrict__ noise, float noise_std, int k, int64_t *idx,
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(GATE_TOK) void gate_fwd_kernel(
 
   float acc[EPAD];
 #pragma unroll
-  for (int e = 0; e < EPAD; ++e) acc[e] = (bias && e < E) ? bias[e] : 0.f;
+  for (int e = 0; e < EPAD; ++e) acc[e] = (bias && (EXACT || e < E)) ? bias[e] : 0.f;
 
   constexpr int CPR = GATE_ROWB / 16;              // 16-byte chunks per row per step = 8
   constexpr int EPC = 16 / (int)sizeof(T);         // elements per chunk
@@ -77,12 +77,13 @@ __global__ __launch_bounds__(GATE_TOK) void gate_fwd_kernel(
     __syncthreads();
     const int d0 = d0b / (int)sizeof(T);
     const int dn = (D - d0 < DC) ? (D - d0) : DC;
+#pragma unroll 4
     for (int dd = 0; dd < dn; ++dd) {
       const float xv = sx[lane * LDS_STRIDE + dd];
       const float *wr = w + (int64_t)(d0 + dd) * E;   // wave-uniform -> scalar loads
 #pragma unroll
       for (int e = 0; e < EPAD; ++e)
-        if (e < E) acc[e] = __builtin_fmaf(xv, wr[e], acc[e]);
+        if (EXACT || e < E) acc[e] = __builtin_fmaf(xv, wr[e], acc[e]);
     }
     __syncthreads();
   }
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(GATE_TOK) void gate_fwd_kernel(
 #pragma unroll
   for (int e = 0; e < EPAD; ++e) {
     float n = acc[e];
-    if (noise && noise_std != 0.f && e < E && tok_ok) {
+    if (noise && noise_std != 0.f && (EXACT || e < E) && tok_ok) {
       const float scaled = noise[t * E + e] * noise_std;
       n = acc[e] + scaled;
     }
@@ -102,13 +103,13 @@ __global__ __launch_bounds__(GATE_TOK) void gate_fwd_kernel(
   float m = nz[0];
 #pragma unroll
   for (int e = 1; e < EPAD; ++e)
-    if (e < E) m = nz[e] > m ? nz[e] : m;
+    if (EXACT || e < E) m = nz[e] > m ? nz[e] : m;
   float q[EPAD];
   float s = 0.f;
 #pragma unroll
   for (int e = 0; e < EPAD; ++e) {
-    q[e] = (e < E) ? expf(nz[e] - m) : 0.f;
-    if (e < E) s = s + q[e];
+    q[e] = (EXACT || e < E) ? expf(nz[e] - m) : 0.f;
+    if (EXACT || e < E) s = s + q[e];
   }
   // top-(k+1) on the noisy logits, ties -> lowest index
   const int kp = (k + 1 < E) ? k + 1 : E;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(GATE_TOK) void gate_fwd_kernel(
     float bv = 0.f, bq = 0.f;
 #pragma unroll
     for (int e = 0; e < EPAD; ++e) {
-      if (e < E && !((taken >> e) & 1ull) && (best < 0 || nz[e] > bv)) {
+      if ((EXACT || e < E) && !((taken >> e) & 1ull) && (best < 0 || nz[e] > bv)) {
         best = e; bv = nz[e]; bq = q[e];
       }
     }
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(GATE_TOK) void gate_fwd_kernel(
   float imp_part = 0.f;
 #pragma unroll
   for (int e = 0; e < EPAD; ++e) {
-    if (e < E) {
+    if (EXACT || e < E) {
       const bool sel = (sel_k >> e) & 1ull;
       const float p = q[e] / s;
       const float gv = (sel && tok_ok) ? p : 0.f;
@@ -272,12 +273,17 @@ static int launch_gate_fwd(int epad, dim3 grid, hipStream_t s, const char *x, in
                            const float *w, int E, const float *bias, const float *noise, float std, int k, int64_t *idx,
                            int32_t *idx32, float *score, float *top, float *clean, float *noisy, float *gates,
                            float *pi, int32_t *pl) {
-#define M3_GATE_CASE(EP)                                                                                              \
-  case EP:                                                                                                            \
-    hipLaunchKernelGGL((gate_fwd_kernel<T, EP>), grid, dim3(GATE_TOK), 0, s, x, T_, D, ldx_b, w, E, bias, noise, std, \
-                       k, idx, idx32, score, top, clean, noisy, gates, pi, pl);                                       \
+#define M3_GATE_CASE(EP)                                                                                      \
+  case EP:                                                                                                    \
+    if (E == EP)                                                                                              \
+      hipLaunchKernelGGL((gate_fwd_kernel<T, EP, true>), grid, dim3(GATE_TOK), 0, s, x, T_, D, ldx_b, w, E,    \
+                         bias, noise, std, k, idx, idx32, score, top, clean, noisy, gates, pi, pl);          \
+    else                                                                                                      \
+      hipLaunchKernelGGL((gate_fwd_kernel<T, EP, false>), grid, dim3(GATE_TOK), 0, s, x, T_, D, ldx_b, w, E,   \
+                         bias, noise, std, k, idx, idx32, score, top, clean, noisy, gates, pi, pl);          \
     break;
   switch (epad) {
+    M3_GATE_CASE(4)
     M3_GATE_CASE(8)
     M3_GATE_CASE(16)
     M3_GATE_CASE(32)
@@ -288,7 +294,8 @@ static int launch_gate_fwd(int epad, dim3 grid, hipStream_t s, const char *x, in
   return check_launch("m3_gate_fwd");
 }
 
-static int epad_of(int E) { return E <= 8 ? 8 : E <= 16 ? 16 : E <= 32 ? 32 : 64; }
+static int epad_of(int E) { return E <= 4 ? 4 : E <= 8 ? 8 : E <= 16 ? 16 : E <= 32 ? 32 : 64; }
+static int epad8_of(int E) { return E <= 8 ? 8 : E <= 16 ? 16 : E <= 32 ? 32 : 64; }
 
 extern "C" int m3_gate_fwd(const void *x, int x_dtype, int64_t T, int D, int64_t ldx, const float *w_gate, int E,
                            const float *logit_bias, const float *noise, float noise_std, int k, int64_t *idx,
@@ -317,9 +324,9 @@ extern "C" int m3_gate_reduce(const float *part_importance, const int32_t *part_
                               float *importance, int64_t *load, void *stream) {
   M3_REQUIRE(part_importance && part_load && importance && load && E >= 1 && E <= 64 && nblk >= 0,
              "m3_gate_reduce: bad args");
-  hipLaunchKernelGGL(gate_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part_importance, part_load, nblk,
-                     E, importance, load);
-  return check_launch("m3_gate_reduce");
+  int rc = launch_reduce_rows_f32(part_importance, nblk, E, 1, 0, importance, 0, (hipStream_t)stream);
+  if (rc) return rc;
+  return launch_reduce_rows_i32(part_load, nblk, E, 1, 0, load, 0, (hipStream_t)stream);
 }
 
 extern "C" int m3_gate_bwd_logits(const float *noisy, const int64_t *idx, const float *d_score,
@@ -341,7 +348,7 @@ extern "C" int m3_gate_bwd_params(const void *x, int x_dtype, int64_t T, int D, 
   if (T == 0) return M3_OK;
   hipStream_t s = (hipStream_t)stream;
   const int es = dtype_size(x_dtype);
-  const int ep = epad_of(E);
+  const int ep = epad8_of(E);
   if (d_w_gate) {
     const int nblk = m3_gate_dw_blocks(T);
     const dim3 grid(nblk), block(((D + 63) / 64) * 64);

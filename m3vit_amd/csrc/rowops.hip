@@ -313,8 +313,9 @@ extern "C" int m3_layernorm_bwd(const void *dy, int dy_dtype, const float *x, co
                        rstd, gamma, dx_res, T, D, dx, ws);
   int rc = check_launch("m3_layernorm_bwd");
   if (rc) return rc;
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((D + 255) / 256), dim3(256), 0, s, ws, nblk, D, dgamma, dbeta, beta);
-  return check_launch("m3_layernorm_bwd(reduce)");
+  rc = launch_reduce_rows_f32(ws, nblk, D, 1, 0, dgamma, beta, s);
+  if (rc) return rc;
+  return launch_reduce_rows_f32(ws + (int64_t)nblk * D, nblk, D, 1, 0, dbeta, beta, s);
 }
 
 extern "C" int m3_cast_matrix(const float *src, int G, int rows, int cols, int transpose, void *dst, int dst_dtype,

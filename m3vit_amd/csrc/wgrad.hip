@@ -192,47 +192,55 @@ __global__ void wgrad_reduce_kernel(const float *ws, int splits, int64_t elems4,
 }
 
 // ------------------------------------------------------------------ column sums
-// db[g][n] = sum over rows of group g of dC[crow(m), n].  Stage 1: each block owns a
-// row slab of CS_ROWS rows of one group and all columns; stage 2 adds block partials in
-// block order.
-constexpr int CS_ROWS = 256;
-
+// db[g][n] = sum over rows of group g of dC[crow(m), n].  Stage 1: grid (column blocks,
+// strips per group, groups); a workgroup is 64 column chunks (16 B each) x 4 row lanes and
+// streams its strip of rows with coalesced 16-byte loads; stage 2 (reduce.hip) adds the strip
+// partials in a fixed order.
 template <typename T>
-__global__ void colsum_part_kernel(const char *dC, int64_t lddc_b, const int32_t *c_row_idx, int64_t M, int N,
-                                   const int32_t *group_offsets, int blocks_per_group, float *part) {
-  const int g = blockIdx.y, b = blockIdx.x;
+__global__ __launch_bounds__(256) void colsum_part_kernel(const char *__restrict__ dC, int64_t lddc_b,
+                                                          const int32_t *__restrict__ c_row_idx, int64_t M, int N,
+                                                          const int32_t *__restrict__ group_offsets, int spg,
+                                                          float *__restrict__ part) {
+  constexpr int ES = (int)sizeof(T), EPC = 16 / ES;
+  __shared__ float sred[4][64][EPC + 1];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = (blockIdx.x * 64 + cl) * EPC;
+  const int strip = blockIdx.y, g = blockIdx.z;
   int64_t r0 = 0, r1 = M;
   if (group_offsets) { r0 = group_offsets[g]; r1 = group_offsets[g + 1]; }
-  const int64_t per = ((r1 - r0) + blocks_per_group - 1) / blocks_per_group;
-  const int64_t b0 = r0 + (int64_t)b * per;
+  const int64_t per = ((r1 - r0) + spg - 1) / spg;
+  const int64_t b0 = r0 + (int64_t)strip * per;
   int64_t b1 = b0 + per;
   if (b1 > r1) b1 = r1;
-  float *out = part + ((int64_t)g * blocks_per_group + b) * N;
-  for (int n = threadIdx.x * 4; n < N; n += blockDim.x * 4) {
-    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int64_t m = b0; m < b1; ++m) {
+  float acc[EPC];
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) acc[j] = 0.f;
+  if (col < N) {
+#pragma unroll 4
+    for (int64_t m = b0 + rl; m < b1; m += 4) {
       const int64_t cr = c_row_idx ? (int64_t)c_row_idx[m] : m;
-      s += Vec4<T>::load((const T *)(dC + cr * lddc_b) + n);
+      const u32x4 raw = *(const u32x4 *)(dC + cr * lddc_b + (int64_t)col * ES);
+      const T *e = (const T *)&raw;
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) acc[j] += (float)e[j];
     }
-    *(f32x4 *)(out + n) = s;
+  }
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) sred[rl][cl][j] = acc[j];
+  __syncthreads();
+  if (rl == 0 && col < N) {
+    float *o = part + ((int64_t)g * spg + strip) * N + col;
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) o[j] = sred[0][cl][j] + sred[1][cl][j] + sred[2][cl][j] + sred[3][cl][j];
   }
 }
 
-__global__ void colsum_final_kernel(const float *part, int blocks_per_group, int N, int G, float *db, int beta) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= G * N) return;
-  const int g = i / N, n = i - g * N;
-  float s = beta ? db[i] : 0.f;
-  for (int b = 0; b < blocks_per_group; ++b) s += part[((int64_t)g * blocks_per_group + b) * N + n];
-  db[i] = s;
-}
-
-static int colsum_blocks_per_group(int64_t M, int G) {
+static int colsum_strips_per_group(int64_t M, int G) {
   int64_t per_group = (M + G - 1) / G;
-  int64_t b = (per_group + CS_ROWS - 1) / CS_ROWS;
-  if (b < 1) b = 1;
-  if (b > 256) b = 256;
-  return (int)b;
+  int64_t s = (per_group + 127) / 128;
+  if (s < 1) s = 1;
+  if (s > 512) s = 512;
+  return (int)s;
 }
 
 }  // namespace m3
@@ -283,7 +291,7 @@ extern "C" int m3_wgrad_reduce(const float *ws, int splits, int64_t elems, float
 }
 
 extern "C" int64_t m3_colsum_ws_elems(int64_t M, int N, int G) {
-  return (int64_t)G * colsum_blocks_per_group(M, G) * N;
+  return (int64_t)G * colsum_strips_per_group(M, G) * N;
 }
 
 extern "C" int m3_colsum(const void *dC, int dtype, int64_t lddc, const int32_t *c_row_idx, int64_t M, int N, int G,
@@ -292,18 +300,20 @@ extern "C" int m3_colsum(const void *dC, int dtype, int64_t lddc, const int32_t 
   M3_REQUIRE(dtype == M3_F32 || dtype == M3_F16, "m3_colsum: bad dtype");
   M3_REQUIRE(N % 4 == 0 && lddc % 4 == 0 && G >= 1, "m3_colsum: N, lddc must be multiples of 4");
   M3_REQUIRE(G == 1 || group_offsets, "m3_colsum: grouped call needs group_offsets");
-  const int bpg = colsum_blocks_per_group(M, G);
+  M3_REQUIRE((N * dtype_size(dtype)) % 16 == 0 && (lddc * dtype_size(dtype)) % 16 == 0 && ((uintptr_t)dC % 16) == 0,
+             "m3_colsum: rows must be 16-byte aligned and N*elem a multiple of 16");
+  const int spg = colsum_strips_per_group(M, G);
   const int es = dtype_size(dtype);
   hipStream_t s = (hipStream_t)stream;
-  const int threads = (N / 4 >= 256) ? 256 : ((N / 4 + 63) / 64) * 64;
+  const int chunks = N * es / 16;
+  const dim3 grid((chunks + 63) / 64, spg, G), block(256);
   if (dtype == M3_F16)
-    hipLaunchKernelGGL(colsum_part_kernel<half_t>, dim3(bpg, G), dim3(threads), 0, s, (const char *)dC, lddc * es,
-                       c_row_idx, M, N, group_offsets, bpg, ws);
+    hipLaunchKernelGGL(colsum_part_kernel<half_t>, grid, block, 0, s, (const char *)dC, lddc * es, c_row_idx, M, N,
+                       group_offsets, spg, ws);
   else
-    hipLaunchKernelGGL(colsum_part_kernel<float>, dim3(bpg, G), dim3(threads), 0, s, (const char *)dC, lddc * es,
-                       c_row_idx, M, N, group_offsets, bpg, ws);
+    hipLaunchKernelGGL(colsum_part_kernel<float>, grid, block, 0, s, (const char *)dC, lddc * es, c_row_idx, M, N,
+                       group_offsets, spg, ws);
   int rc = check_launch("m3_colsum(part)");
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((G * N + 255) / 256), dim3(256), 0, s, ws, bpg, N, G, db, beta);
-  return check_launch("m3_colsum(final)");
+  return launch_reduce_rows_f32(ws, spg, N, G, (int64_t)spg * N, db, beta, s);
 }

@@ -132,7 +132,8 @@ class BackboneEngine:
         # shared workspaces
         wg = 0
         for (M, N, K, G) in [(T, self.Hd, D, 1), (T, D, self.Hd, 1), (T, 3 * D, D, 1), (T, D, D, 1),
-                             (R, self.Hm, D, self.E), (R, D, self.Hm, self.E), (self.B * self.np_, D, Kp, 1)]:
+                             (R, self.Hm, D, self.E), (R, D, self.Hm, self.E), (self.B * self.np_, D, Kp, 1),
+                             (T, D, self.E, 1)]:
             wg = max(wg, ops.default_wgrad_splits(M, N, K, G) * G * N * K)
         self.ws_wgrad = self._e(wg, dtype=f32)
         cs = max(int(ops.lib().m3_colsum_ws_elems(T, 3 * D, 1)), int(ops.lib().m3_colsum_ws_elems(T, self.Hd, 1)),
@@ -140,6 +141,10 @@ class BackboneEngine:
         self.ws_colsum = self._e(cs, dtype=f32)
         self.ws_ln = self._e(2 * ops.lib().m3_ln_bwd_blocks(T) * D, dtype=f32)
         self.ws_gate_dw = self._e(ops.lib().m3_gate_dw_blocks(T) * self.cfg_d_gate() * self.E, dtype=f32)
+        # gate backward through the MFMA GEMMs when E rows are 16-byte multiples
+        es = 2 if self.dt == torch.float16 else 4
+        self.gate_via_gemm = (self.E * es) % 16 == 0 and self.cfg.gate_task_specific_dim < 0
+        self.s_dl_t = self._e(T, self.E)
 
     def cfg_d_gate(self):
         g = self.cfg.gate_task_specific_dim
@@ -175,6 +180,11 @@ class BackboneEngine:
                 ops.cast_matrix(w2, self.wc[n], transpose=False)
             if n in self.wt:
                 ops.cast_matrix(w2, self.wt[n], transpose=True)
+        if self.dt != torch.float32:
+            if not hasattr(self, "wgate_c"):
+                self.wgate_c = {n: torch.empty_like(p, dtype=self.dt) for n, p in self.params.items() if n.endswith("w_gate")}
+            for n, c in self.wgate_c.items():
+                ops.cast_matrix(self.params[n], c, transpose=False)
 
     def zero_grad(self):
         for g in self.grads.values():
@@ -282,7 +292,15 @@ class BackboneEngine:
                 d_imp = cv_squared_grad(g["importance"]) * cv_weight if cv_weight != 0.0 else None
                 dl = ops.gate_bwd_logits(g["noisy"], g["idx"], self.s_dscore, d_imp, k)
                 wg = p[a["wname"]]
-                if wg.shape[0] == D:
+                if self.gate_via_gemm:
+                    # d w_gate += h2^T dl (TN GEMM) ; dh2 += dl w_gate^T (NT GEMM, K = E)
+                    if self.dt == torch.float32:
+                        dl_t, wg_t = dl, wg
+                    else:
+                        dl_t, wg_t = ops.cast_f32(dl, self.s_dl_t), self.wgate_c[a["wname"]]
+                    ops.wgrad_tn(a["h2"], dl_t, gr[a["wname"]], beta=1, ws=self.ws_wgrad)
+                    ops.gemm_nt(dl_t, wg_t, self.s_dh32, residual=self.s_dh32)
+                elif wg.shape[0] == D:
                     ops.gate_bwd_params(a["h2"], wg, dl, d_w_gate=gr[a["wname"]], beta_dw=1, dx=self.s_dh32,
                                         beta_dx=1, part_dw=self.ws_gate_dw)
                 else:   # task-conditioned: only the token rows of w_gate here; tsf rows via d(logit_bias)

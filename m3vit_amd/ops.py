@@ -188,7 +188,7 @@ def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None,
 def default_wgrad_splits(M, N, K, G):
     tiles = ((N + 127) // 128) * ((K + 127) // 128) * G
     steps = max(1, (M // max(G, 1) + 31) // 32)
-    s = max(1, min(steps, (768 + tiles - 1) // tiles))
+    s = max(1, min(steps, 64, (768 + tiles - 1) // tiles))
     return int(s)
 
 
