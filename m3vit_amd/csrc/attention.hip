@@ -162,7 +162,7 @@ constexpr int AB_QB = 32;        // query rows per step
 constexpr int AB_KEYS = 256;     // keys per workgroup (4 waves x 64)
 
 template <typename T, int DH>
-__global__ __launch_bounds__(AT_THREADS, 1) void attention_bwd_kernel(const T *__restrict__ qkv, const T *__restrict__ o,
+__global__ __launch_bounds__(AT_THREADS, ((DH == 32 && sizeof(T) == 2) ? 2 : 1)) void attention_bwd_kernel(const T *__restrict__ qkv, const T *__restrict__ o,
                                                                        const T *__restrict__ d_o,
                                                                        const float *__restrict__ lse, int B, int N,
                                                                        int heads, T *__restrict__ dqkv, float scale) {

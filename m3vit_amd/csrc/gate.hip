@@ -23,7 +23,7 @@ namespace m3 {
 
 constexpr int GATE_TOK = 64;       // tokens per workgroup (one wave)
 constexpr int GATE_DW_TOK = 128;   // tokens per workgroup in the dW kernel
-constexpr int GATE_ROWB = 128;     // bytes of a token row staged per step
+constexpr int GATE_ROWB = 64;      // bytes of a token row staged per step
 
 template <typename T, int EPAD, bool EXACT>
 __global__ __launch_bounds__(GATE_TOK) void gate_fwd_kernel(
@@ -48,11 +48,11 @@ __global__ __launch_bounds__(GATE_TOK) void gate_fwd_kernel(
   constexpr int EPC = 16 / (int)sizeof(T);         // elements per chunk
   const int dbytes = D * (int)sizeof(T);
   for (int d0b = 0; d0b < dbytes; d0b += GATE_ROWB) {
-    // stage 64 rows x 128 B: chunk q = lane + 64*i -> row q>>3, c = q&7
+    // stage 64 rows x GATE_ROWB bytes: chunk q = lane + 64*i -> row q / CPR, c = q % CPR
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < CPR; ++i) {
       const int q = lane + 64 * i;
-      const int row = q >> 3, c = q & 7;
+      const int row = q / CPR, c = q % CPR;
       const int64_t tr = t0 + row;
       const int cb = d0b + c * 16;
       float v[EPC];
@@ -77,8 +77,26 @@ __global__ __launch_bounds__(GATE_TOK) void gate_fwd_kernel(
     __syncthreads();
     const int d0 = d0b / (int)sizeof(T);
     const int dn = (D - d0 < DC) ? (D - d0) : DC;
-#pragma unroll 4
-    for (int dd = 0; dd < dn; ++dd) {
+    int dd = 0;
+    if constexpr (EXACT && EPAD <= 16) {
+      // 4 rows of w_gate fetched by back-to-back scalar loads, then 4 x E fmas (chain order kept)
+      for (; dd + 4 <= dn; dd += 4) {
+        float wv[4][EPAD];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float *wr = w + (int64_t)(d0 + dd + u) * E;
+#pragma unroll
+          for (int e = 0; e < EPAD; ++e) wv[u][e] = wr[e];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float xv = sx[lane * LDS_STRIDE + dd + u];
+#pragma unroll
+          for (int e = 0; e < EPAD; ++e) acc[e] = __builtin_fmaf(xv, wv[u][e], acc[e]);
+        }
+      }
+    }
+    for (; dd < dn; ++dd) {
       const float xv = sx[lane * LDS_STRIDE + dd];
       const float *wr = w + (int64_t)(d0 + dd) * E;   // wave-uniform -> scalar loads
 #pragma unroll
