@@ -166,6 +166,13 @@ int m3_combine_fwd(const void *y, int dtype, const float *score, const float *re
 int m3_combine_bwd(const float *dout, const void *y, int dtype, const float *score,
                    int64_t T, int k, int D, void *dy, float *dscore, void *stream);
 
+/* Row movement of fastmoe's MOEScatter / MOEGather (custom_moe_layer.py:14,263-265) for
+ * callers that run an arbitrary expert_fn between them (the fused path does not need it):
+ *   dst[i,:] = sum_{j<k} src[idx[i*k+j] / div, :]     (k = 1: plain gather; k > 1: the
+ *   backward of the scatter, summing the k routed copies of a token). */
+int m3_gather_rows(const void *src, int dtype, const int32_t *idx, int div, int64_t nout, int k,
+                   int D, void *dst, void *stream);
+
 /* ----------------------------------------------------------- LayerNorm (a9)
  * nn.LayerNorm(D, eps) on the fp32 residual stream, output in the act dtype
  * (vision_transformer_moe.py:441-442, eps 1e-6 :567).  Saves mean/rstd fp32 [T]. */

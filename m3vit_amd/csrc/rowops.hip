@@ -397,3 +397,37 @@ extern "C" int m3_tokens_bwd(const float *dtok, int B, int np_, int D, void *dpa
   else hipLaunchKernelGGL(m3::tokens_bwd_kernel<float>, grid, block, 0, s, dtok, B, np_, D, (float *)dpatch, dpos, dcls, beta);
   return m3::check_launch("m3_tokens_bwd");
 }
+
+// ---- row gather with optional k-way sum: dst[i,:] = sum_{j<k} src[idx[i*k+j] / div, :]
+// (k = 1: MOEScatter / MOEGather row movement of fastmoe behind custom_moe_layer.py:263-265;
+//  k > 1: the backward of MOEScatter, which sums the k routed copies of a token)
+namespace m3 {
+template <typename T>
+__global__ __launch_bounds__(ROW_THREADS) void gather_rows_kernel(const T *__restrict__ src, const int32_t *__restrict__ idx,
+                                                                  int div, int64_t nout, int k, int D,
+                                                                  T *__restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
+  if (i >= nout) return;
+  for (int d = lane * 4; d < D; d += 256) {
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < k; ++j) {
+      const int64_t r = idx[i * k + j] / div;
+      acc += Vec4<T>::load(src + r * D + d);
+    }
+    Vec4<T>::store(dst + i * D + d, acc);
+  }
+}
+}  // namespace m3
+
+extern "C" int m3_gather_rows(const void *src, int dtype, const int32_t *idx, int div, int64_t nout, int k, int D,
+                              void *dst, void *stream) {
+  M3_REQUIRE(src && idx && dst && D % 4 == 0 && D > 0 && k >= 1 && div >= 1, "m3_gather_rows: bad args");
+  M3_REQUIRE(dtype == M3_F32 || dtype == M3_F16, "m3_gather_rows: bad dtype");
+  if (nout == 0) return M3_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)((nout + 3) / 4)), block(m3::ROW_THREADS);
+  if (dtype == M3_F16) hipLaunchKernelGGL(m3::gather_rows_kernel<m3::half_t>, grid, block, 0, s, (const m3::half_t *)src, idx, div, nout, k, D, (m3::half_t *)dst);
+  else hipLaunchKernelGGL(m3::gather_rows_kernel<float>, grid, block, 0, s, (const float *)src, idx, div, nout, k, D, (float *)dst);
+  return m3::check_launch("m3_gather_rows");
+}

@@ -223,6 +223,13 @@ def combine_bwd(dout, y, score, dy, dscore):
           "m3_combine_bwd")
 
 
+def gather_rows(src, idx, dst, div=1, k=1):
+    """dst[i] = sum_{j<k} src[idx[i*k+j] // div]."""
+    nout, D = dst.shape
+    check(lib().m3_gather_rows(_p(src), dt_code(src.dtype), _p(idx), div, nout, k, D, _p(dst), _stream()), "m3_gather_rows")
+    return dst
+
+
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps=1e-6):
     T, D = x.shape
     check(lib().m3_layernorm_fwd(_p(x), T, D, _p(gamma), _p(beta), float(eps), _p(y), dt_code(y.dtype), _p(mean),

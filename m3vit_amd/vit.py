@@ -1,0 +1,243 @@
+"""VisionTransformerMoE / Block / Attention / Mlp / PatchEmbed mirrors
+(models/moe/ckpt/vision_transformer_moe.py:244-261,283-341,379-562,564-886) with the reference's
+module names, state_dict keys and forward signatures, running on the HIP kernels.
+
+Scope notes: drop / attn_drop / drop_path must be 0 (as in every BASELINE config); pretrained
+weight loading, hybrid backbones, distilled tokens, wandb statistics and the sem regularisers are
+out of scope.  `forward` returns (tokens [B,N,D], total_cv_loss) like :882-886."""
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from .functional import AttentionCoreFn, LayerNormFn, MlpFn, PlainLinearFn
+from .gate import NoisyGate_VMoE
+from .moe_layer import FMoETransformerMLP
+
+
+def _gates_to_load(gates):
+    return (gates > 0).sum(0)
+
+
+def cv_squared(x):
+    eps = 1e-10
+    if x.shape[0] == 1:
+        return torch.Tensor([0])
+    return x.float().var() / (x.float().mean() ** 2 + eps)
+
+
+class HipLayerNorm(nn.LayerNorm):
+    """nn.LayerNorm whose forward/backward are the HIP row kernels; output in `act_dtype`."""
+    act_dtype = torch.float32
+
+    def forward(self, x):
+        return LayerNormFn.apply(x, self.weight, self.bias, self.eps, self.act_dtype)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        assert drop == 0.0, "dropout is not part of the hot path (0 in all BASELINE configs)"
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x):
+        return MlpFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        assert attn_drop == 0.0 and proj_drop == 0.0
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        assert qk_scale is None or abs(qk_scale - head_dim ** -0.5) < 1e-12, "custom qk_scale not supported"
+        self.scale = head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=bool(qkv_bias))
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def forward(self, x):
+        qkv = PlainLinearFn.apply(x, self.qkv.weight, self.qkv.bias)
+        o = AttentionCoreFn.apply(qkv, self.num_heads)
+        return PlainLinearFn.apply(o, self.proj.weight, self.proj.bias)
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        img_size = tuple(img_size) if isinstance(img_size, (tuple, list)) else (img_size, img_size)
+        self.img_size = img_size
+        self.patch_size = (patch_size, patch_size)
+        self.num_patches = (img_size[1] // patch_size) * (img_size[0] // patch_size)
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+    def forward(self, x, act_dtype=torch.float32):
+        """-> [B, num_patches, D] (the reference returns the conv map; flatten(2).transpose(1,2) is done
+        by the caller at :783-784 - folded in here)."""
+        from . import ops
+        B, C, H, W = x.shape
+        assert H == self.img_size[0] and W == self.img_size[1]
+        P = self.patch_size[0]
+        rows = torch.empty(B * self.num_patches, C * P * P, dtype=act_dtype, device=x.device)
+        ops.im2row(x.contiguous().float(), P, rows)
+        w2 = self.proj.weight.reshape(self.proj.weight.shape[0], -1)
+        y = PlainLinearFn.apply(rows, w2, self.proj.bias)
+        return y.view(B, self.num_patches, -1)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=HipLayerNorm, moe=False, moe_mlp_ratio=-1,
+                 moe_experts=64, moe_top_k=2, moe_gate_dim=-1, world_size=1, gate_return_decoupled_activation=False,
+                 moe_gate_type="noisy_vmoe", vmoe_noisy_std=1, gate_task_specific_dim=-1, multi_gate=False,
+                 regu_experts_fromtask=False, num_experts_pertask=-1, num_tasks=-1, gate_input_ahead=False,
+                 regu_sem=False, sem_force=False, regu_subimage=False, expert_prune=False, use_checkpointing=False):
+        super().__init__()
+        assert drop == 0.0 and attn_drop == 0.0 and drop_path == 0.0
+        self.moe = moe
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale)
+        self.drop_path = nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.gate_input_ahead = gate_input_ahead
+        if moe:
+            self.tot_expert = moe_experts * world_size
+            self.moe_top_k = moe_top_k
+            activation = nn.Sequential(act_layer(), nn.Dropout(drop))
+            if moe_gate_dim < 0:
+                moe_gate_dim = dim
+            if moe_mlp_ratio < 0:
+                moe_mlp_ratio = mlp_ratio
+            if moe_gate_type != "noisy_vmoe":
+                raise ValueError("only moe_gate_type='noisy_vmoe' works with this layer (SURVEY App. A.8)")
+            self.mlp = FMoETransformerMLP(num_expert=moe_experts, d_model=dim, d_gate=moe_gate_dim,
+                                          d_hidden=int(dim * moe_mlp_ratio), world_size=world_size, top_k=moe_top_k,
+                                          activation=activation, gate=NoisyGate_VMoE, vmoe_noisy_std=vmoe_noisy_std,
+                                          gate_task_specific_dim=gate_task_specific_dim, multi_gate=multi_gate,
+                                          regu_experts_fromtask=regu_experts_fromtask,
+                                          num_experts_pertask=num_experts_pertask, num_tasks=num_tasks,
+                                          expert_prune=expert_prune)
+            self.mlp_drop = nn.Dropout(drop)
+        else:
+            self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+    def forward(self, x, gate_inp=None, task_id=None, task_specific_feature=None, sem=None):
+        if self.gate_input_ahead:
+            gate_inp = x
+        x = x + self.attn(self.norm1(x)).to(x.dtype)
+        normed = self.norm2(x)
+        if not self.moe:
+            return x + self.mlp(normed).to(x.dtype), None
+        out, clean, noisy, std, top_logits, gates = self.mlp(normed, gate_inp, task_id, task_specific_feature, sem)
+        x = x + out.to(x.dtype)
+        importance = gates.sum(0)
+        # load: count form (std == 0); the Normal-CDF form (:456-457) only differs for std > 0
+        load = _gates_to_load(gates)
+        cv_loss = (cv_squared(importance) + cv_squared(load)) if self.training else 0
+        return x, cv_loss
+
+
+class new_Mlp(nn.Module):
+    """Task embedding net (:263-281): fc1 -> GELU -> fc2 -> LayerNorm, on torch ops (O(gtsd^2) work)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.norm = nn.LayerNorm(out_features, eps=1e-6)
+
+    def forward(self, x):
+        return self.norm(self.fc2(self.act(self.fc1(x))))
+
+
+class VisionTransformerMoE(nn.Module):
+    def __init__(self, model_name="vit_small_patch16_224", img_size=224, patch_size=16, in_chans=3, embed_dim=384,
+                 depth=12, num_heads=12, num_classes=19, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_rate=0.,
+                 attn_drop_rate=0., drop_path_rate=0., moe_mlp_ratio=-1, moe_experts=64, moe_top_k=2, world_size=1,
+                 gate_dim=-1, moe_gate_type="noisy_vmoe", vmoe_noisy_std=1, gate_task_specific_dim=-1,
+                 multi_gate=False, regu_experts_fromtask=False, num_experts_pertask=-1, num_tasks=-1,
+                 gate_input_ahead=False, expert_prune=False, use_checkpointing=False, act_dtype=torch.float32,
+                 random_init=True, **kwargs):
+        super().__init__()
+        assert drop_rate == 0.0 and attn_drop_rate == 0.0 and drop_path_rate == 0.0
+        self.img_size = tuple(img_size) if isinstance(img_size, (tuple, list)) else (img_size, img_size)
+        self.patch_size = patch_size
+        self.embed_dim = self.num_features = embed_dim
+        self.depth = depth
+        self.act_dtype = act_dtype
+        norm_layer = partial(_make_norm, act_dtype=act_dtype)
+        self.patch_embed = PatchEmbed(self.img_size, patch_size, in_chans, embed_dim)
+        self.num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.dist_token = None
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.num_patches + 1, embed_dim))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        self.num_tasks = gate_dim - embed_dim
+        self.gate_task_specific_dim = gate_task_specific_dim
+        self.multi_gate = multi_gate
+        if gate_task_specific_dim < 0 or multi_gate:
+            self.gate_task_represent = None
+        else:
+            self.gate_task_represent = new_Mlp(self.num_tasks, int(gate_task_specific_dim), gate_task_specific_dim)
+        blocks = []
+        for i in range(depth):
+            if i % 2 == 0:
+                blocks.append(Block(embed_dim, num_heads, mlp_ratio, qkv_bias, qk_scale, norm_layer=norm_layer))
+            else:
+                blocks.append(Block(embed_dim, num_heads, mlp_ratio, qkv_bias, qk_scale, norm_layer=norm_layer, moe=True,
+                                    moe_mlp_ratio=moe_mlp_ratio, moe_experts=moe_experts, moe_top_k=moe_top_k,
+                                    moe_gate_dim=gate_dim, world_size=world_size, moe_gate_type=moe_gate_type,
+                                    vmoe_noisy_std=vmoe_noisy_std, gate_task_specific_dim=gate_task_specific_dim,
+                                    multi_gate=multi_gate, regu_experts_fromtask=regu_experts_fromtask,
+                                    num_experts_pertask=num_experts_pertask, num_tasks=num_tasks,
+                                    gate_input_ahead=gate_input_ahead, expert_prune=expert_prune))
+        self.blocks = nn.Sequential(*blocks)
+        self.pre_logits = nn.Identity()
+        self.init_weights()
+
+    def init_weights(self):
+        nn.init.trunc_normal_(self.pos_embed, std=.02)
+        nn.init.trunc_normal_(self.cls_token, std=.02)
+        for _, m in self.named_modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=.02)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.constant_(m.bias, 0)
+                nn.init.constant_(m.weight, 1.0)
+
+    def forward_features(self, x, gate_inp, task_id, sem):
+        B = x.shape[0]
+        x = self.patch_embed(x, self.act_dtype).float()
+        x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1) + self.pos_embed
+        tsf = None
+        if (task_id is not None) and (self.gate_task_represent is not None):
+            one_hot = torch.zeros(self.num_tasks, device=x.device)
+            one_hot[task_id] = 1.0
+            tsf = self.gate_task_represent(one_hot)
+        total_cv = torch.tensor(0.0, device=x.device, dtype=x.dtype, requires_grad=True)
+        for blk in self.blocks:
+            if blk.moe:
+                x, cv = blk(x, gate_inp, task_id, tsf, sem=sem)
+                if cv is not None:
+                    total_cv = total_cv + cv
+            else:
+                x, _ = blk(x)
+        return x, total_cv
+
+    def forward(self, x, gate_inp=None, task_id=None, sem=None):
+        return self.forward_features(x, gate_inp, task_id=task_id, sem=sem)
+
+
+def _make_norm(dim, act_dtype=torch.float32):
+    n = HipLayerNorm(dim, eps=1e-6)
+    n.act_dtype = act_dtype
+    return n

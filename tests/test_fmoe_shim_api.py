@@ -1,0 +1,63 @@
+"""CPU: the `fmoe` API surface the reference imports exists with the signatures / attributes it
+relies on, and the layer mirrors expose the reference's state_dict keys."""
+import inspect
+
+import torch
+
+
+def test_reference_import_lines_work():
+    import m3vit_amd
+    m3vit_amd.install_fmoe_shim()
+    # models/moe/ckpt/custom_moe_layer.py:6-16, noisy_gate_vmoe.py:4, train_fastmoe.py:35,460
+    from fmoe.layers import FMoE, _fmoe_general_global_forward          # noqa: F401
+    from fmoe.linear import FMoELinear
+    from fmoe.functions import prepare_forward, ensure_comm              # noqa: F401
+    from fmoe.functions import MOEScatter, MOEGather                     # noqa: F401
+    from fmoe.functions import AllGather, Slice                          # noqa: F401
+    from fmoe.gates import NaiveGate                                     # noqa: F401
+    from fmoe.gates.base_gate import BaseGate
+    import fmoe
+    assert hasattr(fmoe, "DistributedGroupedDataParallel")
+    lin = FMoELinear(4, 8, 16, bias=True, rank=0)
+    assert tuple(lin.weight.shape) == (4, 16, 8) and tuple(lin.bias.shape) == (4, 16)
+    g = BaseGate(4, 2)
+    assert g.tot_expert == 8 and g.loss is None and not g.has_loss
+    g.set_loss(torch.tensor(1.0)); assert g.has_loss and float(g.get_loss()) == 1.0 and not g.has_loss
+    sig = inspect.signature(_fmoe_general_global_forward)
+    assert list(sig.parameters)[:5] == ["inp", "gate", "expert_fn", "num_expert", "world_size"]
+
+
+def test_layer_mirror_signature_and_state_dict_keys():
+    from m3vit_amd.gate import NoisyGate_VMoE
+    from m3vit_amd.moe_layer import FMoETransformerMLP
+    from m3vit_amd.vit import VisionTransformerMoE
+    want = ["num_expert", "d_model", "d_gate", "d_hidden", "activation", "expert_dp_comm", "expert_rank", "gate",
+            "world_size", "top_k", "vmoe_noisy_std", "gate_return_decoupled_activation", "gate_task_specific_dim",
+            "multi_gate", "regu_experts_fromtask", "num_experts_pertask", "num_tasks", "regu_sem", "sem_force",
+            "regu_subimage", "expert_prune", "prune_threshold"]
+    got = list(inspect.signature(FMoETransformerMLP.__init__).parameters)[1:]
+    assert got[:len(want)] == want                      # custom_moe_layer.py:73-98
+    fwd = list(inspect.signature(FMoETransformerMLP.forward).parameters)[1:]
+    assert fwd == ["inp", "gate_inp", "task_id", "task_specific_feature", "sem"]    # :161
+    layer = FMoETransformerMLP(num_expert=4, d_model=32, d_gate=34, d_hidden=48, gate=NoisyGate_VMoE, top_k=2,
+                               multi_gate=True, activation=torch.nn.Sequential(torch.nn.GELU(), torch.nn.Dropout(0.)))
+    keys = set(layer.state_dict().keys())
+    assert keys == {"experts.htoh4.weight", "experts.htoh4.bias", "experts.h4toh.weight", "experts.h4toh.bias",
+                    "gate.0.w_gate", "gate.1.w_gate"}
+    assert tuple(layer.experts.htoh4.weight.shape) == (4, 48, 32)       # utils/helpers.py:645-662
+    assert all(getattr(p, "dp_comm") == "none" for p in layer.experts.parameters())   # :159
+    assert layer.d_model == 32 and layer.top_k == 2 and layer.world_size == 1 and layer.num_expert == 4
+    # multi-gate list length = d_gate - d_model (:143-150)
+    assert len(layer.gate) == 2
+    # task-conditioned: one gate with input dim d_model + gtsd (:127-130)
+    tc = FMoETransformerMLP(num_expert=4, d_model=32, d_gate=37, d_hidden=32, gate=NoisyGate_VMoE, top_k=2,
+                            gate_task_specific_dim=8)
+    assert tuple(tc.gate.w_gate.shape) == (40, 4)
+    vit = VisionTransformerMoE(img_size=(32, 32), embed_dim=64, depth=2, num_heads=2, moe_mlp_ratio=1, moe_experts=4,
+                               moe_top_k=2, gate_dim=66, multi_gate=True)
+    from oracle import ref_torch as R
+    cfg = R.BackboneCfg(img_size=(32, 32), embed_dim=64, depth=2, num_heads=2, moe_mlp_ratio=1.0, moe_experts=4,
+                        moe_top_k=2, gate_dim=66, multi_gate=True)
+    assert set(vit.state_dict().keys()) == set(R.init_backbone_params(cfg).keys())
+    # utils/moe_utils.py:128-134,191-198 key filters keep working
+    assert any("mlp.experts.htoh4" in k for k in vit.state_dict()) and any("mlp.experts.h4toh" in k for k in vit.state_dict())

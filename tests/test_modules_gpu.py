@@ -1,0 +1,104 @@
+"""GPU: the reference-shaped module API (m3vit_amd.vit / moe_layer / fmoe shim) against the oracle."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = a.detach().double().cpu().flatten(); b = b.detach().double().cpu().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def test_vit_mirror_matches_oracle_fwd_bwd():
+    _need_gpu()
+    from m3vit_amd.vit import VisionTransformerMoE
+    from oracle import ref_torch as R
+    kw = dict(img_size=(32, 48), embed_dim=64, depth=4, num_heads=2, moe_experts=4, moe_top_k=2, gate_dim=66,
+              multi_gate=True)
+    cfg = R.BackboneCfg(mlp_ratio=4.0, moe_mlp_ratio=1.0, **kw)
+    P = R.init_backbone_params(cfg, seed=9)
+    m = VisionTransformerMoE(mlp_ratio=4.0, moe_mlp_ratio=1, vmoe_noisy_std=0, **kw).cuda()
+    m.load_state_dict(P)                                        # reference key names and shapes
+    m.train()
+    img = torch.randn(3, 3, 32, 48)
+    dtok = torch.randn(3, cfg.num_tokens, 64) * 0.1
+    Pr = {k: v.clone().double().requires_grad_() for k, v in P.items()}
+    loss_ref = 0.0
+    for task in (0, 1):
+        tok, cv = m(img.cuda(), task_id=task)
+        tr, cr, _ = R.backbone_forward(Pr, cfg, img.double(), task)
+        assert rel(tok, tr) < 2e-4
+        assert abs(float(cv) - float(cr)) < 1e-3 * max(1.0, float(cr))
+        ((tok * dtok.cuda()).sum() + 0.01 * cv).backward()
+        loss_ref = loss_ref + (tr * dtok.double()).sum() + 0.01 * cr
+    loss_ref.backward()
+    bad = [(n, rel(p.grad, Pr[n].grad)) for n, p in m.named_parameters() if Pr[n].grad is not None and rel(p.grad, Pr[n].grad) > 1e-3]
+    assert not bad, bad
+
+
+def test_composable_fmoe_path_with_custom_activation():
+    """_fmoe_general_global_forward + FMoELinear with an activation the fused path does not cover."""
+    _need_gpu()
+    from m3vit_amd.fmoe.layers import _fmoe_general_global_forward
+    from m3vit_amd.fmoe.linear import FMoELinear
+    from oracle import ref_torch as R
+    torch.manual_seed(3)
+    T, D, H, E, k = 300, 64, 96, 4, 2
+    l1, l2 = FMoELinear(E, D, H).cuda(), FMoELinear(E, H, D).cuda()
+    x = torch.randn(T, D, device="cuda", requires_grad=True)
+    idx = torch.stack([torch.randperm(E)[:k] for _ in range(T)]).cuda()
+
+    def expert_fn(rows, cnt):
+        return l2(torch.tanh(l1(rows, cnt)), cnt)
+    y = _fmoe_general_global_forward(x, idx, expert_fn, E, 1)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    # oracle: same routing, tanh experts
+    xr = x.detach().double().cpu().requires_grad_()
+    w1 = l1.weight.detach().double().cpu().requires_grad_(); w2 = l2.weight.detach().double().cpu().requires_grad_()
+    counts, offsets, pos, ros = R.route_build(idx.cpu(), E)
+    rows = xr[ros // k]
+    outs, s = [], 0
+    for e, n in enumerate(counts.tolist()):
+        h = torch.tanh(torch.nn.functional.linear(rows[s:s + n], w1[e], l1.bias[e].detach().double().cpu()))
+        outs.append(torch.nn.functional.linear(h, w2[e], l2.bias[e].detach().double().cpu())); s += n
+    ref = torch.cat(outs)[pos]
+    assert rel(y, ref) < 2e-5
+    ref.backward(gy.double().cpu())
+    assert rel(x.grad, xr.grad) < 2e-5 and rel(l1.weight.grad, w1.grad) < 2e-5 and rel(l2.weight.grad, w2.grad) < 2e-5
+
+
+def test_task_conditioned_layer_matches_oracle():
+    _need_gpu()
+    from m3vit_amd.gate import NoisyGate_VMoE
+    from m3vit_amd.moe_layer import FMoETransformerMLP
+    from oracle import ref_torch as R
+    torch.manual_seed(5)
+    D, H, E, k, gtsd, T = 64, 64, 8, 2, 16, 200
+    layer = FMoETransformerMLP(num_expert=E, d_model=D, d_gate=D + 3, d_hidden=H, gate=NoisyGate_VMoE, top_k=k,
+                               vmoe_noisy_std=0, gate_task_specific_dim=gtsd,
+                               activation=torch.nn.Sequential(torch.nn.GELU(), torch.nn.Dropout(0.))).cuda()
+    with torch.no_grad():
+        for p in layer.experts.parameters():
+            p.normal_(0, 0.1)
+    x = torch.randn(2, T // 2, D, device="cuda", requires_grad=True)
+    tsf = torch.randn(gtsd, device="cuda", requires_grad=True)
+    out, clean, noisy, std, top_logits, gates = layer(x, None, 1, tsf)
+    assert out.shape == x.shape and std == 0.0 and top_logits.shape == (T, k + 1) and gates.shape == (T, E)
+    gout = torch.randn_like(out)
+    (out * gout).sum().backward()
+    xr = x.detach().double().cpu().requires_grad_(); tr = tsf.detach().double().cpu().requires_grad_()
+    wg = layer.gate.w_gate.detach().double().cpu().requires_grad_()
+    gx = torch.cat((xr.reshape(T, D), tr.repeat(T, 1)), -1)                  # the reference's cat (:176-179)
+    e = layer.experts
+    o_ref, *_ = R.moe_layer(xr.reshape(T, D), gx, wg, e.htoh4.weight.detach().double().cpu(), e.htoh4.bias.detach().double().cpu(),
+                            e.h4toh.weight.detach().double().cpu(), e.h4toh.bias.detach().double().cpu(), k)
+    assert rel(out.reshape(T, D), o_ref) < 2e-5
+    (o_ref * gout.double().cpu().reshape(T, D)).sum().backward()
+    assert rel(x.grad, xr.grad) < 1e-4 and rel(tsf.grad, tr.grad) < 1e-4 and rel(layer.gate.w_gate.grad, wg.grad) < 1e-4
