@@ -105,14 +105,32 @@ template <> struct Vec4<half_t> {
   }
 };
 
-// exact-erf GELU and its derivative (nn.GELU default)
+// erf-GELU (nn.GELU default) and its derivative.  erfc is evaluated with Abramowitz-Stegun 7.1.26
+// (|abs error| <= 1.5e-7, i.e. at the fp32 rounding level of the surrounding MFMA sums) instead
+// of the ~40-instruction libm erff: in the GEMM epilogues the libm version cost as much as the
+// whole K loop.  q = 0.5*erfc(|x|/sqrt2) is formed without cancellation; e = exp(-x^2/2) is
+// shared with the derivative's pdf term.
+__device__ __forceinline__ void gelu_parts(float x, float &cdf, float &e) {
+  const float u = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * u);
+  e = __expf(-u * u);
+  float poly = 1.061405429f;
+  poly = __builtin_fmaf(poly, t, -1.453152027f);
+  poly = __builtin_fmaf(poly, t, 1.421413741f);
+  poly = __builtin_fmaf(poly, t, -0.284496736f);
+  poly = __builtin_fmaf(poly, t, 0.254829592f);
+  const float q = 0.5f * poly * t * e;
+  cdf = (x < 0.f) ? q : 1.0f - q;
+}
 __device__ __forceinline__ float gelu_f(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  float cdf, e;
+  gelu_parts(x, cdf, e);
+  return x * cdf;
 }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float cdf, e;
+  gelu_parts(x, cdf, e);
+  return __builtin_fmaf(x * 0.39894228040143267794f, e, cdf);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

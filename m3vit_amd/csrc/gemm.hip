@@ -43,6 +43,7 @@ struct GemmDev {
   const int32_t *tile_starts;
   int32_t n_tiles;
   int32_t m_tiles_max;
+  int32_t vec8;                                 // N and all leading dims multiples of 8: staged epilogue
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
@@ -86,42 +87,47 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
   const int n0 = nt * BN;
 
   // ---- per-thread staging assignment: 4 x 16-byte chunks per operand per step
-  // chunk q = tid + 256*i -> row = q >> 3 (0..127), c = q & 7
+  // chunk q = tid + 256*i -> row = q >> 3 (0..127), c = q & 7.
+  // Rows past the end of the group / of N are CLAMPED to a valid row instead of predicated: an
+  // output element depends only on its own A row and B row, and those rows/columns are never
+  // stored, so the loads can be unconditional (no branches -> hipcc keeps counted vmcnt waits).
   const char *a_src[4];
   const char *b_src[4];
-  bool a_ok[4], b_ok[4];
   const int c_stage = tid & 7;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = (tid >> 3) + 32 * i;
-    const int64_t m = m_begin + row;
-    a_ok[i] = m < m_end;
+    int64_t m = m_begin + row;
+    if (m >= m_end) m = m_end - 1;
     int64_t src = m;
-    if (a_ok[i] && p.a_row_idx) src = (int64_t)(p.a_row_idx[m] / p.a_row_div);
-    a_src[i] = p.A + (a_ok[i] ? src : 0) * p.lda_b + c_stage * 16;
-    const int n = n0 + row;
-    b_ok[i] = n < p.N;
-    b_src[i] = p.B + (int64_t)g * p.b_group_b + (int64_t)(b_ok[i] ? n : 0) * p.ldb_b + c_stage * 16;
+    if (p.a_row_idx) src = (int64_t)(p.a_row_idx[m] / p.a_row_div);
+    a_src[i] = p.A + src * p.lda_b;
+    int n = n0 + row;
+    if (n >= p.N) n = p.N - 1;
+    b_src[i] = p.B + (int64_t)g * p.b_group_b + (int64_t)n * p.ldb_b;
   }
   const int kbytes = p.K * (int)sizeof(T);
   const int nk = (kbytes + ROWB - 1) / ROWB;
 
-  u32x4 ra[4], rb[4];
-  auto load_global = [&](int ks) {
+  // Two register sets: tile t+1 waits in one set while tile t+2 is being fetched into the other,
+  // so every global load has two compute phases to land (prefetch distance 2).
+  u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+  auto load_global = [&](int ks, u32x4(&ra)[4], u32x4(&rb)[4]) {
     const int kb = ks * ROWB + c_stage * 16;
-    const bool kin = kb < kbytes;
+    const int koff = (kb < kbytes) ? kb : 0;    // K tail: load a valid chunk, zeroed at store time
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ra[i] = (a_ok[i] && kin) ? *(const u32x4 *)(a_src[i] + (int64_t)ks * ROWB) : u32x4{0u, 0u, 0u, 0u};
-      rb[i] = (b_ok[i] && kin) ? *(const u32x4 *)(b_src[i] + (int64_t)ks * ROWB) : u32x4{0u, 0u, 0u, 0u};
+      ra[i] = *(const u32x4 *)(a_src[i] + koff);
+      rb[i] = *(const u32x4 *)(b_src[i] + koff);
     }
   };
-  auto store_lds = [&](int buf) {
+  auto store_lds = [&](int buf, const u32x4(&ra)[4], const u32x4(&rb)[4], int ks) {
+    const bool kin = (ks * ROWB + c_stage * 16) < kbytes;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = (tid >> 3) + 32 * i;
-      *(u32x4 *)(sA(buf) + lds_off(row, c_stage)) = ra[i];
-      *(u32x4 *)(sB(buf) + lds_off(row, c_stage)) = rb[i];
+      *(u32x4 *)(sA(buf) + lds_off(row, c_stage)) = kin ? ra[i] : u32x4{0u, 0u, 0u, 0u};
+      *(u32x4 *)(sB(buf) + lds_off(row, c_stage)) = kin ? rb[i] : u32x4{0u, 0u, 0u, 0u};
     }
   };
 
@@ -131,13 +137,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_global(0);
-  store_lds(0);
-  __syncthreads();
-
-  for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < nk) load_global(ks + 1);
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int kc = 0; kc < CHUNKS; ++kc) {
       frag fa[4], fb[4];
@@ -154,12 +154,111 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = MM::mma(fb[ni], fa[mi], acc[ni][mi]);
     }
-    if (ks + 1 < nk) store_lds(buf ^ 1);
+  };
+
+  load_global(0, ra1, rb1);
+  load_global(nk > 1 ? 1 : 0, ra0, rb0);
+  store_lds(0, ra1, rb1, 0);
+  __syncthreads();
+
+  // Steady state (entry of an even step ks): LDS buf0 holds tile ks, set 0 holds tile ks+1 (in
+  // flight).  The loop body only runs while both of its loads are in range, so every load/store is
+  // unconditional and hipcc's counted vmcnt waits stay exact; the last 1-3 tiles are peeled.
+  int ks = 0;
+  for (; ks + 3 < nk; ks += 2) {
+    load_global(ks + 2, ra1, rb1);
+    __builtin_amdgcn_sched_barrier(0);          // keep the prefetch ahead of the MFMA phase
+    compute(0);
+    store_lds(1, ra0, rb0, ks + 1);
+    __syncthreads();
+    load_global(ks + 3, ra0, rb0);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1);
+    store_lds(0, ra1, rb1, ks + 2);
     __syncthreads();
   }
+  const int rem = nk - ks;
+  if (rem == 3) {
+    load_global(ks + 2, ra1, rb1);
+    __builtin_amdgcn_sched_barrier(0);          // keep the prefetch ahead of the MFMA phase
+    compute(0);
+    store_lds(1, ra0, rb0, ks + 1);
+    __syncthreads();
+    compute(1);
+    store_lds(0, ra1, rb1, ks + 2);
+    __syncthreads();
+    compute(0);
+  } else if (rem == 2) {
+    compute(0);
+    store_lds(1, ra0, rb0, ks + 1);
+    __syncthreads();
+    compute(1);
+  } else {
+    compute(0);
+  }
 
-  // ---- epilogue: lane holds for tile (ni, mi): n = nb + 4*lg + r (r = 0..3), m = mb + li
+  // ---- epilogue.  Fast path: the 128x128 fp32 tile is transposed through the (now free) 64 KiB
+  // of LDS so that every lane owns 8 consecutive n of one row: bias/residual/pre/C accesses become
+  // 16/32-byte vectors and each wave store covers whole 256/512-byte row segments (matters most for
+  // the scattered token-major store of the expert FC2 and for the two-output FC1).
   const float *bias = p.bias ? p.bias + (int64_t)g * p.N : nullptr;
+  if (p.vec8) {
+    __syncthreads();                         // all waves are done with the operand buffers
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int row = wr * 64 + mi * 16 + li;
+        const int chunk = wc * 16 + ni * 4 + lg;
+        *(f32x4 *)(smem + row * 512 + ((chunk ^ (row & 31)) << 4)) = acc[ni][mi];
+      }
+    __syncthreads();
+    const int cg = tid & 15, r16 = tid >> 4;
+    const int n = n0 + cg * 8;
+    if (n < p.N) {
+      f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
+      if (bias) { b0 = *(const f32x4 *)(bias + n); b1 = *(const f32x4 *)(bias + n + 4); }
+#pragma unroll 2
+      for (int ps = 0; ps < 8; ++ps) {
+        const int row = ps * 16 + r16;
+        const int64_t m = m_begin + row;
+        if (m >= m_end) break;
+        const int64_t crow = p.c_row_idx ? (int64_t)p.c_row_idx[m] : m;
+        const int sw = row & 31;
+        f32x4 v0 = *(const f32x4 *)(smem + row * 512 + (((2 * cg) ^ sw) << 4));
+        f32x4 v1 = *(const f32x4 *)(smem + row * 512 + (((2 * cg + 1) ^ sw) << 4));
+        v0 += b0; v1 += b1;
+        if (p.pre_out) {
+          Vec4<T>::store((T *)p.pre_out + crow * p.ld_pre + n, v0);
+          Vec4<T>::store((T *)p.pre_out + crow * p.ld_pre + n + 4, v1);
+        }
+        if (p.act == M3_ACT_GELU) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v0[j] = gelu_f(v0[j]); v1[j] = gelu_f(v1[j]); }
+        }
+        if (p.gpre) {
+          const f32x4 p0 = Vec4<T>::load((const T *)p.gpre + crow * p.ld_gpre + n);
+          const f32x4 p1 = Vec4<T>::load((const T *)p.gpre + crow * p.ld_gpre + n + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v0[j] *= gelu_grad_f(p0[j]); v1[j] *= gelu_grad_f(p1[j]); }
+        }
+        if (p.residual) {
+          v0 += *(const f32x4 *)(p.residual + crow * p.ld_res + n);
+          v1 += *(const f32x4 *)(p.residual + crow * p.ld_res + n + 4);
+        }
+        if (p.c_f32) {
+          *(f32x4 *)((float *)p.C + crow * p.ldc + n) = v0;
+          *(f32x4 *)((float *)p.C + crow * p.ldc + n + 4) = v1;
+        } else {
+          Vec4<T>::store((T *)p.C + crow * p.ldc + n, v0);
+          Vec4<T>::store((T *)p.C + crow * p.ldc + n + 4, v1);
+        }
+      }
+    }
+    return;
+  }
+  // Generic path (N or a leading dimension not a multiple of 8): lane holds for tile (ni, mi)
+  // n = nb + 4*lg + r (r = 0..3), m = mb + li.
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
     const int64_t m = m_begin + wr * 64 + mi * 16 + li;
@@ -232,6 +331,8 @@ extern "C" int m3_gemm_nt(const m3_gemm_args *a, void *stream) {
   const int64_t mt = (a->M + BM - 1) / BM + (a->group_offsets ? a->G : 0);
   M3_REQUIRE(mt * d.n_tiles < (int64_t)1 << 30, "m3_gemm_nt: grid too large");
   d.m_tiles_max = (int)mt;
+  d.vec8 = (a->N % 8 == 0 && a->ldc % 8 == 0 && (!a->pre_out || a->ld_pre % 8 == 0) &&
+            (!a->gelu_grad_pre || a->ld_gpre % 8 == 0) && (!a->residual || a->ld_res % 8 == 0)) ? 1 : 0;
   const dim3 grid((unsigned)(mt * d.n_tiles)), block(GEMM_THREADS);
   const size_t lds = 4 * BM * ROWB;  // 64 KiB
   hipStream_t s = (hipStream_t)stream;
