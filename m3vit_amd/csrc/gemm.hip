@@ -50,7 +50,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <typename T>
+template <typename T, bool KTAIL>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev p) {
   typedef Mma<T> MM;
   typedef typename MM::frag frag;
@@ -59,8 +59,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [buf][A|B][128 rows * 128 B]
-  auto sA = [&](int buf) -> char * { return smem + buf * (2 * BM * ROWB); };
-  auto sB = [&](int buf) -> char * { return smem + buf * (2 * BM * ROWB) + BM * ROWB; };
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -91,8 +89,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
   // Rows past the end of the group / of N are CLAMPED to a valid row instead of predicated: an
   // output element depends only on its own A row and B row, and those rows/columns are never
   // stored, so the loads can be unconditional (no branches -> hipcc keeps counted vmcnt waits).
-  const char *a_src[4];
-  const char *b_src[4];
+  // Addresses are (wave-uniform 64-bit base that advances with k) + (32-bit per-lane byte offset):
+  // the loads take the SGPR-base form and cost no per-step VALU address arithmetic.
+  uint32_t a_off[4], b_off[4];
   const int c_stage = tid & 7;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -101,33 +100,45 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
     if (m >= m_end) m = m_end - 1;
     int64_t src = m;
     if (p.a_row_idx) src = (int64_t)(p.a_row_idx[m] / p.a_row_div);
-    a_src[i] = p.A + src * p.lda_b;
+    a_off[i] = (uint32_t)(src * p.lda_b) + c_stage * 16;
     int n = n0 + row;
     if (n >= p.N) n = p.N - 1;
-    b_src[i] = p.B + (int64_t)g * p.b_group_b + (int64_t)n * p.ldb_b;
+    b_off[i] = (uint32_t)((int64_t)n * p.ldb_b) + c_stage * 16;
   }
+  const char *a_base = p.A;
+  const char *b_base = p.B + (int64_t)g * p.b_group_b;
   const int kbytes = p.K * (int)sizeof(T);
   const int nk = (kbytes + ROWB - 1) / ROWB;
+
+  // LDS addressing: the XOR swizzle term (row>>1)&7 only depends on the lane (tile rows advance in
+  // multiples of 16 / 32), so one base per (operand, k-chunk) plus compile-time offsets is enough.
+  const int st_base = (tid >> 3) * ROWB + ((c_stage ^ ((tid >> 4) & 7)) << 4);      // + i*4096
+  const int sw = (li >> 1) & 7;
+  const int rdA0 = (wr * 64 + li) * ROWB + ((lg ^ sw) << 4);                        // + i*2048
+  const int rdA1 = (wr * 64 + li) * ROWB + (((4 + lg) ^ sw) << 4);
+  const int rdB0 = (wc * 64 + li) * ROWB + ((lg ^ sw) << 4) + BM * ROWB;
+  const int rdB1 = (wc * 64 + li) * ROWB + (((4 + lg) ^ sw) << 4) + BM * ROWB;
 
   // Two register sets: tile t+1 waits in one set while tile t+2 is being fetched into the other,
   // so every global load has two compute phases to land (prefetch distance 2).
   u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
   auto load_global = [&](int ks, u32x4(&ra)[4], u32x4(&rb)[4]) {
-    const int kb = ks * ROWB + c_stage * 16;
-    const int koff = (kb < kbytes) ? kb : 0;    // K tail: load a valid chunk, zeroed at store time
+    int kb = ks * ROWB;
+    if (KTAIL && kb + c_stage * 16 >= kbytes) kb = -c_stage * 16;   // K tail: a valid chunk, zeroed at store
+    const char *pa = a_base + kb, *pb = b_base + kb;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ra[i] = *(const u32x4 *)(a_src[i] + koff);
-      rb[i] = *(const u32x4 *)(b_src[i] + koff);
+      ra[i] = *(const u32x4 *)(pa + a_off[i]);
+      rb[i] = *(const u32x4 *)(pb + b_off[i]);
     }
   };
   auto store_lds = [&](int buf, const u32x4(&ra)[4], const u32x4(&rb)[4], int ks) {
-    const bool kin = (ks * ROWB + c_stage * 16) < kbytes;
+    const bool kin = !KTAIL || (ks * ROWB + c_stage * 16) < kbytes;
+    char *base = smem + buf * (2 * BM * ROWB) + st_base;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = (tid >> 3) + 32 * i;
-      *(u32x4 *)(sA(buf) + lds_off(row, c_stage)) = kin ? ra[i] : u32x4{0u, 0u, 0u, 0u};
-      *(u32x4 *)(sB(buf) + lds_off(row, c_stage)) = kin ? rb[i] : u32x4{0u, 0u, 0u, 0u};
+      *(u32x4 *)(base + i * 32 * ROWB) = kin ? ra[i] : u32x4{0u, 0u, 0u, 0u};
+      *(u32x4 *)(base + i * 32 * ROWB + BM * ROWB) = kin ? rb[i] : u32x4{0u, 0u, 0u, 0u};
     }
   };
 
@@ -138,16 +149,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto compute = [&](int buf) {
+    const char *sb = smem + buf * (2 * BM * ROWB);
 #pragma unroll
     for (int kc = 0; kc < CHUNKS; ++kc) {
       frag fa[4], fb[4];
-      const int chunk = kc * 4 + lg;
+      const char *pa = sb + (kc ? rdA1 : rdA0), *pb = sb + (kc ? rdB1 : rdB0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int rowa = wr * 64 + i * 16 + li;
-        const int rowb = wc * 64 + i * 16 + li;
-        fa[i] = *(const frag *)(sA(buf) + lds_off(rowa, chunk));
-        fb[i] = *(const frag *)(sB(buf) + lds_off(rowb, chunk));
+        fa[i] = *(const frag *)(pa + i * 16 * ROWB);
+        fb[i] = *(const frag *)(pb + i * 16 * ROWB);
       }
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
@@ -336,10 +346,16 @@ extern "C" int m3_gemm_nt(const m3_gemm_args *a, void *stream) {
   const dim3 grid((unsigned)(mt * d.n_tiles)), block(GEMM_THREADS);
   const size_t lds = 4 * BM * ROWB;  // 64 KiB
   hipStream_t s = (hipStream_t)stream;
+  // 32-bit per-lane byte offsets: A rows (gathered source rows must be < M) and one B group must fit 4 GiB
+  M3_REQUIRE((a->M + 1) * a->lda * es < ((int64_t)1 << 32) && (int64_t)a->N * a->ldb * es < ((int64_t)1 << 32),
+             "m3_gemm_nt: operand panel exceeds the 4 GiB reach of the 32-bit lane offsets");
+  const bool ktail = (a->K * es) % ROWB != 0;
   if (a->dtype == M3_F16) {
-    hipLaunchKernelGGL(gemm_nt_kernel<half_t>, grid, block, lds, s, d);
+    if (ktail) hipLaunchKernelGGL((gemm_nt_kernel<half_t, true>), grid, block, lds, s, d);
+    else hipLaunchKernelGGL((gemm_nt_kernel<half_t, false>), grid, block, lds, s, d);
   } else {
-    hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, block, lds, s, d);
+    if (ktail) hipLaunchKernelGGL((gemm_nt_kernel<float, true>), grid, block, lds, s, d);
+    else hipLaunchKernelGGL((gemm_nt_kernel<float, false>), grid, block, lds, s, d);
   }
   return check_launch("m3_gemm_nt");
 }

@@ -70,20 +70,20 @@ __device__ __forceinline__ f32x4 read_tr_frag<float>(const char *base, int rb, i
   return f;
 }
 
-template <typename T>
+template <typename T, bool GC, bool GA>
 __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev p) {
   typedef Mma<T> MM;
   typedef typename MM::frag frag;
   constexpr int ES = (int)sizeof(T);
+  constexpr int EPC = 16 / ES;
   constexpr int STRIDE = WgLds<T>::STRIDE;
   constexpr int CPR = WG_T * ES / 16;                       // 16-byte chunks per tile row
   constexpr int NLD = WG_ROWS * CPR / WG_THREADS;           // chunks per thread per operand
+  constexpr int RSTEP = WG_THREADS / CPR;                   // tile rows between a thread's chunks
   constexpr int OPB = WG_ROWS * STRIDE;                     // bytes per operand image
-  constexpr int KCH = WG_ROWS / MM::KC;                     // fragments chunks per step
+  constexpr int KCH = WG_ROWS / MM::KC;                     // fragment chunks per step
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  auto sC = [&](int buf) -> char * { return smem + buf * (2 * OPB); };
-  auto sA = [&](int buf) -> char * { return smem + buf * (2 * OPB) + OPB; };
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
   const int64_t s_begin = (int64_t)sp * per;
   int64_t s_end = s_begin + per;
   if (s_end > nsteps_all) s_end = nsteps_all;
+  const int nst = (int)(s_end > s_begin ? s_end - s_begin : 0);
 
   f32x4 acc[4][4];   // [ki][ni]: MFMA rows = k, cols = n
 #pragma unroll
@@ -109,62 +110,114 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 rc[NLD], ra[NLD];
-  auto load_global = [&](int64_t step) {
+  // staging assignment: chunk i of this thread is tile row (tid / CPR) + RSTEP*i, 16-byte column c.
+  // Columns beyond N / K are clamped (they only feed outputs that are never stored); rows beyond the
+  // end of the group are clamped for the load and ZEROED at the LDS store (they would otherwise add
+  // into every output).  Loads are unconditional so hipcc's counted vmcnt waits stay exact.
+  const int srow = tid / CPR, c = tid - srow * CPR;
+  int ncol = n0 + c * EPC, kcol = k0 + c * EPC;
+  if (ncol > p.N - EPC) ncol = p.N - EPC;
+  if (kcol > p.K - EPC) kcol = p.K - EPC;
+  const char *c_base = p.dC + (int64_t)ncol * ES;
+  const char *a_base = p.A + (int64_t)kcol * ES;
+  const int st_off = srow * STRIDE + c * 16;                // + i*RSTEP*STRIDE
+  const int64_t rbase = r0 + s_begin * WG_ROWS + srow;      // row of chunk 0 in local step 0
+
+  auto row_of = [&](int step, int i) -> int64_t {           // clamped slot row
+    int64_t m = rbase + (int64_t)step * WG_ROWS + i * RSTEP;
+    return m < r1 ? m : r1 - 1;
+  };
+  auto load_index = [&](int step, int32_t(&ic)[NLD], int32_t(&ia)[NLD]) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int q = tid + WG_THREADS * i;
-      const int row = q / CPR, c = q - row * CPR;
-      const int64_t m = r0 + step * WG_ROWS + row;
-      const bool mok = m < r1;
-      const int ncol = n0 + c * (16 / ES), kcol = k0 + c * (16 / ES);
-      u32x4 vc = u32x4{0u, 0u, 0u, 0u}, va = u32x4{0u, 0u, 0u, 0u};
-      if (mok) {
-        if (ncol < p.N) {
-          const int64_t cr = p.c_row_idx ? (int64_t)p.c_row_idx[m] : m;
-          vc = *(const u32x4 *)(p.dC + cr * p.lddc_b + (int64_t)ncol * ES);
-        }
-        if (kcol < p.K) {
-          const int64_t ar = p.a_row_idx ? (int64_t)(p.a_row_idx[m] / p.a_row_div) : m;
-          va = *(const u32x4 *)(p.A + ar * p.lda_b + (int64_t)kcol * ES);
-        }
-      }
-      rc[i] = vc; ra[i] = va;
+      const int64_t m = row_of(step, i);
+      if (GC) ic[i] = p.c_row_idx[m];
+      if (GA) ia[i] = p.a_row_idx[m];
     }
   };
-  auto store_lds = [&](int buf) {
+  auto load_global = [&](int step, const int32_t(&ic)[NLD], const int32_t(&ia)[NLD], u32x4(&rc)[NLD], u32x4(&ra)[NLD]) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int q = tid + WG_THREADS * i;
-      const int row = q / CPR, c = q - row * CPR;
-      *(u32x4 *)(sC(buf) + row * STRIDE + c * 16) = rc[i];
-      *(u32x4 *)(sA(buf) + row * STRIDE + c * 16) = ra[i];
+      const int64_t m = row_of(step, i);
+      const int64_t cr = GC ? (int64_t)ic[i] : m;
+      const int64_t ar = GA ? (int64_t)(ia[i] / p.a_row_div) : m;
+      rc[i] = *(const u32x4 *)(c_base + cr * p.lddc_b);
+      ra[i] = *(const u32x4 *)(a_base + ar * p.lda_b);
+    }
+  };
+  auto store_lds = [&](int buf, int step, const u32x4(&rc)[NLD], const u32x4(&ra)[NLD]) {
+    char *base = smem + buf * (2 * OPB) + st_off;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const bool ok = rbase + (int64_t)step * WG_ROWS + i * RSTEP < r1;
+      *(u32x4 *)(base + i * RSTEP * STRIDE) = ok ? rc[i] : u32x4{0u, 0u, 0u, 0u};
+      *(u32x4 *)(base + i * RSTEP * STRIDE + OPB) = ok ? ra[i] : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto compute = [&](int buf) {
+    const char *sC = smem + buf * (2 * OPB), *sA = sC + OPB;
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc) {
+      frag fk[4], fn[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fk[i] = read_tr_frag<T>(sA, kc * MM::KC, wr * 64 + i * 16, li, lg);
+        fn[i] = read_tr_frag<T>(sC, kc * MM::KC, wc * 64 + i * 16, li, lg);
+      }
+#pragma unroll
+      for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[ki][ni] = MM::mma(fk[ki], fn[ni], acc[ki][ni]);
     }
   };
 
-  if (s_begin < s_end) {
-    load_global(s_begin);
-    store_lds(0);
+  if (nst > 0) {
+    // prefetch distance 2 for the data (two register sets), 3 for the gather indices; steps past the
+    // end re-load the last step (clamped) so that nothing in the steady-state loop is conditional.
+    const int last = nst - 1;
+    auto cl = [&](int s_) { return s_ < last ? s_ : last; };
+    u32x4 rc0[NLD], ra0[NLD], rc1[NLD], ra1[NLD];
+    int32_t ic[NLD], ia[NLD];
+    load_index(0, ic, ia);
+    load_global(0, ic, ia, rc1, ra1);
+    load_index(cl(1), ic, ia);
+    load_global(cl(1), ic, ia, rc0, ra0);
+    load_index(cl(2), ic, ia);
+    store_lds(0, 0, rc1, ra1);
     __syncthreads();
-    int buf = 0;
-    for (int64_t st = s_begin; st < s_end; ++st) {
-      if (st + 1 < s_end) load_global(st + 1);
-#pragma unroll
-      for (int kc = 0; kc < KCH; ++kc) {
-        frag fk[4], fn[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          fk[i] = read_tr_frag<T>(sA(buf), kc * MM::KC, wr * 64 + i * 16, li, lg);
-          fn[i] = read_tr_frag<T>(sC(buf), kc * MM::KC, wc * 64 + i * 16, li, lg);
-        }
-#pragma unroll
-        for (int ki = 0; ki < 4; ++ki)
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) acc[ki][ni] = MM::mma(fk[ki], fn[ni], acc[ki][ni]);
-      }
-      if (st + 1 < s_end) store_lds(buf ^ 1);
+    // entry of even local step t: buf0 = tile t, set0 = tile t+1, (ic, ia) = indices of tile t+2
+    int t = 0;
+    for (; t + 3 < nst; t += 2) {
+      load_global(t + 2, ic, ia, rc1, ra1);
+      load_index(cl(t + 3), ic, ia);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(0);
+      store_lds(1, t + 1, rc0, ra0);
       __syncthreads();
-      buf ^= 1;
+      load_global(t + 3, ic, ia, rc0, ra0);
+      load_index(cl(t + 4), ic, ia);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(1);
+      store_lds(0, t + 2, rc1, ra1);
+      __syncthreads();
+    }
+    const int rem = nst - t;
+    if (rem == 3) {
+      load_global(t + 2, ic, ia, rc1, ra1);
+      compute(0);
+      store_lds(1, t + 1, rc0, ra0);
+      __syncthreads();
+      compute(1);
+      store_lds(0, t + 2, rc1, ra1);
+      __syncthreads();
+      compute(0);
+    } else if (rem == 2) {
+      compute(0);
+      store_lds(1, t + 1, rc0, ra0);
+      __syncthreads();
+      compute(1);
+    } else {
+      compute(0);
     }
   }
 
@@ -266,17 +319,30 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   d.tiles_k = (a->K + WG_T - 1) / WG_T;
   const dim3 grid(tiles_n * d.tiles_k, a->G, a->splits), block(WG_THREADS);
   hipStream_t s = (hipStream_t)stream;
+  M3_REQUIRE(a->N * es >= 16 && a->K * es >= 16, "m3_wgrad_tn: N, K too small");
+  const bool gc = a->c_row_idx != nullptr, ga = a->a_row_idx != nullptr;
+  const size_t lds16 = 4 * WG_ROWS * WgLds<half_t>::STRIDE, lds32 = 4 * WG_ROWS * WgLds<float>::STRIDE;
+#define M3_WG(TT, LDS)                                                                               \
+  do {                                                                                               \
+    if (gc && ga) hipLaunchKernelGGL((wgrad_tn_kernel<TT, true, true>), grid, block, LDS, s, d);     \
+    else if (gc) hipLaunchKernelGGL((wgrad_tn_kernel<TT, true, false>), grid, block, LDS, s, d);     \
+    else if (ga) hipLaunchKernelGGL((wgrad_tn_kernel<TT, false, true>), grid, block, LDS, s, d);     \
+    else hipLaunchKernelGGL((wgrad_tn_kernel<TT, false, false>), grid, block, LDS, s, d);            \
+  } while (0)
   if (a->dtype == M3_F16) {
-    hipLaunchKernelGGL(wgrad_tn_kernel<half_t>, grid, block, 4 * WG_ROWS * WgLds<half_t>::STRIDE, s, d);
+    M3_WG(half_t, lds16);
   } else {
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                4 * WG_ROWS * WgLds<float>::STRIDE);
+      (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<float, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
+      (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<float, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
+      (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<float, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
+      (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<float, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
       attr_set = true;
     }
-    hipLaunchKernelGGL(wgrad_tn_kernel<float>, grid, block, 4 * WG_ROWS * WgLds<float>::STRIDE, s, d);
+    M3_WG(float, lds32);
   }
+#undef M3_WG
   return check_launch("m3_wgrad_tn");
 }
 

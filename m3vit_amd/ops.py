@@ -186,9 +186,11 @@ def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None,
 
 
 def default_wgrad_splits(M, N, K, G):
+    """Row splits of the TN GEMM: fill the 512 resident workgroup slots (2 per CU) exactly once - more
+    splits only add slab traffic and a ragged second wave of workgroups."""
     tiles = ((N + 127) // 128) * ((K + 127) // 128) * G
     steps = max(1, (M // max(G, 1) + 31) // 32)
-    s = max(1, min(steps, 64, (768 + tiles - 1) // tiles))
+    s = max(1, min(steps, 32, 512 // tiles if tiles <= 512 else 1))
     return int(s)
 
 
