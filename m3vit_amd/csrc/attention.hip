@@ -57,13 +57,18 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_fwd_kernel(const T *_
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+  // XCD-aware order: the query blocks of one (image, head) and the neighbouring heads of the same
+  // image (which share 128-byte lines of the packed qkv rows) get consecutive logical ids -> one XCD.
+  const int nqb = gridDim.x;
+  const int log_id = xcd_remap(blockIdx.x + nqb * blockIdx.y, nqb * gridDim.y);
+  const int qb = log_id % nqb;
+  const int bh = log_id / nqb, b = bh / heads, h = bh - b * heads;
   const int C = heads * DH;
   const int64_t ld = 3 * (int64_t)C;
   const T *qbase = qkv + (int64_t)b * N * ld + h * DH;
   const T *kbase = qbase + C, *vbase = qbase + 2 * C;
 
-  const int q0 = blockIdx.x * AT_QB + wave * 16;
+  const int q0 = qb * AT_QB + wave * 16;
   const int qrow = q0 + li;
   frag qf[NCH];
 #pragma unroll
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(AT_THREADS, ((DH == 32 && sizeof(T) == 2) ? 2 : 1))
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+  const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / heads, h = bh - b * heads;   // heads of an image share lines
   const int C = heads * DH;
   const int64_t ld = 3 * (int64_t)C;
   const T *qbase = qkv + (int64_t)b * N * ld + h * DH;

@@ -90,8 +90,15 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
   const int li = lane & 15, lg = lane >> 4;
   const int wr = wave >> 1, wc = wave & 1;
 
-  const int tn = blockIdx.x / p.tiles_k, tk = blockIdx.x - tn * p.tiles_k;
-  const int g = blockIdx.y, sp = blockIdx.z;
+  // XCD-aware order: all tiles of one (group, split) read the SAME rows of dC and A (each byte is
+  // needed by tiles_k resp. tiles_n workgroups), so they are given consecutive logical ids, which the
+  // remap places on one XCD: the re-reads hit that XCD's L2 instead of the fabric.
+  const int tiles = gridDim.x;
+  const int lin = blockIdx.x + tiles * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int log_id = xcd_remap(lin, tiles * gridDim.y * gridDim.z);
+  const int tile = log_id % tiles, gs = log_id / tiles;
+  const int g = gs % (int)gridDim.y, sp = gs / (int)gridDim.y;
+  const int tn = tile / p.tiles_k, tk = tile - tn * p.tiles_k;
   const int n0 = tn * WG_T, k0 = tk * WG_T;
 
   int64_t r0, r1;
