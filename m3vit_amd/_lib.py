@@ -79,7 +79,8 @@ SIGNATURES = {
     "m3_ln_bwd_blocks": (c_int, [_L]),
     "m3_layernorm_bwd": (c_int, [_V, _I, _V, _V, _V, _V, _V, _L, _I, _V, _V, _V, _V, _I, _V]),
     "m3_attention_fwd": (c_int, [_V, _I, _I, _I, _I, _I, _V, _V, _V]),
-    "m3_attention_bwd": (c_int, [_V, _V, _V, _V, _I, _I, _I, _I, _I, _V, _V]),
+    "m3_attention_bwd_ws_elems": (c_int64, [_I, _I, _I, _I]),
+    "m3_attention_bwd": (c_int, [_V, _V, _V, _V, _I, _I, _I, _I, _I, _V, _V, _V]),
     "m3_cast_matrix": (c_int, [_V, _I, _I, _I, _I, _V, _I, _V]),
     "m3_cast_f32": (c_int, [_V, _L, _V, _I, _V]),
     "m3_im2row": (c_int, [_V, _I, _I, _I, _I, _I, _V, _I, _V]),

@@ -170,7 +170,7 @@ template <typename T, int DH>
 __global__ __launch_bounds__(AT_THREADS, ((DH == 32 && sizeof(T) == 2) ? 2 : 1)) void attention_bwd_kernel(const T *__restrict__ qkv, const T *__restrict__ o,
                                                                        const T *__restrict__ d_o,
                                                                        const float *__restrict__ lse, int B, int N,
-                                                                       int heads, T *__restrict__ dqkv, float scale) {
+                                                                       int heads, T *__restrict__ dqkv, float *__restrict__ dq_ws, float scale) {
   typedef Mma<T> MM;
   typedef typename MM::frag frag;
   constexpr int ES = (int)sizeof(T);
@@ -207,11 +207,18 @@ __global__ __launch_bounds__(AT_THREADS, ((DH == 32 && sizeof(T) == 2) ? 2 : 1))
   const float *lbase = lse + ((int64_t)b * heads + h) * N;
   const int kw0 = wave * 64;
 
+  // Sequences longer than AB_KEYS keys are processed one 256-key block at a time by the SAME workgroup:
+  // dK/dV of a key block are complete after its sweep; dQ is accumulated across key blocks in an fp32
+  // workspace that only this workgroup touches, by the same lane each time (no atomics, deterministic).
+  float *dqw = dq_ws ? dq_ws + ((int64_t)b * heads + h) * N * DH : nullptr;
+  for (int kb0 = 0; kb0 < N; kb0 += AB_KEYS) {
+  const bool first_kb = kb0 == 0, last_kb = kb0 + AB_KEYS >= N;
+  __syncthreads();
   // ---- K^T image (all keys) + this wave's K / V fragments
   for (int q = tid; q < AB_KEYS * CPR; q += AT_THREADS) {
     const int row = q / CPR, c = q - row * CPR;
     u32x4 kv = u32x4{0u, 0u, 0u, 0u};
-    if (row < N) kv = *(const u32x4 *)((const char *)(kbase + (int64_t)row * ld) + c * 16);
+    if (kb0 + row < N) kv = *(const u32x4 *)((const char *)(kbase + (int64_t)(kb0 + row) * ld) + c * 16);
     const T *ke = (const T *)&kv;
 #pragma unroll
     for (int j = 0; j < EPC; ++j) *(T *)(sKt + (c * EPC + j) * SSTR + row * ES) = ke[j];
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(AT_THREADS, ((DH == 32 && sizeof(T) == 2) ? 2 : 1))
   frag kf[4][NCH], vf[4][NCH];
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
-    const int key = kw0 + kt * 16 + li;
+    const int key = kb0 + kw0 + kt * 16 + li;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       if (key < N) {
@@ -237,7 +244,8 @@ __global__ __launch_bounds__(AT_THREADS, ((DH == 32 && sizeof(T) == 2) ? 2 : 1))
 #pragma unroll
     for (int c = 0; c < 4; ++c) { dkt[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  const int nkc = (N + KC - 1) / KC;   // key chunks that matter for dQ
+  const int nkeys = (N - kb0 < AB_KEYS) ? N - kb0 : AB_KEYS;
+  const int nkc = (nkeys + KC - 1) / KC;   // key chunks that matter for dQ
 
   for (int qs = 0; qs < N; qs += AB_QB) {
     __syncthreads();
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(AT_THREADS, ((DH == 32 && sizeof(T) == 2) ? 2 : 1))
           s = MM::mma(qfr[ch], kf[kt][ch], s);      // D[q = 4*lg + r][key = li]
           dp = MM::mma(dof[ch], vf[kt][ch], dp);
         }
-        const int key = kw0 + kt * 16 + li;
+        const int key = kb0 + kw0 + kt * 16 + li;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int ql = qt * 16 + 4 * lg + r;
@@ -352,14 +360,21 @@ __global__ __launch_bounds__(AT_THREADS, ((DH == 32 && sizeof(T) == 2) ? 2 : 1))
         acc = MM::mma(a, bq, acc);                   // D[d = 4*lg + r][q = li]
       }
       const int qr = qs + qt * 16 + li;
-      if (qr < N) Vec4<T>::store(dqbase + (int64_t)qr * ld + dt * 16 + 4 * lg, acc);
+      if (qr < N) {
+        if (dqw) {
+          float *w = dqw + (int64_t)qr * DH + dt * 16 + 4 * lg;
+          if (!first_kb) acc += *(const f32x4 *)w;
+          if (!last_kb) *(f32x4 *)w = acc;
+        }
+        if (last_kb) Vec4<T>::store(dqbase + (int64_t)qr * ld + dt * 16 + 4 * lg, acc);
+      }
     }
   }
 
   // ---- dK, dV rows of this wave's keys
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
-    const int key = kw0 + kt * 16 + li;
+    const int key = kb0 + kw0 + kt * 16 + li;
     if (key < N) {
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
@@ -368,6 +383,7 @@ __global__ __launch_bounds__(AT_THREADS, ((DH == 32 && sizeof(T) == 2) ? 2 : 1))
       }
     }
   }
+  }   // key blocks
 }
 
 template <typename T, int DH>
@@ -401,7 +417,7 @@ extern "C" int m3_attention_fwd(const void *qkv, int dtype, int B, int N, int he
 
 template <typename T, int DH>
 static int launch_attn_bwd(const void *qkv, const void *o, const void *d_o, const float *lse, int B, int N, int heads,
-                           void *dqkv, float scale, hipStream_t s) {
+                           void *dqkv, float *dq_ws, float scale, hipStream_t s) {
   const size_t lds = attn_bwd_lds<T, DH>();
   static bool attr_set = false;
   if (!attr_set) {
@@ -410,22 +426,28 @@ static int launch_attn_bwd(const void *qkv, const void *o, const void *d_o, cons
     attr_set = true;
   }
   hipLaunchKernelGGL((attention_bwd_kernel<T, DH>), dim3(B * heads), dim3(AT_THREADS), lds, s, (const T *)qkv,
-                     (const T *)o, (const T *)d_o, lse, B, N, heads, (T *)dqkv, scale);
+                     (const T *)o, (const T *)d_o, lse, B, N, heads, (T *)dqkv, dq_ws, scale);
   return check_launch("m3_attention_bwd");
 }
 
+extern "C" int64_t m3_attention_bwd_ws_elems(int B, int N, int heads, int dh) {
+  return N > AB_KEYS ? (int64_t)B * heads * N * dh : 0;
+}
+
 extern "C" int m3_attention_bwd(const void *qkv, const void *o, const void *d_o, const float *lse, int dtype, int B,
-                                int N, int heads, int dh, void *dqkv, void *stream) {
+                                int N, int heads, int dh, void *dqkv, float *dq_ws, void *stream) {
   M3_REQUIRE(qkv && o && d_o && lse && dqkv, "m3_attention_bwd: null operand");
   M3_REQUIRE(dtype == M3_F32 || dtype == M3_F16, "m3_attention_bwd: bad dtype");
   M3_REQUIRE(dh == 32 || dh == 64, "m3_attention_bwd: head dim %d not in {32, 64}", dh);
-  M3_REQUIRE(N > 0 && N <= AB_KEYS, "m3_attention_bwd: N=%d > %d keys per workgroup not supported in this release", N, AB_KEYS);
+  M3_REQUIRE(N > 0, "m3_attention_bwd: bad N");
+  M3_REQUIRE(N <= AB_KEYS || dq_ws, "m3_attention_bwd: N=%d > %d needs the fp32 dQ workspace (m3_attention_bwd_ws_elems)", N, AB_KEYS);
+  if (N <= AB_KEYS) dq_ws = nullptr;
   const float scale = 1.0f / sqrtf((float)dh);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == M3_F16) {
-    if (dh == 32) return launch_attn_bwd<half_t, 32>(qkv, o, d_o, lse, B, N, heads, dqkv, scale, s);
-    return launch_attn_bwd<half_t, 64>(qkv, o, d_o, lse, B, N, heads, dqkv, scale, s);
+    if (dh == 32) return launch_attn_bwd<half_t, 32>(qkv, o, d_o, lse, B, N, heads, dqkv, dq_ws, scale, s);
+    return launch_attn_bwd<half_t, 64>(qkv, o, d_o, lse, B, N, heads, dqkv, dq_ws, scale, s);
   }
-  if (dh == 32) return launch_attn_bwd<float, 32>(qkv, o, d_o, lse, B, N, heads, dqkv, scale, s);
-  return launch_attn_bwd<float, 64>(qkv, o, d_o, lse, B, N, heads, dqkv, scale, s);
+  if (dh == 32) return launch_attn_bwd<float, 32>(qkv, o, d_o, lse, B, N, heads, dqkv, dq_ws, scale, s);
+  return launch_attn_bwd<float, 64>(qkv, o, d_o, lse, B, N, heads, dqkv, dq_ws, scale, s);
 }

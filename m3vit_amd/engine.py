@@ -78,7 +78,8 @@ class BackboneEngine:
         self.depth = cfg.depth
         self.params = {n: p.to(self.dev, torch.float32).contiguous() for n, p in params.items()}
         self.grads = {n: torch.zeros_like(p) for n, p in self.params.items()}
-        self.is_moe = [i % 2 == 1 for i in range(self.depth)]
+        dense_only = bool(getattr(cfg, "dense_only", False))
+        self.is_moe = [(i % 2 == 1) and not dense_only for i in range(self.depth)]
         self._alloc()
         self.prepare_weights()
 
@@ -140,6 +141,8 @@ class BackboneEngine:
                  int(ops.lib().m3_colsum_ws_elems(R, max(self.Hm, D), self.E)))
         self.ws_colsum = self._e(cs, dtype=f32)
         self.ws_ln = self._e(2 * ops.lib().m3_ln_bwd_blocks(T) * D, dtype=f32)
+        need_dq = int(ops.lib().m3_attention_bwd_ws_elems(self.B, self.N, self.heads, self.dh))
+        self.ws_dq = self._e(need_dq, dtype=f32) if need_dq else None
         self.ws_gate_dw = self._e(ops.lib().m3_gate_dw_blocks(T) * self.cfg_d_gate() * self.E, dtype=f32)
         # gate backward through the MFMA GEMMs when E rows are 16-byte multiples
         es = 2 if self.dt == torch.float16 else 4
@@ -317,7 +320,8 @@ class BackboneEngine:
             self._wgrad(self.s_dx_t, a["o"], b + "attn.proj.weight")
             ops.colsum(self.s_dx_t, gr[b + "attn.proj.bias"], beta=1, ws=self.ws_colsum)
             ops.gemm_nt(self.s_dx_t, self.wt[b + "attn.proj"], self.s_do)
-            ops.attention_bwd(a["qkv"], a["o"], self.s_do, a["lse"], B, self.N, self.heads, self.dh, self.s_dqkv)
+            ops.attention_bwd(a["qkv"], a["o"], self.s_do, a["lse"], B, self.N, self.heads, self.dh, self.s_dqkv,
+                              dq_ws=self.ws_dq)
             self._wgrad(self.s_dqkv, a["h1"], b + "attn.qkv.weight")
             ops.colsum(self.s_dqkv, gr[b + "attn.qkv.bias"], beta=1, ws=self.ws_colsum)
             ops.gemm_nt(self.s_dqkv, self.wt[b + "attn.qkv"], self.s_dh)

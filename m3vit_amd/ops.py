@@ -253,9 +253,12 @@ def attention_fwd(qkv, B, N, heads, dh, o, lse):
           "m3_attention_fwd")
 
 
-def attention_bwd(qkv, o, d_o, lse, B, N, heads, dh, dqkv):
+def attention_bwd(qkv, o, d_o, lse, B, N, heads, dh, dqkv, dq_ws=None):
+    need = int(lib().m3_attention_bwd_ws_elems(B, N, heads, dh))
+    if need and dq_ws is None:
+        dq_ws = torch.empty(need, dtype=torch.float32, device=qkv.device)
     check(lib().m3_attention_bwd(_p(qkv), _p(o), _p(d_o), _p(lse), dt_code(qkv.dtype), B, N, heads, dh, _p(dqkv),
-                                 _stream()), "m3_attention_bwd")
+                                 _p(dq_ws) if need else None, _stream()), "m3_attention_bwd")
 
 
 # ---------------------------------------------------------------------- elementwise

@@ -198,7 +198,8 @@ class BackboneCfg:
 
     def __init__(self, img_size=(224, 224), patch_size=16, in_chans=3, embed_dim=384, depth=12,
                  num_heads=12, mlp_ratio=4.0, moe_mlp_ratio=1.0, moe_experts=16, moe_top_k=4,
-                 gate_dim=386, multi_gate=True, gate_task_specific_dim=-1, vmoe_noisy_std=0.0):
+                 gate_dim=386, multi_gate=True, gate_task_specific_dim=-1, vmoe_noisy_std=0.0, dense_only=False):
+        self.dense_only = dense_only        # BASELINE configs[0]: models/backbones/vit.py (no MoE blocks)
         self.img_size = tuple(img_size)
         self.patch_size = patch_size
         self.in_chans = in_chans
@@ -228,7 +229,7 @@ class BackboneCfg:
         return self.embed_dim if self.gate_task_specific_dim < 0 else self.embed_dim + self.gate_task_specific_dim
 
     def is_moe(self, i):
-        return i % 2 == 1                              # vision_transformer_moe.py:643-657
+        return (i % 2 == 1) and not self.dense_only    # vision_transformer_moe.py:643-657
 
 
 def _trunc_normal(shape, std, gen, dtype):

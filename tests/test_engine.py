@@ -50,3 +50,30 @@ def test_backbone_fwd_bwd_matches_oracle(dtype, tol):
         if e > tol * 5:
             bad.append((name, e))
     assert not bad, bad
+
+
+def test_config0_dense_vit_tiny_plumbing():
+    """BASELINE configs[0]: dense ViT-Tiny/16 (no MoE), 8 images of 480x640 -> tokens [8,1201,192]
+    (configs/nyud/vit/pup_vit_tiny_multi_task_baseline.yml; the reference path is train_vit.py ->
+    models/backbones/vit.py).  Forward + backward of the engine's dense path against the oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from m3vit_amd.engine import BackboneEngine
+    from oracle import ref_torch as R
+    cfg = R.BackboneCfg(img_size=(480, 640), embed_dim=192, depth=2, num_heads=3, mlp_ratio=4.0, dense_only=True,
+                        gate_dim=192)
+    B = 2
+    P = R.init_backbone_params(cfg, seed=11)
+    torch.manual_seed(1)
+    img = torch.randn(B, 3, 480, 640)
+    dtok = torch.randn(B, cfg.num_tokens, 192) * 0.1
+    assert cfg.num_tokens == 1201
+    eng = BackboneEngine(cfg, P, batch=B, dtype=torch.float32)
+    tok, cv = eng.forward(img.cuda(), None)
+    Pr = {k: v.clone().requires_grad_() for k, v in P.items()}
+    tr, _, _ = R.backbone_forward(Pr, cfg, img, None)
+    assert tok.shape == (B, 1201, 192) and rel(tok, tr) < 2e-4
+    eng.backward(dtok.cuda())
+    (tr * dtok).sum().backward()
+    bad = [(n, rel(g, Pr[n].grad)) for n, g in eng.grads.items() if rel(g, Pr[n].grad) > 2e-3]
+    assert not bad, bad
