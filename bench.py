@@ -115,14 +115,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # rehearsal knobs (tests only): M3_BENCH_BACKEND=gloo + M3_BENCH_ONE_DEVICE=1 run N ranks on ONE GPU
+    backend = os.environ.get("M3_BENCH_BACKEND", "nccl")
+    dev_index = 0 if (world == 1 or os.environ.get("M3_BENCH_ONE_DEVICE") == "1") else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from m3vit_amd import ops
     from m3vit_amd.config import VIT_SMALL_MOE, BackboneConfig, init_params
@@ -137,25 +142,23 @@ def main():
     dtok = (torch.randn(args.batch, cfg.num_tokens, cfg.embed_dim, generator=g) * 0.05).to(dev)
     ntasks = cfg.num_tasks
 
-    flat = None
-    if world > 1:
-        # one flat fp32 gradient bucket so the data-parallel sync is a single RCCL all-reduce
-        total = sum(v.numel() for v in eng.grads.values())
-        flat = torch.zeros(total, device=dev)
-        o = 0
-        for n_, v in list(eng.grads.items()):
-            eng.grads[n_] = flat[o:o + v.numel()].view_as(v)
-            o += v.numel()
+    flat = eng.flat_grads                                   # one flat fp32 gradient buffer
 
-    def step():
+    def compute_step():
         eng.prepare_weights()
         eng.zero_grad()
         for task in range(ntasks):
             eng.forward(images, task)
             eng.backward(dtok, cv_weight=CV_WEIGHT)
+
+    def sync_grads():
         if world > 1:
-            dist.all_reduce(flat)
+            dist.all_reduce(flat)                           # RCCL over xGMI; mean over ranks
             flat.div_(world)
+
+    def step():
+        compute_step()
+        sync_grads()
 
     def barrier():
         if world > 1:
@@ -174,18 +177,21 @@ def main():
     # into a hipGraph and replay it (the launch-bound inner loop is the graph, not the Python loop).
     run = step
     graph = None
-    if not args.no_graph and world == 1:
+    if not args.no_graph:
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                step()
+                compute_step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                step()
-            run = graph.replay
+                compute_step()
+
+            def run():                                      # collective stays outside the graph
+                graph.replay()
+                sync_grads()
             log("step captured into a hipGraph")
         except Exception as e:          # capture is an optimisation, never a requirement
             graph = None

@@ -77,7 +77,14 @@ class BackboneEngine:
         self.R = self.T * self.k
         self.depth = cfg.depth
         self.params = {n: p.to(self.dev, torch.float32).contiguous() for n, p in params.items()}
-        self.grads = {n: torch.zeros_like(p) for n, p in self.params.items()}
+        # one flat fp32 gradient buffer (views per parameter): zeroing is one memset and the data-parallel
+        # sync is one RCCL all-reduce (xGMI is point-to-point: few large collectives)
+        total = sum(p.numel() for p in self.params.values())
+        self.flat_grads = torch.zeros(total, dtype=torch.float32, device=self.dev)
+        self.grads, o = {}, 0
+        for n, p in self.params.items():
+            self.grads[n] = self.flat_grads[o:o + p.numel()].view_as(p)
+            o += p.numel()
         dense_only = bool(getattr(cfg, "dense_only", False))
         self.is_moe = [(i % 2 == 1) and not dense_only for i in range(self.depth)]
         self._alloc()
@@ -190,8 +197,7 @@ class BackboneEngine:
                 ops.cast_matrix(self.params[n], c, transpose=False)
 
     def zero_grad(self):
-        for g in self.grads.values():
-            g.zero_()
+        self.flat_grads.zero_()
 
     # ------------------------------------------------------------------ forward
     def _gate_weight(self, i, task_id):
