@@ -388,3 +388,40 @@ def test_errors_are_loud(ops):
         ops.gate_fwd(rnd(4, 8, seed=1), rnd(8, 100, seed=2), 2)   # E > 64
     with pytest.raises(M3Error):
         ops.gemm_nt(A.cpu(), B, C)                  # no CPU path
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_full_size_config2_shapes(ops, dtype):
+    """BASELINE config-2 sizes (many tiles per CU, skewed expert load):
+    dense with every epilogue option, and grouped with gather + scatter, at BASELINE config-2 sizes."""
+    T, D, E, k = 128 * 197, 384, 16, 4
+    x = rnd(T, D, dtype=dtype, seed=91)
+    W = rnd(1152, D, dtype=dtype, scale=0.05, seed=92)
+    bias = rnd(1152, seed=93, scale=0.1)
+    C = torch.empty(T, 1152, dtype=dtype, device=dev()); pre = torch.empty_like(C)
+    ops.gemm_nt(x, W, C, bias=bias, act=ops.M3_ACT_GELU, pre_out=pre)
+    lin = x.double() @ W.double().t() + bias.double()
+    assert rel(pre, lin) < TOL[dtype] and rel(C, gelu64(lin)) < TOL[dtype]
+    Wp = rnd(D, D, dtype=dtype, scale=0.05, seed=94)
+    res = rnd(T, D, seed=95)
+    out = torch.empty(T, D, dtype=torch.float32, device=dev())
+    ops.gemm_nt(x, Wp, out, residual=res)
+    assert rel(out, x.double() @ Wp.double().t() + res.double()) < TOL[dtype]
+    g = torch.Generator().manual_seed(96)
+    idx = torch.stack([torch.randperm(E, generator=g)[:k] for _ in range(T)]).to(torch.int32)
+    idx[:2000] = torch.tensor([0, 1, 2, 3], dtype=torch.int32)          # skewed load: expert 0-3 hot
+    idx = idx.to(dev())
+    r = ops.route_build(idx, E)
+    We = rnd(E, D, D, dtype=dtype, scale=0.05, seed=97)
+    be = rnd(E, D, scale=0.1, seed=98)
+    R = T * k
+    y = torch.full((R, D), float("nan"), dtype=dtype, device=dev())
+    ops.gemm_nt(x, We, y, M=R, bias=be, a_row_idx=r.row_of_slot, a_row_div=k, c_row_idx=r.row_of_slot,
+                group_offsets=r.offsets, tile_starts=r.tile_starts)
+    e_flat = idx.flatten().long()
+    ref = torch.empty(R, D, dtype=torch.float64, device=dev())
+    xd = x.double()
+    for e in range(E):
+        sel = (e_flat == e).nonzero().squeeze(1)
+        ref[sel] = xd[sel // k] @ We[e].double().t() + be[e].double()
+    assert rel(y, ref) < TOL[dtype]
