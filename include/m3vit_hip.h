@@ -146,9 +146,13 @@ typedef struct {
   int32_t splits;
   float *ws;                       /* [splits][G][N][K] */
   int32_t dtype;
+  float *bias_ws;                  /* optional [splits][G][N]: bias-grad column sums of dC, fused into the
+                                      same pass (one extra MFMA row); reduce with m3_wgrad_bias_reduce */
 } m3_wgrad_args;
 int m3_wgrad_tn(const m3_wgrad_args *args, void *stream);
 int m3_wgrad_reduce(const float *ws, int splits, int64_t elems, float *dW, int beta, void *stream);
+/* db[g][n] (+)= sum_s bias_ws[s][g][n], elems = G*N */
+int m3_wgrad_bias_reduce(const float *bias_ws, int splits, int64_t elems, float *db, int beta, void *stream);
 /* Column sums for bias grads: db[g][n] (+)= sum_{m in group g} dC[crow(m), n].
  * ws fp32 [m3_colsum_ws_elems(M, N, G)]. */
 int64_t m3_colsum_ws_elems(int64_t M, int N, int G);
@@ -179,12 +183,13 @@ int m3_gather_rows(const void *src, int dtype, const int32_t *idx, int div, int6
 int m3_layernorm_fwd(const float *x, int64_t T, int D, const float *gamma, const float *beta,
                      float eps, void *y, int y_dtype, float *mean, float *rstd, void *stream);
 /* dx[t,:] = dx_res[t,:] + LN'(dy[t,:]) ; dgamma/dbeta via per-block partials in ws
- * (fp32 [2][m3_ln_bwd_blocks(T)][D]) reduced in fixed order (beta = accumulate). */
+ * (fp32 [2][m3_ln_bwd_blocks(T)][D]) reduced in fixed order (beta = accumulate).
+ * dx_act (optional): a copy of dx in the activation dtype for the GEMMs that consume it next. */
 int m3_ln_bwd_blocks(int64_t T);
 int m3_layernorm_bwd(const void *dy, int dy_dtype, const float *x, const float *mean,
                      const float *rstd, const float *gamma, const float *dx_res,
                      int64_t T, int D, float *dx, float *ws, float *dgamma, float *dbeta,
-                     int beta, void *stream);
+                     int beta, void *dx_act, int dx_act_dtype, void *stream);
 
 /* ----------------------------------------------------------- attention (a8)
  * softmax(q k^T * dh^-0.5) v over the packed qkv activations written by the qkv

@@ -49,6 +49,7 @@ class WgradArgs(Structure):
         ("splits", c_int32),
         ("ws", c_void_p),
         ("dtype", c_int32),
+        ("bias_ws", c_void_p),
     ]
 
 
@@ -70,6 +71,7 @@ SIGNATURES = {
     "m3_gemm_nt": (c_int, [POINTER(GemmArgs), _V]),
     "m3_wgrad_tn": (c_int, [POINTER(WgradArgs), _V]),
     "m3_wgrad_reduce": (c_int, [_V, _I, _L, _V, _I, _V]),
+    "m3_wgrad_bias_reduce": (c_int, [_V, _I, _L, _V, _I, _V]),
     "m3_colsum_ws_elems": (c_int64, [_L, _I, _I]),
     "m3_colsum": (c_int, [_V, _I, _L, _V, _L, _I, _I, _V, _V, _V, _I, _V]),
     "m3_combine_fwd": (c_int, [_V, _I, _V, _V, _L, _I, _I, _V, _V]),
@@ -77,7 +79,7 @@ SIGNATURES = {
     "m3_gather_rows": (c_int, [_V, _I, _V, _I, _L, _I, _I, _V, _V]),
     "m3_layernorm_fwd": (c_int, [_V, _L, _I, _V, _V, _F, _V, _I, _V, _V, _V]),
     "m3_ln_bwd_blocks": (c_int, [_L]),
-    "m3_layernorm_bwd": (c_int, [_V, _I, _V, _V, _V, _V, _V, _L, _I, _V, _V, _V, _V, _I, _V]),
+    "m3_layernorm_bwd": (c_int, [_V, _I, _V, _V, _V, _V, _V, _L, _I, _V, _V, _V, _V, _I, _V, _I, _V]),
     "m3_attention_fwd": (c_int, [_V, _I, _I, _I, _I, _I, _V, _V, _V]),
     "m3_attention_bwd_ws_elems": (c_int64, [_I, _I, _I, _I]),
     "m3_attention_bwd": (c_int, [_V, _V, _V, _V, _I, _I, _I, _I, _I, _V, _V, _V]),

@@ -155,6 +155,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 int launch_reduce_rows_f32(const float *part, int nrows, int N, int G, int64_t gstride, float *out, int beta,
                            hipStream_t s);
+int launch_reduce_rows2_f32(const float *part, int nrows, int N, float *out0, float *out1, int beta, hipStream_t s);
 int launch_reduce_rows_i32(const int32_t *part, int nrows, int N, int G, int64_t gstride, int64_t *out, int beta,
                            hipStream_t s);
 

@@ -28,6 +28,34 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const TI *__restrict__
   }
 }
 
+// two outputs (LayerNorm dgamma / dbeta): part is [2][nrows][N]
+__global__ __launch_bounds__(256) void reduce_rows2_kernel(const float *__restrict__ part, int nrows, int N,
+                                                           float *__restrict__ out0, float *__restrict__ out1, int beta) {
+  __shared__ float s[8][33];
+  const int c = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + c, g = blockIdx.y;
+  float acc = 0.f;
+  if (n < N) {
+    const float *p = part + (int64_t)g * nrows * N + n;
+#pragma unroll 4
+    for (int r = rl; r < nrows; r += 8) acc += p[(int64_t)r * N];
+  }
+  s[rl][c] = acc;
+  __syncthreads();
+  if (rl == 0 && n < N) {
+    float t = s[0][c];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) t += s[i][c];
+    float *o = (g ? out1 : out0) + n;
+    *o = beta ? (*o + t) : t;
+  }
+}
+
+int launch_reduce_rows2_f32(const float *part, int nrows, int N, float *out0, float *out1, int beta, hipStream_t s) {
+  hipLaunchKernelGGL(reduce_rows2_kernel, dim3((N + 31) / 32, 2), dim3(256), 0, s, part, nrows, N, out0, out1, beta);
+  return check_launch("reduce_rows2_f32");
+}
+
 int launch_reduce_rows_f32(const float *part, int nrows, int N, int G, int64_t gstride, float *out, int beta,
                            hipStream_t s) {
   hipLaunchKernelGGL((reduce_rows_kernel<float, float>), dim3((N + 31) / 32, G), dim3(256), 0, s, part, nrows, N,

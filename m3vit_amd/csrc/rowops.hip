@@ -103,13 +103,14 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_fwd_kernel(const float 
 // dgamma/dbeta (rows of a block summed in row order).
 constexpr int LNB_ROWS = 32;   // rows per workgroup in the backward (4 waves x 8 rows)
 
-template <typename T>
+template <typename T, typename TA>
 __global__ __launch_bounds__(ROW_THREADS) void layernorm_bwd_kernel(const T *__restrict__ dy, const float *__restrict__ x,
                                                                     const float *__restrict__ mean,
                                                                     const float *__restrict__ rstd,
                                                                     const float *__restrict__ gamma,
                                                                     const float *__restrict__ dx_res, int64_t T_, int D,
-                                                                    float *__restrict__ dx, float *__restrict__ part) {
+                                                                    float *__restrict__ dx, float *__restrict__ part,
+                                                                    TA *__restrict__ dx_act) {
   extern __shared__ float sred[];   // [4 waves][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nblk = gridDim.x;
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_bwd_kernel(const T *__r
         f32x4 o = (gdy[i] - m1 - xh[i] * m2) * rs;
         if (dx_res) o += *(const f32x4 *)(dx_res + t * D + d);
         *(f32x4 *)(dx + t * D + d) = o;
+        if (dx_act) Vec4<TA>::store(dx_act + t * D + d, o);   // activation-dtype copy for the next GEMMs
       }
     }
   }
@@ -297,25 +299,25 @@ extern "C" int m3_ln_bwd_blocks(int64_t T) { return (int)((T + LNB_ROWS - 1) / L
 
 extern "C" int m3_layernorm_bwd(const void *dy, int dy_dtype, const float *x, const float *mean, const float *rstd,
                                 const float *gamma, const float *dx_res, int64_t T, int D, float *dx, float *ws,
-                                float *dgamma, float *dbeta, int beta, void *stream) {
+                                float *dgamma, float *dbeta, int beta, void *dx_act, int dx_act_dtype, void *stream) {
   M3_REQUIRE(dy && x && mean && rstd && gamma && dx && ws && dgamma && dbeta, "m3_layernorm_bwd: null operand");
   M3_REQUIRE(dy_dtype == M3_F32 || dy_dtype == M3_F16, "m3_layernorm_bwd: bad dtype");
+  M3_REQUIRE(!dx_act || dx_act_dtype == M3_F32 || dx_act_dtype == M3_F16, "m3_layernorm_bwd: bad dx_act dtype");
   M3_REQUIRE(D % 4 == 0 && D > 0 && D <= 1024, "m3_layernorm_bwd: D must be a multiple of 4 and <= 1024");
   if (T == 0) return M3_OK;
   hipStream_t s = (hipStream_t)stream;
   const int nblk = m3_ln_bwd_blocks(T);
   const size_t lds = (size_t)8 * D * sizeof(float);
-  if (dy_dtype == M3_F16)
-    hipLaunchKernelGGL(layernorm_bwd_kernel<half_t>, dim3(nblk), dim3(ROW_THREADS), lds, s, (const half_t *)dy, x, mean,
-                       rstd, gamma, dx_res, T, D, dx, ws);
-  else
-    hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nblk), dim3(ROW_THREADS), lds, s, (const float *)dy, x, mean,
-                       rstd, gamma, dx_res, T, D, dx, ws);
+  const bool a16 = dx_act && dx_act_dtype == M3_F16;
+#define M3_LNB(TT, TA)                                                                                         \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<TT, TA>), dim3(nblk), dim3(ROW_THREADS), lds, s, (const TT *)dy, x, \
+                     mean, rstd, gamma, dx_res, T, D, dx, ws, (TA *)dx_act)
+  if (dy_dtype == M3_F16) { if (a16) M3_LNB(half_t, half_t); else M3_LNB(half_t, float); }
+  else { if (a16) M3_LNB(float, half_t); else M3_LNB(float, float); }
+#undef M3_LNB
   int rc = check_launch("m3_layernorm_bwd");
   if (rc) return rc;
-  rc = launch_reduce_rows_f32(ws, nblk, D, 1, 0, dgamma, beta, s);
-  if (rc) return rc;
-  return launch_reduce_rows_f32(ws + (int64_t)nblk * D, nblk, D, 1, 0, dbeta, beta, s);
+  return launch_reduce_rows2_f32(ws, nblk, D, dgamma, dbeta, beta, s);
 }
 
 extern "C" int m3_cast_matrix(const float *src, int G, int rows, int cols, int transpose, void *dst, int dst_dtype,

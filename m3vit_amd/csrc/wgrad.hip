@@ -32,6 +32,7 @@ struct WgradDev {
   const int32_t *group_offsets;
   int32_t splits;
   float *ws;
+  float *bias_ws;                  // optional [splits][G][N]: column sums of dC (bias grads), fused
   int32_t tiles_k;
 };
 
@@ -161,6 +162,16 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
       *(u32x4 *)(base + i * RSTEP * STRIDE + OPB) = ok ? ra[i] : u32x4{0u, 0u, 0u, 0u};
     }
   };
+  // Bias gradient fused as one extra MFMA row: with an all-ones A operand the product is the column
+  // sum of dC over the contraction rows.  Done once per n-tile (k-tile 0, waves wr == 0).
+  const bool do_bias = p.bias_ws && tk == 0 && wr == 0;
+  f32x4 acc_b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc_b[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  frag ones;
+#pragma unroll
+  for (int j = 0; j < MM::EPL; ++j) ones[j] = (T)1.0f;
+
   auto compute = [&](int buf) {
     const char *sC = smem + buf * (2 * OPB), *sA = sC + OPB;
 #pragma unroll
@@ -175,6 +186,10 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
       for (int ki = 0; ki < 4; ++ki)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[ki][ni] = MM::mma(fk[ki], fn[ni], acc[ki][ni]);
+      if (do_bias) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc_b[ni] = MM::mma(ones, fn[ni], acc_b[ni]);
+      }
     }
   };
 
@@ -228,6 +243,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
     }
   }
 
+  if (do_bias && lg == 0) {                       // every row of the ones-product is the column sum: take row 0
+    float *bs = p.bias_ws + ((int64_t)sp * p.G + g) * p.N;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wc * 64 + ni * 16 + li;
+      if (n < p.N) bs[n] = acc_b[ni][0];
+    }
+  }
   // slab[sp][g][n][k]; lane holds k = kb + 4*lg + r, n = nb + li
   float *slab = p.ws + ((int64_t)sp * p.G + g) * (int64_t)p.N * p.K;
 #pragma unroll
@@ -321,7 +344,7 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   d.dC = (const char *)a->dC; d.lddc_b = a->lddc * es; d.c_row_idx = a->c_row_idx;
   d.A = (const char *)a->A; d.lda_b = a->lda * es; d.a_row_idx = a->a_row_idx; d.a_row_div = a->a_row_idx ? a->a_row_div : 1;
   d.M = a->M; d.N = a->N; d.K = a->K; d.G = a->G; d.group_offsets = a->group_offsets;
-  d.splits = a->splits; d.ws = a->ws;
+  d.splits = a->splits; d.ws = a->ws; d.bias_ws = a->bias_ws;
   const int tiles_n = (a->N + WG_T - 1) / WG_T;
   d.tiles_k = (a->K + WG_T - 1) / WG_T;
   const dim3 grid(tiles_n * d.tiles_k, a->G, a->splits), block(WG_THREADS);
@@ -361,6 +384,11 @@ extern "C" int m3_wgrad_reduce(const float *ws, int splits, int64_t elems, float
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((e4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws,
                      splits, e4, dW, beta);
   return check_launch("m3_wgrad_reduce");
+}
+
+extern "C" int m3_wgrad_bias_reduce(const float *bias_ws, int splits, int64_t elems, float *db, int beta, void *stream) {
+  M3_REQUIRE(bias_ws && db && splits >= 1 && elems > 0 && elems < ((int64_t)1 << 31), "m3_wgrad_bias_reduce: bad args");
+  return launch_reduce_rows_f32(bias_ws, splits, (int)elems, 1, 0, db, beta, (hipStream_t)stream);
 }
 
 extern "C" int64_t m3_colsum_ws_elems(int64_t M, int N, int G) {

@@ -142,7 +142,7 @@ class BackboneEngine:
         for (M, N, K, G) in [(T, self.Hd, D, 1), (T, D, self.Hd, 1), (T, 3 * D, D, 1), (T, D, D, 1),
                              (R, self.Hm, D, self.E), (R, D, self.Hm, self.E), (self.B * self.np_, D, Kp, 1),
                              (T, D, self.E, 1)]:
-            wg = max(wg, ops.default_wgrad_splits(M, N, K, G) * G * N * K)
+            wg = max(wg, ops.default_wgrad_splits(M, N, K, G) * G * N * (K + 1))
         self.ws_wgrad = self._e(wg, dtype=f32)
         cs = max(int(ops.lib().m3_colsum_ws_elems(T, 3 * D, 1)), int(ops.lib().m3_colsum_ws_elems(T, self.Hd, 1)),
                  int(ops.lib().m3_colsum_ws_elems(R, max(self.Hm, D), self.E)))
@@ -256,8 +256,10 @@ class BackboneEngine:
         return x.view(B, self.N, D), total_cv
 
     # ----------------------------------------------------------------- backward
-    def _wgrad(self, dC, A, name, M=None, **kw):
-        ops.wgrad_tn(dC, A, self.grads[name], M=M, beta=1, ws=self.ws_wgrad, **kw)
+    def _wgrad(self, dC, A, name, M=None, bias=None, **kw):
+        """weight grad (+ fused bias grad) accumulated into self.grads"""
+        ops.wgrad_tn(dC, A, self.grads[name], M=M, beta=1, ws=self.ws_wgrad,
+                     db=self.grads[bias] if bias is not None else None, **kw)
 
     def backward(self, d_tokens: torch.Tensor, cv_weight: float = 0.0):
         """Accumulates parameter gradients of  <tokens, d_tokens> + cv_weight * total_cv_loss
@@ -267,17 +269,17 @@ class BackboneEngine:
         dx = self.s_dxa
         dx.copy_(d_tokens.reshape(T, D))
         other = self.s_dxb
+        have_dx_t = False
         for i in reversed(range(self.depth)):
             a = self.act[i]
             b = f"blocks.{i}."
             if not self.is_moe[i]:
-                ops.cast_f32(dx, self.s_dx_t)
+                if not have_dx_t:
+                    ops.cast_f32(dx, self.s_dx_t)
                 dpre = self.s_dpre[: T * self.Hd].view(T, self.Hd)
-                self._wgrad(self.s_dx_t, a["u"], b + "mlp.fc2.weight")
-                ops.colsum(self.s_dx_t, gr[b + "mlp.fc2.bias"], beta=1, ws=self.ws_colsum)
+                self._wgrad(self.s_dx_t, a["u"], b + "mlp.fc2.weight", bias=b + "mlp.fc2.bias")
                 ops.gemm_nt(self.s_dx_t, self.wt[b + "mlp.fc2"], dpre, gelu_grad_pre=a["pre"])
-                self._wgrad(dpre, a["h2"], b + "mlp.fc1.weight")
-                ops.colsum(dpre, gr[b + "mlp.fc1.bias"], beta=1, ws=self.ws_colsum)
+                self._wgrad(dpre, a["h2"], b + "mlp.fc1.weight", bias=b + "mlp.fc1.bias")
                 ops.gemm_nt(dpre, self.wt[b + "mlp.fc1"], self.s_dh)
                 dh2 = self.s_dh
             else:
@@ -285,15 +287,11 @@ class BackboneEngine:
                 ops.combine_bwd(dx, a["y"], g["score"], self.s_dy, self.s_dscore)
                 dhp = self.s_dpre[: R * self.Hm].view(R, self.Hm)
                 self._wgrad(self.s_dy, a["hid"], b + "mlp.experts.h4toh.weight", M=R, c_row_idx=r.row_of_slot,
-                            group_offsets=r.offsets)
-                ops.colsum(self.s_dy, gr[b + "mlp.experts.h4toh.bias"], M=R, beta=1, c_row_idx=r.row_of_slot,
-                           group_offsets=r.offsets, ws=self.ws_colsum)
+                            group_offsets=r.offsets, bias=b + "mlp.experts.h4toh.bias")
                 ops.gemm_nt(self.s_dy, self.wt[b + "mlp.experts.h4toh"], dhp, M=R, gelu_grad_pre=a["hid_pre"],
                             a_row_idx=r.row_of_slot, a_row_div=1, group_offsets=r.offsets, tile_starts=r.tile_starts)
                 self._wgrad(dhp, a["h2"], b + "mlp.experts.htoh4.weight", M=R, a_row_idx=r.row_of_slot, a_row_div=k,
-                            group_offsets=r.offsets)
-                ops.colsum(dhp, gr[b + "mlp.experts.htoh4.bias"], M=R, beta=1, group_offsets=r.offsets,
-                           ws=self.ws_colsum)
+                            group_offsets=r.offsets, bias=b + "mlp.experts.htoh4.bias")
                 ops.gemm_nt(dhp, self.wt[b + "mlp.experts.htoh4"], self.s_dxe, M=R, c_row_idx=r.row_of_slot,
                             group_offsets=r.offsets, tile_starts=r.tile_starts)
                 ops.combine_fwd(self.s_dxe, self.ones_k, None, self.s_dh32)       # dh2 = sum_j dxe[t,j]
@@ -320,23 +318,23 @@ class BackboneEngine:
                     a["d_logit_bias"] = dl.sum(0)
                 dh2 = self.s_dh32
             ops.layernorm_bwd(dh2, a["x1"], a["mean2"], a["rstd2"], p[b + "norm2.weight"], dx, other,
-                              gr[b + "norm2.weight"], gr[b + "norm2.bias"], beta=1, ws=self.ws_ln)
+                              gr[b + "norm2.weight"], gr[b + "norm2.bias"], beta=1, ws=self.ws_ln,
+                              dx_act=self.s_dx_t)                        # also emits the activation-dtype copy
             dx, other = other, dx                                        # dx = d x1
-            ops.cast_f32(dx, self.s_dx_t)
-            self._wgrad(self.s_dx_t, a["o"], b + "attn.proj.weight")
-            ops.colsum(self.s_dx_t, gr[b + "attn.proj.bias"], beta=1, ws=self.ws_colsum)
+            self._wgrad(self.s_dx_t, a["o"], b + "attn.proj.weight", bias=b + "attn.proj.bias")
             ops.gemm_nt(self.s_dx_t, self.wt[b + "attn.proj"], self.s_do)
             ops.attention_bwd(a["qkv"], a["o"], self.s_do, a["lse"], B, self.N, self.heads, self.dh, self.s_dqkv,
                               dq_ws=self.ws_dq)
-            self._wgrad(self.s_dqkv, a["h1"], b + "attn.qkv.weight")
-            ops.colsum(self.s_dqkv, gr[b + "attn.qkv.bias"], beta=1, ws=self.ws_colsum)
+            self._wgrad(self.s_dqkv, a["h1"], b + "attn.qkv.weight", bias=b + "attn.qkv.bias")
             ops.gemm_nt(self.s_dqkv, self.wt[b + "attn.qkv"], self.s_dh)
+            nxt_dense = i > 0 and not self.is_moe[i - 1]                 # the block below consumes dx_t directly
             ops.layernorm_bwd(self.s_dh, a["x_in"], a["mean1"], a["rstd1"], p[b + "norm1.weight"], dx, other,
-                              gr[b + "norm1.weight"], gr[b + "norm1.bias"], beta=1, ws=self.ws_ln)
+                              gr[b + "norm1.weight"], gr[b + "norm1.bias"], beta=1, ws=self.ws_ln,
+                              dx_act=self.s_dx_t if nxt_dense else None)
             dx, other = other, dx
+            have_dx_t = nxt_dense
         # patch embedding / cls / pos
         ops.tokens_bwd(dx, B, self.np_, D, self.s_dpatch, gr["pos_embed"].view(self.N, D), gr["cls_token"].view(D), beta=1)
         gw = gr["patch_embed.proj.weight"].view(D, -1)
-        ops.wgrad_tn(self.s_dpatch, self.rows, gw, beta=1, ws=self.ws_wgrad)
-        ops.colsum(self.s_dpatch, gr["patch_embed.proj.bias"], beta=1, ws=self.ws_colsum)
+        ops.wgrad_tn(self.s_dpatch, self.rows, gw, beta=1, ws=self.ws_wgrad, db=gr["patch_embed.proj.bias"])
         return dx

@@ -157,8 +157,9 @@ def gemm_nt(A, B, C, *, M=None, bias=None, act=M3_ACT_NONE, pre_out=None, gelu_g
 
 
 def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None, a_row_idx=None, a_row_div=1,
-             group_offsets=None):
-    """dW[g][n,k] (+)= sum_m dC[crow(m),n] A[arow(m),k].  dW f32 [N,K] or [G,N,K]."""
+             group_offsets=None, db=None, beta_db=None):
+    """dW[g][n,k] (+)= sum_m dC[crow(m),n] A[arow(m),k].  dW f32 [N,K] or [G,N,K].
+    db (optional, f32 [N] / [G,N]): bias gradient = column sums of dC, fused into the same pass."""
     _req(dC, name="dC"); _req(A, dC.dtype, "A"); _req(dW, torch.float32, "dW")
     G = 1 if dW.dim() == 2 else dW.shape[0]
     N, K = dW.shape[-2], dW.shape[-1]
@@ -166,9 +167,9 @@ def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None,
         M = dC.shape[0]
     if splits is None:
         splits = default_wgrad_splits(M, N, K, G)
-    if ws is None:
-        ws = torch.empty(splits * G * N * K, dtype=torch.float32, device=dW.device)
-    assert ws.numel() >= splits * G * N * K
+    need = splits * G * N * K + (splits * G * N if db is not None else 0)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=dW.device)
     a = WgradArgs()
     a.dC = dC.data_ptr(); a.lddc = dC.stride(0)
     a.c_row_idx = c_row_idx.data_ptr() if c_row_idx is not None else None
@@ -180,8 +181,14 @@ def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None,
     a.splits = splits
     a.ws = ws.data_ptr()
     a.dtype = dt_code(dC.dtype)
+    bias_ws = ws[splits * G * N * K:] if db is not None else None
+    a.bias_ws = bias_ws.data_ptr() if bias_ws is not None else None
     check(lib().m3_wgrad_tn(byref(a), _stream()), "m3_wgrad_tn")
     check(lib().m3_wgrad_reduce(_p(ws), splits, G * N * K, _p(dW), beta, _stream()), "m3_wgrad_reduce")
+    if db is not None:
+        _req(db, torch.float32, "db")
+        check(lib().m3_wgrad_bias_reduce(_p(bias_ws), splits, G * N, _p(db), beta if beta_db is None else beta_db,
+                                         _stream()), "m3_wgrad_bias_reduce")
     return dW
 
 
@@ -238,13 +245,14 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps=1e-6):
                                  _p(rstd), _stream()), "m3_layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dx_res, dx, dgamma, dbeta, beta=0, ws=None):
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx_res, dx, dgamma, dbeta, beta=0, ws=None, dx_act=None):
     T, D = x.shape
     nblk = lib().m3_ln_bwd_blocks(T)
     if ws is None:
         ws = torch.empty(2 * nblk * D, dtype=torch.float32, device=x.device)
     check(lib().m3_layernorm_bwd(_p(dy), dt_code(dy.dtype), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx_res), T, D,
-                                 _p(dx), _p(ws), _p(dgamma), _p(dbeta), beta, _stream()), "m3_layernorm_bwd")
+                                 _p(dx), _p(ws), _p(dgamma), _p(dbeta), beta, _p(dx_act),
+                                 dt_code(dx_act.dtype) if dx_act is not None else M3_F32, _stream()), "m3_layernorm_bwd")
 
 
 # ------------------------------------------------------------------------ attention

@@ -113,8 +113,10 @@ def test_grouped_linear_golden_parallel_linear(ops, dtype):
     ops.gemm_nt(gy, Wt, dx, M=R, group_offsets=r.offsets, tile_starts=r.tile_starts)
     assert rel(dx, torch.tensor(g["dx"])) < tol
     dW = torch.empty(E, Dout, x.shape[1], dtype=torch.float32, device=dev())
-    ops.wgrad_tn(gy, x, dW, M=R, group_offsets=r.offsets, splits=3)
+    dbf = torch.empty(E, Dout, dtype=torch.float32, device=dev())
+    ops.wgrad_tn(gy, x, dW, M=R, group_offsets=r.offsets, splits=3, db=dbf)
     assert rel(dW, torch.tensor(g["dw_in_out"]).transpose(1, 2)) < tol
+    assert rel(dbf, torch.tensor(g["db"])) < tol                       # fused bias grad (empty expert -> zeros)
     db = torch.empty(E, Dout, dtype=torch.float32, device=dev())
     ops.colsum(gy, db, M=R, group_offsets=r.offsets)
     assert rel(db, torch.tensor(g["db"])) < tol
@@ -164,6 +166,11 @@ def test_wgrad_dense_and_colsum(ops, dtype):
     db = torch.empty(N, dtype=torch.float32, device=dev())
     ops.colsum(dC, db)
     assert rel(db, dC.double().sum(0)) < TOL[dtype]
+    # bias gradient fused into the weight-gradient pass (ones-row MFMA), with accumulation
+    dW2 = torch.zeros(N, K, device=dev()); db2 = rnd(N, seed=24); db0 = db2.clone()
+    ops.wgrad_tn(dC, A, dW2, beta=1, db=db2)
+    assert rel(dW2, dC.double().t() @ A.double()) < TOL[dtype]
+    assert rel(db2 - db0, dC.double().sum(0)) < max(TOL[dtype], 1e-4)
 
 
 # ------------------------------------------------------------------------------ gate
