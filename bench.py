@@ -224,8 +224,18 @@ def main():
         torch.cuda.synchronize()
     gs = gt.summary()
     peak = PEAK[args.dtype]
+    # HBM traffic per launch of that kernel: PMC numbers cannot be read from inside the process; they come from
+    # the committed rocprofv3 --pmc passes over this same command (profiles/r01_pmc_traffic.json)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            pm = json.load(fh)
+        if pm.get("dtype") == args.dtype and args.batch == 128:
+            traffic = round(pm["kernels"]["gemm_nt"]["hbm_bytes_per_launch"])
+    except Exception:
+        traffic = None
     roofline = {"kernel": "gemm_nt_kernel", "bound": "mfma", "achieved": round(gs["tflops"], 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(gs["tflops"] / peak, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(gs["tflops"] / peak, 4), "traffic": traffic,
                 "avg_launch_us": round(gs["avg_us"], 2), "launches_per_step": gs["launches"] // min(3, args.steps),
                 "flops_per_launch": gs["flops_per_launch"],
                 "expert_grouped_gemm_tflops": round(gs["grouped_tflops"], 2),
