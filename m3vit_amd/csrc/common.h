@@ -105,6 +105,27 @@ template <> struct Vec4<half_t> {
   }
 };
 
+// 8 consecutive elements of T <-> two f32x4: one 16-byte access for f16 (store-issue-bound epilogues:
+// a wave64 dwordx4 store moves twice the bytes of a dwordx2 at the same issue cost), two for f32.
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+  static __device__ __forceinline__ void load(const float *p, f32x4 &a, f32x4 &b) { a = *(const f32x4 *)p; b = *(const f32x4 *)(p + 4); }
+  static __device__ __forceinline__ void store(float *p, f32x4 a, f32x4 b) { *(f32x4 *)p = a; *(f32x4 *)(p + 4) = b; }
+};
+template <> struct Vec8<half_t> {
+  static __device__ __forceinline__ void load(const half_t *p, f32x4 &a, f32x4 &b) {
+    const f16x8 h = *(const f16x8 *)p;
+    a = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    b = f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+  }
+  static __device__ __forceinline__ void store(half_t *p, f32x4 a, f32x4 b) {
+    f16x8 h;
+    h[0] = (half_t)a[0]; h[1] = (half_t)a[1]; h[2] = (half_t)a[2]; h[3] = (half_t)a[3];
+    h[4] = (half_t)b[0]; h[5] = (half_t)b[1]; h[6] = (half_t)b[2]; h[7] = (half_t)b[3];
+    *(f16x8 *)p = h;
+  }
+};
+
 // erf-GELU (nn.GELU default) and its derivative.  erfc is evaluated with Abramowitz-Stegun 7.1.26
 // (|abs error| <= 1.5e-7, i.e. at the fp32 rounding level of the surrounding MFMA sums) instead
 // of the ~40-instruction libm erff: in the GEMM epilogues the libm version cost as much as the

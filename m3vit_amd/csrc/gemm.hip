@@ -238,17 +238,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
         f32x4 v0 = *(const f32x4 *)(smem + row * 512 + (((2 * cg) ^ sw) << 4));
         f32x4 v1 = *(const f32x4 *)(smem + row * 512 + (((2 * cg + 1) ^ sw) << 4));
         v0 += b0; v1 += b1;
-        if (p.pre_out) {
-          Vec4<T>::store((T *)p.pre_out + crow * p.ld_pre + n, v0);
-          Vec4<T>::store((T *)p.pre_out + crow * p.ld_pre + n + 4, v1);
-        }
+        if (p.pre_out) Vec8<T>::store((T *)p.pre_out + crow * p.ld_pre + n, v0, v1);
         if (p.act == M3_ACT_GELU) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { v0[j] = gelu_f(v0[j]); v1[j] = gelu_f(v1[j]); }
         }
         if (p.gpre) {
-          const f32x4 p0 = Vec4<T>::load((const T *)p.gpre + crow * p.ld_gpre + n);
-          const f32x4 p1 = Vec4<T>::load((const T *)p.gpre + crow * p.ld_gpre + n + 4);
+          f32x4 p0, p1;
+          Vec8<T>::load((const T *)p.gpre + crow * p.ld_gpre + n, p0, p1);
 #pragma unroll
           for (int j = 0; j < 4; ++j) { v0[j] *= gelu_grad_f(p0[j]); v1[j] *= gelu_grad_f(p1[j]); }
         }
@@ -260,8 +257,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
           *(f32x4 *)((float *)p.C + crow * p.ldc + n) = v0;
           *(f32x4 *)((float *)p.C + crow * p.ldc + n + 4) = v1;
         } else {
-          Vec4<T>::store((T *)p.C + crow * p.ldc + n, v0);
-          Vec4<T>::store((T *)p.C + crow * p.ldc + n + 4, v1);
+          Vec8<T>::store((T *)p.C + crow * p.ldc + n, v0, v1);
         }
       }
     }
