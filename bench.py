@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--ep", action="store_true", help="N > 1: shard the experts over the ranks (expert parallel, "
+                    "all-to-all over RCCL) instead of replicating them")
     return ap.parse_args()
 
 
@@ -136,7 +138,9 @@ def main():
     cfg = BackboneConfig(**VIT_SMALL_MOE)
     dtype = torch.float16 if args.dtype == "f16" else torch.float32
     params = init_params(cfg, seed=1)                       # same weights on every rank
-    eng = BackboneEngine(cfg, params, batch=args.batch, dtype=dtype, device=str(dev))
+    use_ep = args.ep and world > 1
+    eng = BackboneEngine(cfg, params, batch=args.batch, dtype=dtype, device=str(dev),
+                         ep_world=world if use_ep else 1, ep_rank=rank if use_ep else 0)
     g = torch.Generator().manual_seed(1000 + rank)          # each rank its own images
     images = torch.randn(args.batch, 3, *cfg.img_size, generator=g).to(dev)
     dtok = (torch.randn(args.batch, cfg.num_tokens, cfg.embed_dim, generator=g) * 0.05).to(dev)
@@ -152,9 +156,7 @@ def main():
             eng.backward(dtok, cv_weight=CV_WEIGHT)
 
     def sync_grads():
-        if world > 1:
-            dist.all_reduce(flat)                           # RCCL over xGMI; mean over ranks
-            flat.div_(world)
+        eng.sync_grads(world=world)                         # RCCL over xGMI; mean over ranks (experts stay local under EP)
 
     def step():
         compute_step()
@@ -177,7 +179,7 @@ def main():
     # into a hipGraph and replay it (the launch-bound inner loop is the graph, not the Python loop).
     run = step
     graph = None
-    if not args.no_graph:
+    if not args.no_graph and not use_ep:       # EP reads the per-layer counts on the host: not capturable
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -251,7 +253,8 @@ def main():
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "task_passes": ntasks,
                    "tokens_per_image": cfg.num_tokens, "cv_loss_weight": CV_WEIGHT,
                    "launch": "hipGraph replay" if graph is not None else "eager",
-                   "parallelism": "single" if world == 1 else f"dp{world} (replicated experts, RCCL all-reduce)"},
+                   "parallelism": "single" if world == 1 else (f"dp{world}+ep{world} (experts sharded, RCCL all-to-all + all-reduce)"
+                                                                    if use_ep else f"dp{world} (replicated experts, RCCL all-reduce)")},
         "model_tflops": round(step_flops * args.steps / dt / 1e12 * world, 2),
         "roofline": roofline,
     }

@@ -57,11 +57,15 @@ def cv_squared_grad(x: torch.Tensor) -> torch.Tensor:
 
 class BackboneEngine:
     def __init__(self, cfg, params: Dict[str, torch.Tensor], batch: int, dtype=torch.float16,
-                 device="cuda:0"):
+                 device="cuda:0", ep_group=None, ep_world: int = 1, ep_rank: int = 0):
+        """params: GLOBAL parameters (all E experts).  With ep_world > 1 this rank keeps experts
+        [ep_rank*E/W, (ep_rank+1)*E/W) (utils/common_config.py:179-185) and exchanges routed rows with
+        the other ranks over torch.distributed (RCCL) - see _experts_fwd_ep."""
         self.cfg = cfg
         self.dev = torch.device(device)
         self.dt = dtype
         self.B = batch
+        self.ep_group, self.ep_world, self.ep_rank = ep_group, int(ep_world), int(ep_rank)
         self.D = cfg.embed_dim
         self.heads = cfg.num_heads
         self.dh = self.D // self.heads
@@ -76,7 +80,14 @@ class BackboneEngine:
         self.Hm = int(self.D * cfg.moe_mlp_ratio)
         self.R = self.T * self.k
         self.depth = cfg.depth
-        self.params = {n: p.to(self.dev, torch.float32).contiguous() for n, p in params.items()}
+        assert self.E % self.ep_world == 0, "experts must divide evenly over the EP ranks"
+        self.E_loc = self.E // self.ep_world
+        is_exp = lambda n: ".mlp.experts." in n                                  # noqa: E731
+        lo, hi = self.ep_rank * self.E_loc, (self.ep_rank + 1) * self.E_loc
+        names = [n for n in params if not is_exp(n)] + [n for n in params if is_exp(n)]     # experts last
+        self.params = {n: (params[n][lo:hi] if (is_exp(n) and self.ep_world > 1) else params[n])
+                       .to(self.dev, torch.float32).contiguous() for n in names}
+        self.n_dense = sum(p.numel() for n, p in self.params.items() if not is_exp(n))
         # one flat fp32 gradient buffer (views per parameter): zeroing is one memset and the data-parallel
         # sync is one RCCL all-reduce (xGMI is point-to-point: few large collectives)
         total = sum(p.numel() for p in self.params.values())
@@ -240,20 +251,107 @@ class BackboneEngine:
                 g = ops.gate_fwd(a["h2"], wg_tok, self.k, logit_bias=None if tsf_bias is None else tsf_bias[i],
                                  noise=noise, noise_std=std, dense=True)
                 a["gate"] = g
-                r = ops.route_build(g["idx32"], self.E)
-                a["route"] = r
-                ops.gemm_nt(a["h2"], self.wc[b + "mlp.experts.htoh4"], a["hid"], M=self.R,
-                            bias=p[b + "mlp.experts.htoh4.bias"], act=M3_ACT_GELU, pre_out=a["hid_pre"],
-                            a_row_idx=r.row_of_slot, a_row_div=self.k, group_offsets=r.offsets,
-                            tile_starts=r.tile_starts)
-                ops.gemm_nt(a["hid"], self.wc[b + "mlp.experts.h4toh"], a["y"], M=self.R,
-                            bias=p[b + "mlp.experts.h4toh.bias"], c_row_idx=r.row_of_slot, group_offsets=r.offsets,
-                            tile_starts=r.tile_starts)
+                if self.ep_world > 1:
+                    self._experts_fwd_ep(i, a, g)
+                else:
+                    r = ops.route_build(g["idx32"], self.E)
+                    a["route"] = r
+                    ops.gemm_nt(a["h2"], self.wc[b + "mlp.experts.htoh4"], a["hid"], M=self.R,
+                                bias=p[b + "mlp.experts.htoh4.bias"], act=M3_ACT_GELU, pre_out=a["hid_pre"],
+                                a_row_idx=r.row_of_slot, a_row_div=self.k, group_offsets=r.offsets,
+                                tile_starts=r.tile_starts)
+                    ops.gemm_nt(a["hid"], self.wc[b + "mlp.experts.h4toh"], a["y"], M=self.R,
+                                bias=p[b + "mlp.experts.h4toh.bias"], c_row_idx=r.row_of_slot,
+                                group_offsets=r.offsets, tile_starts=r.tile_starts)
                 ops.combine_fwd(a["y"], g["score"], a["x1"], a["x2"])
                 # cv_loss = cv^2(importance) + cv^2(load)   (vision_transformer_moe.py:453-459,540)
                 total_cv = total_cv + cv_squared(g["importance"]) + cv_squared(g["load"].float())
             x = a["x2"]
         return x.view(B, self.N, D), total_cv
+
+    # ------------------------------------------------------------- expert parallel
+    def _a2a(self, x, in_splits, out_splits):
+        import torch.distributed as dist
+        out = torch.empty((sum(out_splits),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_to_all_single(out, x.contiguous(), output_split_sizes=out_splits, input_split_sizes=in_splits,
+                               group=self.ep_group)
+        return out
+
+    def _experts_fwd_ep(self, i, a, g):
+        """EP forward of one MoE layer: ONE count exchange + ONE row exchange each way (m3vit_amd/ep.py has
+        the same logic for the module API).  Rows are routed by GLOBAL expert id, so the expert-major send
+        buffer is already grouped by destination rank; received rows are regrouped from (src, expert) to
+        (expert, src) order for the local grouped GEMMs."""
+        import torch.distributed as dist
+        from .ep import ExchangePlan
+        b = f"blocks.{i}."
+        p, k, D, dev = self.params, self.k, self.D, self.dev
+        r = ops.route_build(g["idx32"], self.E, want_counts64=True)
+        a["route"] = r
+        x_send = self._e(self.R, D)
+        ops.gather_rows(a["h2"], r.row_of_slot, x_send, div=k)
+        recv = torch.empty_like(r.counts64)
+        dist.all_to_all_single(recv, r.counts64, group=self.ep_group)
+        plan = ExchangePlan(r.counts64.tolist(), recv.tolist(), self.ep_world, self.E_loc)   # host sync (sizes)
+        n = plan.n_recv
+        x_recv = self._a2a(x_send, plan.in_splits, plan.out_splits)
+        ep = dict(plan=plan, n=n)
+        ep["rg"] = torch.tensor(plan.regroup, dtype=torch.int32, device=dev)
+        ep["rgi"] = torch.tensor(plan.regroup_inv, dtype=torch.int32, device=dev)
+        cnt = torch.tensor(plan.fwd_expert_count, dtype=torch.int32, device=dev)
+        z = torch.zeros(1, dtype=torch.int32, device=dev)
+        ep["offsets"] = torch.cat((z, torch.cumsum(cnt, 0).to(torch.int32))).contiguous()
+        ep["tile_starts"] = torch.cat((z, torch.cumsum((cnt + 127) // 128, 0).to(torch.int32))).contiguous()
+        y_recv = self._e(n, D)
+        if n > 0:
+            ep["x_exp"] = ops.gather_rows(x_recv, ep["rg"], self._e(n, D))
+            ep["hid_pre"], ep["hid"] = self._e(n, self.Hm), self._e(n, self.Hm)
+            ops.gemm_nt(ep["x_exp"], self.wc[b + "mlp.experts.htoh4"], ep["hid"], M=n,
+                        bias=p[b + "mlp.experts.htoh4.bias"], act=M3_ACT_GELU, pre_out=ep["hid_pre"],
+                        group_offsets=ep["offsets"], tile_starts=ep["tile_starts"])
+            y_exp = self._e(n, D)
+            ops.gemm_nt(ep["hid"], self.wc[b + "mlp.experts.h4toh"], y_exp, M=n, bias=p[b + "mlp.experts.h4toh.bias"],
+                        group_offsets=ep["offsets"], tile_starts=ep["tile_starts"])
+            ops.gather_rows(y_exp, ep["rgi"], y_recv)
+        y_send = self._a2a(y_recv, plan.out_splits, plan.in_splits)
+        ops.gather_rows(y_send, r.pos, a["y"])                       # back to token-major [T*k, D]
+        a["ep"] = ep
+
+    def _experts_bwd_ep(self, i, a):
+        """mirror of _experts_fwd_ep: self.s_dy (token-major d y) -> expert grads (local experts only) and
+        self.s_dxe (token-major d of the routed input copies)."""
+        b = f"blocks.{i}."
+        k, D, r, ep = self.k, self.D, a["route"], a["ep"]
+        plan, n = ep["plan"], ep["n"]
+        dy_send = ops.gather_rows(self.s_dy, r.row_of_slot, self._e(self.R, D))
+        dy_recv = self._a2a(dy_send, plan.in_splits, plan.out_splits)
+        dx_recv = self._e(n, D)
+        if n > 0:
+            dy_exp = ops.gather_rows(dy_recv, ep["rg"], self._e(n, D))
+            self._wgrad(dy_exp, ep["hid"], b + "mlp.experts.h4toh.weight", M=n, group_offsets=ep["offsets"],
+                        bias=b + "mlp.experts.h4toh.bias")
+            dhp = self._e(n, self.Hm)
+            ops.gemm_nt(dy_exp, self.wt[b + "mlp.experts.h4toh"], dhp, M=n, gelu_grad_pre=ep["hid_pre"],
+                        group_offsets=ep["offsets"], tile_starts=ep["tile_starts"])
+            self._wgrad(dhp, ep["x_exp"], b + "mlp.experts.htoh4.weight", M=n, group_offsets=ep["offsets"],
+                        bias=b + "mlp.experts.htoh4.bias")
+            dx_exp = self._e(n, D)
+            ops.gemm_nt(dhp, self.wt[b + "mlp.experts.htoh4"], dx_exp, M=n, group_offsets=ep["offsets"],
+                        tile_starts=ep["tile_starts"])
+            ops.gather_rows(dx_exp, ep["rgi"], dx_recv)
+        dx_send = self._a2a(dx_recv, plan.out_splits, plan.in_splits)
+        ops.gather_rows(dx_send, r.pos, self.s_dxe)
+
+    def sync_grads(self, group=None, world: int = 1):
+        """Data-parallel gradient sync (mean): everything when experts are replicated, only the non-expert
+        slice of the flat buffer under expert parallelism (expert params have dp_comm == "none",
+        custom_moe_layer.py:159)."""
+        if world <= 1:
+            return
+        import torch.distributed as dist
+        buf = self.flat_grads[: self.n_dense] if self.ep_world > 1 else self.flat_grads
+        dist.all_reduce(buf, group=group)
+        buf.div_(world)
 
     # ----------------------------------------------------------------- backward
     def _wgrad(self, dC, A, name, M=None, bias=None, **kw):
@@ -285,15 +383,19 @@ class BackboneEngine:
             else:
                 g, r = a["gate"], a["route"]
                 ops.combine_bwd(dx, a["y"], g["score"], self.s_dy, self.s_dscore)
-                dhp = self.s_dpre[: R * self.Hm].view(R, self.Hm)
-                self._wgrad(self.s_dy, a["hid"], b + "mlp.experts.h4toh.weight", M=R, c_row_idx=r.row_of_slot,
-                            group_offsets=r.offsets, bias=b + "mlp.experts.h4toh.bias")
-                ops.gemm_nt(self.s_dy, self.wt[b + "mlp.experts.h4toh"], dhp, M=R, gelu_grad_pre=a["hid_pre"],
-                            a_row_idx=r.row_of_slot, a_row_div=1, group_offsets=r.offsets, tile_starts=r.tile_starts)
-                self._wgrad(dhp, a["h2"], b + "mlp.experts.htoh4.weight", M=R, a_row_idx=r.row_of_slot, a_row_div=k,
-                            group_offsets=r.offsets, bias=b + "mlp.experts.htoh4.bias")
-                ops.gemm_nt(dhp, self.wt[b + "mlp.experts.htoh4"], self.s_dxe, M=R, c_row_idx=r.row_of_slot,
-                            group_offsets=r.offsets, tile_starts=r.tile_starts)
+                if self.ep_world > 1:
+                    self._experts_bwd_ep(i, a)
+                else:
+                    dhp = self.s_dpre[: R * self.Hm].view(R, self.Hm)
+                    self._wgrad(self.s_dy, a["hid"], b + "mlp.experts.h4toh.weight", M=R, c_row_idx=r.row_of_slot,
+                                group_offsets=r.offsets, bias=b + "mlp.experts.h4toh.bias")
+                    ops.gemm_nt(self.s_dy, self.wt[b + "mlp.experts.h4toh"], dhp, M=R, gelu_grad_pre=a["hid_pre"],
+                                a_row_idx=r.row_of_slot, a_row_div=1, group_offsets=r.offsets,
+                                tile_starts=r.tile_starts)
+                    self._wgrad(dhp, a["h2"], b + "mlp.experts.htoh4.weight", M=R, a_row_idx=r.row_of_slot,
+                                a_row_div=k, group_offsets=r.offsets, bias=b + "mlp.experts.htoh4.bias")
+                    ops.gemm_nt(dhp, self.wt[b + "mlp.experts.htoh4"], self.s_dxe, M=R, c_row_idx=r.row_of_slot,
+                                group_offsets=r.offsets, tile_starts=r.tile_starts)
                 ops.combine_fwd(self.s_dxe, self.ones_k, None, self.s_dh32)       # dh2 = sum_j dxe[t,j]
                 # gate: d score from the combine, d importance from the cv loss
                 d_imp = cv_squared_grad(g["importance"]) * cv_weight if cv_weight != 0.0 else None

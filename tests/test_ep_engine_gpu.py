@@ -1,0 +1,85 @@
+"""GPU box, 2 ranks on ONE GPU over gloo (RCCL refuses two ranks on one device; the exchange code is
+backend-agnostic): the engine's expert-parallel path against the same engine with all experts local."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def rel(a, b):
+    a = a.detach().double().cpu().flatten(); b = b.detach().double().cpu().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from m3vit_amd.config import BackboneConfig, init_params
+        from m3vit_amd.engine import BackboneEngine
+        torch.cuda.set_device(0)
+        cfg = BackboneConfig(img_size=(32, 48), embed_dim=64, depth=4, num_heads=2, moe_experts=4, moe_top_k=2,
+                             gate_dim=66, multi_gate=True)
+        P = init_params(cfg, seed=3, zero_bias=False)
+        B = 3
+        g = torch.Generator().manual_seed(50 + rank)
+        img = torch.randn(B, 3, 32, 48, generator=g).cuda()
+        dtok = (torch.randn(B, cfg.num_tokens, 64, generator=g) * 0.1).cuda()
+        ref = BackboneEngine(cfg, P, batch=B, dtype=torch.float32)                       # all 4 experts local
+        ep = BackboneEngine(cfg, P, batch=B, dtype=torch.float32, ep_world=world, ep_rank=rank)
+        assert ep.params["blocks.1.mlp.experts.htoh4.weight"].shape[0] == 2
+        for task in (0, 1):
+            t_ref, cv_ref = ref.forward(img, task)
+            t_ep, cv_ep = ep.forward(img, task)
+            assert rel(t_ep, t_ref) < 1e-5, ("tokens", task, rel(t_ep, t_ref))
+            assert abs(float(cv_ep) - float(cv_ref)) < 1e-5
+            ref.backward(dtok, cv_weight=0.01)
+            ep.backward(dtok, cv_weight=0.01)
+        lo = rank * 2
+        bad = []
+        for n, gr in ep.grads.items():
+            gref = ref.grads[n]
+            if ".mlp.experts." in n:
+                tot = gref.clone(); dist.all_reduce(tot)            # this rank's experts saw tokens of BOTH ranks
+                e = rel(gr, tot[lo:lo + 2])
+            else:
+                e = rel(gr, gref)                                   # before the DP sync: own images only
+            if e > 2e-4:
+                bad.append((n, e))
+        assert not bad, bad
+        # DP sync touches only the non-expert slice under EP
+        before = ep.flat_grads.clone()
+        ep.sync_grads(world=world)
+        assert torch.equal(ep.flat_grads[ep.n_dense:], before[ep.n_dense:])
+        m = before[: ep.n_dense].clone(); dist.all_reduce(m); m /= world
+        assert torch.allclose(ep.flat_grads[: ep.n_dense], m, rtol=1e-6, atol=1e-8)
+        q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_engine_expert_parallel_two_ranks_one_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert all(r[1] == "ok" for r in res), res
