@@ -101,6 +101,10 @@ def lib():
             raise M3Error(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C m3vit_amd/csrc` (hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+        # torch ships its own HIP runtime (libamdhip64): import it FIRST so that this library binds to the
+        # same runtime instance (and therefore the same device context / streams) instead of a second copy
+        # from /opt/rocm, which would see "no ROCm-capable device" for torch-allocated memory.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)       # AttributeError here = header/library mismatch
