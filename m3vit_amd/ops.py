@@ -115,6 +115,12 @@ def route_build(idx32: torch.Tensor, E: int, want_counts64=False) -> Route:
     r.tile_starts = torch.empty(E + 1, dtype=torch.int32, device=dev)
     r.counts64 = torch.empty(E, dtype=torch.int64, device=dev) if want_counts64 else None
     ws = torch.empty(int(lib().m3_route_ws_elems(n, E)), dtype=torch.int32, device=dev)
+    if n == 0:                                   # nothing routed: all-zero metadata, no launch
+        for t_ in (r.counts, r.offsets, r.tile_starts):
+            t_.zero_()
+        if r.counts64 is not None:
+            r.counts64.zero_()
+        return r
     check(lib().m3_route_build(_p(idx32), n, E, _p(r.counts), _p(r.offsets), _p(r.pos), _p(r.row_of_slot),
                                _p(r.tile_starts), _p(r.counts64), _p(ws), _stream()), "m3_route_build")
     return r
@@ -152,6 +158,8 @@ def gemm_nt(A, B, C, *, M=None, bias=None, act=M3_ACT_NONE, pre_out=None, gelu_g
         _req(bias, torch.float32, "bias")
     if residual is not None:
         _req(residual, torch.float32, "residual")
+    if M == 0:
+        return C
     check(lib().m3_gemm_nt(byref(a), _stream()), "m3_gemm_nt")
     return C
 

