@@ -81,6 +81,15 @@ def init_params(cfg: BackboneConfig, seed: int = 1, zero_bias: bool = True) -> D
     P = {"patch_embed.proj.weight": _tn((D, cfg.in_chans, cfg.patch_size, cfg.patch_size), .02, g),
          "patch_embed.proj.bias": bias(D),
          "cls_token": _tn((1, 1, D), .02, g), "pos_embed": _tn((1, cfg.num_tokens, D), .02, g)}
+    if cfg.gate_task_specific_dim >= 0 and not cfg.multi_gate:
+        # gate_task_represent = new_Mlp(num_tasks, gtsd, gtsd) (vision_transformer_moe.py:638-641, :263-281)
+        gt = cfg.gate_task_specific_dim
+        P["gate_task_represent.fc1.weight"] = _tn((gt, cfg.num_tasks), .02, g)
+        P["gate_task_represent.fc1.bias"] = bias(gt)
+        P["gate_task_represent.fc2.weight"] = _tn((gt, gt), .02, g)
+        P["gate_task_represent.fc2.bias"] = bias(gt)
+        P["gate_task_represent.norm.weight"] = torch.ones(gt) if zero_bias else 1 + _tn((gt,), .02, g)
+        P["gate_task_represent.norm.bias"] = bias(gt)
     for i in range(cfg.depth):
         b = f"blocks.{i}."
         for n in ("norm1", "norm2"):

@@ -164,7 +164,9 @@ class BackboneEngine:
         self.ws_gate_dw = self._e(ops.lib().m3_gate_dw_blocks(T) * self.cfg_d_gate() * self.E, dtype=f32)
         # gate backward through the MFMA GEMMs when E rows are 16-byte multiples
         es = 2 if self.dt == torch.float16 else 4
-        self.gate_via_gemm = (self.E * es) % 16 == 0 and self.cfg.gate_task_specific_dim < 0
+        self.gate_via_gemm = (self.E * es) % 16 == 0
+        # task-conditioned gate (custom_moe_layer.py:161-181): one shared w_gate [D + gtsd, E] per MoE block
+        self.task_cond = self.cfg.gate_task_specific_dim >= 0 and not self.cfg.multi_gate
         self.s_dl_t = self._e(T, self.E)
 
     def cfg_d_gate(self):
@@ -217,11 +219,51 @@ class BackboneEngine:
             return b + f"{task_id}.w_gate"           # custom_moe_layer.py:213-214
         return b + "w_gate"
 
+    def _task_feature(self, task_id):
+        """tsf = gate_task_represent(one_hot(task_id)) (vision_transformer_moe.py:793-797; new_Mlp :263-281:
+        fc1 -> GELU -> fc2 -> LayerNorm) and the per-block logit bias tsf @ w_gate[D:], which is what
+        cat(inp, tsf.repeat(T, 1)) @ w_gate (custom_moe_layer.py:176-179) adds to every token's logits.
+        A [num_tasks] -> [gtsd] vector MLP: kept as a torch autograd graph over leaf copies of its six
+        parameters; backward() finishes it from the d(logit bias) the gate kernels produce."""
+        import torch.nn.functional as F
+        p, D = self.params, self.D
+        names = [f"gate_task_represent.{n}" for n in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias",
+                                                      "norm.weight", "norm.bias")]
+        leaves = [p[n].detach().requires_grad_() for n in names]
+        with torch.enable_grad():
+            h = F.gelu(leaves[0][:, task_id] + leaves[1])          # fc1(one_hot(task)) = column task of fc1.weight
+            h = F.linear(h, leaves[2], leaves[3])
+            tsf = F.layer_norm(h, (h.shape[-1],), leaves[4], leaves[5], 1e-6)
+        self._tsf = dict(names=names, leaves=leaves, tsf=tsf)
+        tv = tsf.detach()
+        return {i: tv @ p[self._gate_weight(i, task_id)][D:] for i in range(self.depth) if self.is_moe[i]}
+
+    def _task_feature_bwd(self):
+        """d(logit bias) of every MoE block -> w_gate[D:] rows, tsf, and the gate_task_represent parameters."""
+        p, gr, D = self.params, self.grads, self.D
+        t = self._tsf
+        tv = t["tsf"].detach()
+        d_tsf = torch.zeros_like(tv)
+        for i in range(self.depth):
+            if not self.is_moe[i]:
+                continue
+            a = self.act[i]
+            dlb = a.pop("d_logit_bias")
+            gr[a["wname"]][D:].addr_(tv, dlb)
+            d_tsf += p[a["wname"]][D:] @ dlb
+        for n, g in zip(t["names"], torch.autograd.grad(t["tsf"], t["leaves"], d_tsf)):
+            gr[n] += g
+        self._tsf = None
+
     def forward(self, images: torch.Tensor, task_id: Optional[int], tsf_bias=None, noises=None):
-        """Returns (tokens fp32 [B,N,D], total_cv_loss).  tsf_bias: per-MoE-block logit bias for the
-        task-conditioned gate (tsf @ w_gate[D:]); noises: {block: [T,E]} caller-supplied N(0,1)."""
+        """Returns (tokens fp32 [B,N,D], total_cv_loss).  noises: {block: [T,E]} caller-supplied N(0,1).
+        Task-conditioned configs compute the per-block logit bias tsf @ w_gate[D:] here (tsf_bias overrides
+        it with a caller-supplied {block: [E]} and then no gradient flows to the task embedding)."""
         P_, p = self.P, self.params
         B, T, D = self.B, self.T, self.D
+        self._tsf = None
+        if self.task_cond and tsf_bias is None and task_id is not None:
+            tsf_bias = self._task_feature(task_id)
         ops.im2row(images, P_, self.rows)
         ops.gemm_nt(self.rows, self.wc["patch_embed.proj"], self.patch, bias=p["patch_embed.proj.bias"])
         ops.assemble_tokens(self.patch, p["cls_token"], p["pos_embed"], B, self.np_, D, self.x0)
@@ -400,24 +442,21 @@ class BackboneEngine:
                 # gate: d score from the combine, d importance from the cv loss
                 d_imp = cv_squared_grad(g["importance"]) * cv_weight if cv_weight != 0.0 else None
                 dl = ops.gate_bwd_logits(g["noisy"], g["idx"], self.s_dscore, d_imp, k)
-                wg = p[a["wname"]]
+                # token rows of w_gate ([:D]; the task-conditioned rows [D:] are handled by _task_feature_bwd)
+                wg, dwg = p[a["wname"]][:D], gr[a["wname"]][:D]
                 if self.gate_via_gemm:
                     # d w_gate += h2^T dl (TN GEMM) ; dh2 += dl w_gate^T (NT GEMM, K = E)
                     if self.dt == torch.float32:
                         dl_t, wg_t = dl, wg
                     else:
-                        dl_t, wg_t = ops.cast_f32(dl, self.s_dl_t), self.wgate_c[a["wname"]]
-                    ops.wgrad_tn(a["h2"], dl_t, gr[a["wname"]], beta=1, ws=self.ws_wgrad)
+                        dl_t, wg_t = ops.cast_f32(dl, self.s_dl_t), self.wgate_c[a["wname"]][:D]
+                    ops.wgrad_tn(a["h2"], dl_t, dwg, beta=1, ws=self.ws_wgrad)
                     ops.gemm_nt(dl_t, wg_t, self.s_dh32, residual=self.s_dh32)
-                elif wg.shape[0] == D:
-                    ops.gate_bwd_params(a["h2"], wg, dl, d_w_gate=gr[a["wname"]], beta_dw=1, dx=self.s_dh32,
+                else:
+                    ops.gate_bwd_params(a["h2"], wg, dl, d_w_gate=dwg, beta_dw=1, dx=self.s_dh32,
                                         beta_dx=1, part_dw=self.ws_gate_dw)
-                else:   # task-conditioned: only the token rows of w_gate here; tsf rows via d(logit_bias)
-                    dwt = torch.zeros(D, self.E, device=self.dev)
-                    ops.gate_bwd_params(a["h2"], wg[:D].contiguous(), dl, d_w_gate=dwt, beta_dw=0, dx=self.s_dh32,
-                                        beta_dx=1, part_dw=self.ws_gate_dw)
-                    gr[a["wname"]][:D] += dwt
-                    a["d_logit_bias"] = dl.sum(0)
+                if self._tsf is not None:
+                    a["d_logit_bias"] = ops.colsum(dl, torch.empty(self.E, device=self.dev), ws=self.ws_colsum)
                 dh2 = self.s_dh32
             ops.layernorm_bwd(dh2, a["x1"], a["mean2"], a["rstd2"], p[b + "norm2.weight"], dx, other,
                               gr[b + "norm2.weight"], gr[b + "norm2.bias"], beta=1, ws=self.ws_ln,
@@ -439,4 +478,6 @@ class BackboneEngine:
         ops.tokens_bwd(dx, B, self.np_, D, self.s_dpatch, gr["pos_embed"].view(self.N, D), gr["cls_token"].view(D), beta=1)
         gw = gr["patch_embed.proj.weight"].view(D, -1)
         ops.wgrad_tn(self.s_dpatch, self.rows, gw, beta=1, ws=self.ws_wgrad, db=gr["patch_embed.proj.bias"])
+        if self._tsf is not None:
+            self._task_feature_bwd()
         return dx

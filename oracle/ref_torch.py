@@ -27,7 +27,7 @@ __all__ = [
 # --------------------------------------------------------------------------- gate
 def gate_vmoe(x: torch.Tensor, w_gate: torch.Tensor, top_k: int,
               noise: Optional[torch.Tensor] = None, noise_std: float = 0.0,
-              training: bool = True):
+              training: bool = True, idx_override: Optional[torch.Tensor] = None):
     """NoisyGate_VMoE.forward, models/moe/ckpt/noisy_gate_vmoe.py:80-264
     (torch-only twin models/moe/gates.py:405-466).
 
@@ -37,6 +37,10 @@ def gate_vmoe(x: torch.Tensor, w_gate: torch.Tensor, top_k: int,
     score = top_logits[:, :k], idx = top_idx[:, :k] (:202-204), NOT renormalised;
     gates = zeros.scatter(1, idx, score) (:206-207).
     Returns ((idx, score), clean, noisy, std, top_logits, gates) (:257-264).
+
+    idx_override (test aid, not in the reference): use these expert indices instead of the top-k and
+    take their scores from the same softmax - lets a reduced-precision run be checked value-for-value
+    on ITS OWN routing once that routing has been verified separately on its own gate input.
     """
     x2 = x.reshape(-1, x.shape[-1])
     E = w_gate.shape[1]
@@ -50,6 +54,9 @@ def gate_vmoe(x: torch.Tensor, w_gate: torch.Tensor, top_k: int,
     top_logits, top_idx = p.topk(min(top_k + 1, E), dim=1)
     score = top_logits[:, :top_k]
     idx = top_idx[:, :top_k]
+    if idx_override is not None:
+        idx = idx_override.to(torch.int64)
+        score = p.gather(1, idx)
     gates = torch.zeros_like(p).scatter(1, idx, score)
     return (idx, score), clean, noisy, std, top_logits, gates
 
@@ -141,7 +148,7 @@ def moe_dispatch_ffn(x: torch.Tensor, idx: torch.Tensor, w1, b1, w2, b2):
 
 
 def moe_layer(x: torch.Tensor, gate_x: torch.Tensor, w_gate, w1, b1, w2, b2, top_k: int,
-              noise=None, noise_std: float = 0.0, training: bool = True):
+              noise=None, noise_std: float = 0.0, training: bool = True, idx_override=None):
     """FMoETransformerMLP.forward / forward_moe, models/moe/ckpt/custom_moe_layer.py:161-322
     (gate :213-219, dispatch :263-265, combine bmm(score[T,1,k], out[T,k,D]) :291-305).
     gate_x is the gate input ([T,D] or [T,D+gtsd] after the task-conditioning cat :176-179).
@@ -149,7 +156,7 @@ def moe_layer(x: torch.Tensor, gate_x: torch.Tensor, w_gate, w1, b1, w2, b2, top
     shp = x.shape
     x2 = x.reshape(-1, shp[-1])
     (idx, score), clean, noisy, std, top_logits, gates = gate_vmoe(
-        gate_x, w_gate, top_k, noise, noise_std, training)
+        gate_x, w_gate, top_k, noise, noise_std, training, idx_override)
     y = moe_dispatch_ffn(x2, idx, w1, b1, w2, b2)            # [T*k, D]
     y = y.view(-1, top_k, y.shape[-1])
     out = torch.bmm(score.view(-1, 1, top_k), y).reshape(-1, y.shape[-1])
@@ -300,7 +307,7 @@ def patch_embed(images, w, b, cls_token, pos_embed):
 
 
 def block_forward(params, cfg: BackboneCfg, i: int, x, task_id: Optional[int], tsf=None,
-                  training: bool = True, noise=None):
+                  training: bool = True, noise=None, idx_override=None):
     """Block._ckpt_main_moe / _ckpt_non_moe, vision_transformer_moe.py:438-487, and the
     cv-loss part of Block.forward :539-543 (drop_path = 0, mlp_drop = 0).
     Returns (x_out, cv_loss or None, aux dict)."""
@@ -328,7 +335,8 @@ def block_forward(params, cfg: BackboneCfg, i: int, x, task_id: Optional[int], t
         normed, gate_x, w_gate,
         p[b + "mlp.experts.htoh4.weight"], p[b + "mlp.experts.htoh4.bias"],
         p[b + "mlp.experts.h4toh.weight"], p[b + "mlp.experts.h4toh.bias"],
-        cfg.moe_top_k, noise=noise, noise_std=cfg.vmoe_noisy_std, training=training)
+        cfg.moe_top_k, noise=noise, noise_std=cfg.vmoe_noisy_std, training=training,
+        idx_override=idx_override)
     x = x + out
     importance = gates.sum(0)                                  # :453
     E = gates.shape[1]
@@ -338,11 +346,11 @@ def block_forward(params, cfg: BackboneCfg, i: int, x, task_id: Optional[int], t
         load = gates_to_load(gates)
     cv = (cv_squared(importance) + cv_squared(load)) if training else None   # :539-543
     return x, cv, {"importance": importance, "load": load, "idx": idx, "score": score,
-                   "gates": gates, "clean": clean}
+                   "gates": gates, "clean": clean, "gate_x": gate_x, "w_gate": w_gate}
 
 
 def backbone_forward(params, cfg: BackboneCfg, images, task_id: Optional[int], training: bool = True,
-                     noises=None):
+                     noises=None, route_override=None):
     """VisionTransformerMoE.forward_features, vision_transformer_moe.py:780-880:
     returns (tokens[B,N,D] of the last block, total_cv_loss)."""
     p = params
@@ -355,7 +363,8 @@ def backbone_forward(params, cfg: BackboneCfg, images, task_id: Optional[int], t
     aux_all = []
     for i in range(cfg.depth):
         noise = None if noises is None else noises.get(i)
-        x, cv, aux = block_forward(p, cfg, i, x, task_id, tsf, training, noise)
+        ovr = None if route_override is None else route_override.get(i)
+        x, cv, aux = block_forward(p, cfg, i, x, task_id, tsf, training, noise, ovr)
         if cv is not None:
             total_cv = total_cv + cv
         aux_all.append(aux)
