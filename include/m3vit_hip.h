@@ -56,26 +56,55 @@ int m3_device_query(char *name, int len);
  * idx32 i32 [T,k] copy for the routing kernels.
  * part_importance f32 [nblk,E], part_load i32 [nblk,E] with nblk =
  * m3_gate_num_blocks(T): per-block partial sums of gates.sum(0) and (gates>0).sum(0)
- * (vision_transformer_moe.py:453-459), reduced in fixed order by m3_gate_reduce.
+ * (vision_transformer_moe.py:453-459), reduced in fixed order by m3_gate_reduce /
+ * m3_balance_loss.
  * E in {2..64}, k < = 8, k <= E. */
 int m3_gate_num_blocks(int64_t T);
 int m3_gate_dw_blocks(int64_t T);
-int m3_gate_fwd(const void *x, int x_dtype, int64_t T, int D, int64_t ldx,
-                const float *w_gate, int E, const float *logit_bias,
-                const float *noise, float noise_std, int k,
-                int64_t *idx, int32_t *idx32, float *score, float *top_logits,
-                float *clean, float *noisy, float *gates,
-                float *part_importance, int32_t *part_load, void *stream);
+typedef struct m3_gate_fwd_args {
+  const void *x; int32_t x_dtype; int64_t T; int32_t D; int64_t ldx;
+  const float *w_gate; int32_t E;
+  const float *logit_bias;          /* [E] or NULL */
+  const float *noise;               /* [T,E] N(0,1) draws or NULL (randn_like at noisy_gate_vmoe.py:168) */
+  float noise_std;                  /* noise_std / E_tot * training, :92-93 */
+  int32_t k;
+  int64_t *idx; int32_t *idx32;     /* [T,k]; idx32 optional */
+  int32_t *idx_next;                /* [T] index of the (k+1)-th expert (top_idx[:, k], :198-200) or NULL */
+  float *score; float *top_logits;  /* [T,k], [T,min(k+1,E)] */
+  float *clean; float *noisy; float *gates;   /* dense [T,E] or NULL */
+  float *part_importance; int32_t *part_load; /* [nblk,E] */
+  float *part_load_prob;            /* [nblk,E] or NULL: partial sums of _prob_in_top_k
+                                       (vision_transformer_moe.py:33-71), the load of noisy training
+                                       (:456-457; needs noise, noise_std != 0, k < E, clean and noisy) */
+} m3_gate_fwd_args;
+int m3_gate_fwd(const m3_gate_fwd_args *args, void *stream);
 /* importance f32 [E], load i64 [E] from the per-block partials */
 int m3_gate_reduce(const float *part_importance, const int32_t *part_load, int nblk, int E,
                    float *importance, int64_t *load, void *stream);
-/* Backward of the gate: d_score [T,k] (from the combine) and d_importance [E]
- * (from cv_squared(importance), vision_transformer_moe.py:540) -> d_logits f32 [T,E]
- * through the scatter (:206-207) and the softmax (:197).  probs are recomputed from
- * `noisy` [T,E]. */
-int m3_gate_bwd_logits(const float *noisy, const int64_t *idx, const float *d_score,
-                       const float *d_importance, int64_t T, int E, int k,
-                       float *d_logits, void *stream);
+/* Block-level balance loss, vision_transformer_moe.py:453-459,540 with cv_squared :73-87 and
+ * _gates_to_load :23-31: reduces the partials (fixed order) to importance f32 [E], load i64 [E]
+ * (count form) and, when part_load_prob is given, load_prob f32 [E] (Normal-CDF form, which then
+ * replaces the count in the loss); loss = cv^2(importance) + cv^2(load) is written to loss_out and
+ * added to loss_acc (either may be NULL); d_importance / d_load_prob [E] receive d loss / d(.)
+ * (NULL to skip; the count form of load carries no gradient). */
+int m3_balance_loss(const float *part_importance, const int32_t *part_load, const float *part_load_prob,
+                    int nblk, int E, float *importance, int64_t *load, float *load_prob,
+                    float *loss_out, float *loss_acc, float *d_importance, float *d_load_prob, void *stream);
+/* Backward of the gate -> d_logits f32 [T,E] through the scatter (:206-207), the softmax (:197)
+ * and, for noisy training, the Normal-CDF load term.  Upstream gradients (each may be NULL):
+ * d_score [T,k] (from the combine), d_top [T,min(k+1,E)] (w.r.t. top_logits), d_importance [E] and
+ * d_load_prob [E] (from m3_balance_loss; both multiplied by balance_scale = the loss weight).
+ * probs are recomputed from `noisy` [T,E]; clean / top_logits / idx_next / noise_std are only read
+ * for d_load_prob (and idx_next for d_top). */
+typedef struct m3_gate_bwd_args {
+  const float *noisy; const float *clean; const float *top_logits;
+  const int64_t *idx; const int32_t *idx_next;
+  const float *d_score; const float *d_top; const float *d_importance; const float *d_load_prob;
+  float balance_scale; float noise_std;
+  int64_t T; int32_t E; int32_t k;
+  float *d_logits;
+} m3_gate_bwd_args;
+int m3_gate_bwd_logits(const m3_gate_bwd_args *args, void *stream);
 /* d_w_gate[D,E] (+)= x^T d_logits ; dx[T,D] (+)= d_logits w_gate^T  (noisy_gate_vmoe.py:91).
  * part_dw f32 [m3_gate_dw_blocks(T), D, E] workspace; dx fp32 accumulate (beta_dx 0/1). */
 int m3_gate_bwd_params(const void *x, int x_dtype, int64_t T, int D, int64_t ldx,

@@ -53,6 +53,29 @@ class WgradArgs(Structure):
     ]
 
 
+class GateFwdArgs(Structure):
+    _fields_ = [
+        ("x", c_void_p), ("x_dtype", c_int32), ("T", c_int64), ("D", c_int32), ("ldx", c_int64),
+        ("w_gate", c_void_p), ("E", c_int32),
+        ("logit_bias", c_void_p), ("noise", c_void_p), ("noise_std", c_float), ("k", c_int32),
+        ("idx", c_void_p), ("idx32", c_void_p), ("idx_next", c_void_p),
+        ("score", c_void_p), ("top_logits", c_void_p),
+        ("clean", c_void_p), ("noisy", c_void_p), ("gates", c_void_p),
+        ("part_importance", c_void_p), ("part_load", c_void_p), ("part_load_prob", c_void_p),
+    ]
+
+
+class GateBwdArgs(Structure):
+    _fields_ = [
+        ("noisy", c_void_p), ("clean", c_void_p), ("top_logits", c_void_p),
+        ("idx", c_void_p), ("idx_next", c_void_p),
+        ("d_score", c_void_p), ("d_top", c_void_p), ("d_importance", c_void_p), ("d_load_prob", c_void_p),
+        ("balance_scale", c_float), ("noise_std", c_float),
+        ("T", c_int64), ("E", c_int32), ("k", c_int32),
+        ("d_logits", c_void_p),
+    ]
+
+
 _V, _I, _L, _F = c_void_p, c_int, c_int64, c_float
 
 # name -> (restype, argtypes); every symbol include/m3vit_hip.h declares
@@ -62,9 +85,10 @@ SIGNATURES = {
     "m3_device_query": (c_int, [c_char_p, _I]),
     "m3_gate_num_blocks": (c_int, [_L]),
     "m3_gate_dw_blocks": (c_int, [_L]),
-    "m3_gate_fwd": (c_int, [_V, _I, _L, _I, _L, _V, _I, _V, _V, _F, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V]),
+    "m3_gate_fwd": (c_int, [POINTER(GateFwdArgs), _V]),
     "m3_gate_reduce": (c_int, [_V, _V, _I, _I, _V, _V, _V]),
-    "m3_gate_bwd_logits": (c_int, [_V, _V, _V, _V, _L, _I, _I, _V, _V]),
+    "m3_balance_loss": (c_int, [_V, _V, _V, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V]),
+    "m3_gate_bwd_logits": (c_int, [POINTER(GateBwdArgs), _V]),
     "m3_gate_bwd_params": (c_int, [_V, _I, _L, _I, _L, _V, _I, _V, _V, _V, _I, _V, _L, _I, _V]),
     "m3_route_ws_elems": (c_int64, [_L, _I]),
     "m3_route_build": (c_int, [_V, _L, _I, _V, _V, _V, _V, _V, _V, _V, _V]),

@@ -1,16 +1,19 @@
 // Fused task-aware router for gfx950: logits + noise + softmax + top-(k+1) + gates +
-// load-balance partials in one pass over the token rows.
+// load-balance partials in one pass over the token rows, and its backward.
 //
 // Replaces the 5-6 ATen kernels of NoisyGate_VMoE.forward
 // (models/moe/ckpt/noisy_gate_vmoe.py:91-93,168,197-207), the multi-gate select
 // (custom_moe_layer.py:213-217: the caller just passes that task's w_gate) and the
 // task-conditioning cat (custom_moe_layer.py:176-179: folded into logit_bias), plus the
-// importance / load summaries of vision_transformer_moe.py:453-459.
+// importance / load summaries and the cv^2 balance loss of
+// vision_transformer_moe.py:23-87,453-459,540.
 //
 // HBM-bound by design: each token row is read once (coalesced 16-byte loads, staged
-// through LDS so that every LANE then owns one TOKEN), w_gate is wave-uniform and comes
-// through the scalar cache, all E logits of a token live in that lane's registers, so
-// softmax and the top-(k+1) selection need no cross-lane traffic at all.
+// through LDS so that every LANE then owns one TOKEN).  A workgroup is 64 tokens x up to
+// 4 waves; wave w accumulates the logits of experts [w*EW, (w+1)*EW) for all 64 tokens
+// (w_gate rows are wave-uniform and come through the scalar cache), then wave 0 gathers
+// the E logits of each token into that lane's registers, so softmax and the top-(k+1)
+// selection need no cross-lane traffic at all.
 //
 // Arithmetic order is pinned (and mirrored by oracle/gate_route.c) so that expert
 // indices are bit-exact: sequential fmaf chain over d starting from the bias, selection
@@ -21,99 +24,142 @@
 
 namespace m3 {
 
-constexpr int GATE_TOK = 64;       // tokens per workgroup (one wave)
+constexpr int GATE_TOK = 64;       // tokens per workgroup
 constexpr int GATE_DW_TOK = 128;   // tokens per workgroup in the dW kernel
 constexpr int GATE_ROWB = 64;      // bytes of a token row staged per step
 
-template <typename T, int EPAD, bool EXACT>
-__global__ __launch_bounds__(GATE_TOK) void gate_fwd_kernel(
-    const char *__restrict__ x, int64_t T_, int D, int64_t ldx_b, const float *__restrict__ w, int E,
-    const float *__restrict__ bias, const float *__restrict__ noise, float noise_std, int k, int64_t *idx,
-    int32_t *idx32, float *score, float *top_logits, float *clean, float *noisy_out, float *gates,
-    float *part_imp, int32_t *part_load) {
+__device__ __forceinline__ float normal_cdf(float z) { return 0.5f * erfcf(-z * 0.70710678118654752f); }
+__device__ __forceinline__ float normal_pdf(float z) { return 0.3989422804014327f * expf(-0.5f * z * z); }
+
+struct GateFwdDev {
+  const char *x; int64_t T; int D; int64_t ldx_b;
+  const float *w; int E;
+  const float *bias; const float *noise; float noise_std; int k;
+  int64_t *idx; int32_t *idx32; int32_t *idx_next; float *score; float *top_logits;
+  float *clean; float *noisy; float *gates;
+  float *part_imp; int32_t *part_load; float *part_load_prob;
+};
+
+// EW = experts per wave, NW = EPAD / EW waves per workgroup
+template <typename T, int EPAD, int EW, bool EXACT>
+__global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const GateFwdDev p) {
+  constexpr int NW = EPAD / EW;
+  constexpr int NT = GATE_TOK * NW;
   constexpr int DC = GATE_ROWB / (int)sizeof(T);   // d per step
   constexpr int LDS_STRIDE = DC + 1;               // floats; odd -> conflict-free per-lane rows
-  __shared__ float sx[GATE_TOK * LDS_STRIDE];
-
-  const int lane = threadIdx.x;
-  const int64_t t0 = (int64_t)blockIdx.x * GATE_TOK;
-  const int64_t t = t0 + lane;
-  const bool tok_ok = t < T_;
-
-  float acc[EPAD];
-#pragma unroll
-  for (int e = 0; e < EPAD; ++e) acc[e] = (bias && (EXACT || e < E)) ? bias[e] : 0.f;
-
-  constexpr int CPR = GATE_ROWB / 16;              // 16-byte chunks per row per step = 8
+  constexpr int CPR = GATE_ROWB / 16;              // 16-byte chunks per row per step
   constexpr int EPC = 16 / (int)sizeof(T);         // elements per chunk
+  constexpr int NCH = GATE_TOK * CPR / NT;         // chunks per thread per step
+  __shared__ float sx[2][GATE_TOK * LDS_STRIDE];
+  __shared__ float slog[NW > 1 ? GATE_TOK * (EPAD + 1) : 1];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int e0 = wave * EW;
+  const int E = EXACT ? EPAD : p.E;
+  const int64_t T_ = p.T;
+  const int64_t t0 = (int64_t)blockIdx.x * GATE_TOK;
+  const int D = p.D;
   const int dbytes = D * (int)sizeof(T);
-  for (int d0b = 0; d0b < dbytes; d0b += GATE_ROWB) {
-    // stage 64 rows x GATE_ROWB bytes: chunk q = lane + 64*i -> row q / CPR, c = q % CPR
+  const int nsteps = (dbytes + GATE_ROWB - 1) / GATE_ROWB;
+
+  float acc[EW];
 #pragma unroll
-    for (int i = 0; i < CPR; ++i) {
-      const int q = lane + 64 * i;
+  for (int e = 0; e < EW; ++e) acc[e] = (p.bias && (EXACT || e0 + e < E)) ? p.bias[e0 + e] : 0.f;
+
+  // staging: chunk q = tid + NT*i -> row q / CPR, c = q % CPR; rows past T and bytes past D read as zero
+  u32x4 pre[NCH];
+  auto fetch = [&](int step) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int q = tid + NT * i;
       const int row = q / CPR, c = q % CPR;
       const int64_t tr = t0 + row;
-      const int cb = d0b + c * 16;
-      float v[EPC];
-      if (tr < T_ && cb < dbytes) {
-        const u32x4 raw = *(const u32x4 *)(x + tr * ldx_b + cb);
-        if constexpr (sizeof(T) == 2) {
-          const f16x8 h = __builtin_bit_cast(f16x8, raw);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
-        } else {
-          const f32x4 f = __builtin_bit_cast(f32x4, raw);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = f[j];
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < EPC; ++j) v[j] = 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < EPC; ++j) sx[row * LDS_STRIDE + c * EPC + j] = v[j];
+      const int cb = step * GATE_ROWB + c * 16;
+      pre[i] = (tr < T_ && cb < dbytes) ? *(const u32x4 *)(p.x + tr * p.ldx_b + cb) : u32x4{0u, 0u, 0u, 0u};
     }
-    __syncthreads();
-    const int d0 = d0b / (int)sizeof(T);
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int q = tid + NT * i;
+      const int row = q / CPR, c = q % CPR;
+      float *dst = &sx[buf][row * LDS_STRIDE + c * EPC];
+      if constexpr (sizeof(T) == 2) {
+        const f16x8 h = __builtin_bit_cast(f16x8, pre[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j] = (float)h[j];
+      } else {
+        const f32x4 f = __builtin_bit_cast(f32x4, pre[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = f[j];
+      }
+    }
+  };
+
+  fetch(0);
+  for (int step = 0; step < nsteps; ++step) {
+    const int buf = step & 1;
+    stash(buf);
+    __syncthreads();            // one barrier per step: the other buffer is only rewritten after the next one
+    if (step + 1 < nsteps) fetch(step + 1);
+    const float *xs = &sx[buf][lane * LDS_STRIDE];
+    const int d0 = step * DC;
     const int dn = (D - d0 < DC) ? (D - d0) : DC;
     int dd = 0;
-    if constexpr (EXACT && EPAD <= 16) {
-      // 4 rows of w_gate fetched by back-to-back scalar loads, then 4 x E fmas (chain order kept)
+    if constexpr (EXACT) {
+      // 4 rows of w_gate fetched by back-to-back scalar loads, then 4 x EW fmas (chain order kept)
       for (; dd + 4 <= dn; dd += 4) {
-        float wv[4][EPAD];
+        float wv[4][EW];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const float *wr = w + (int64_t)(d0 + dd + u) * E;
+          const float *wr = p.w + (int64_t)(d0 + dd + u) * EPAD + e0;
 #pragma unroll
-          for (int e = 0; e < EPAD; ++e) wv[u][e] = wr[e];
+          for (int e = 0; e < EW; ++e) wv[u][e] = wr[e];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const float xv = sx[lane * LDS_STRIDE + dd + u];
+          const float xv = xs[dd + u];
 #pragma unroll
-          for (int e = 0; e < EPAD; ++e) acc[e] = __builtin_fmaf(xv, wv[u][e], acc[e]);
+          for (int e = 0; e < EW; ++e) acc[e] = __builtin_fmaf(xv, wv[u][e], acc[e]);
         }
       }
     }
     for (; dd < dn; ++dd) {
-      const float xv = sx[lane * LDS_STRIDE + dd];
-      const float *wr = w + (int64_t)(d0 + dd) * E;   // wave-uniform -> scalar loads
+      const float xv = xs[dd];
+      const float *wr = p.w + (int64_t)(d0 + dd) * E + e0;   // wave-uniform -> scalar loads
 #pragma unroll
-      for (int e = 0; e < EPAD; ++e)
-        if (EXACT || e < E) acc[e] = __builtin_fmaf(xv, wr[e], acc[e]);
+      for (int e = 0; e < EW; ++e)
+        if (EXACT || e0 + e < E) acc[e] = __builtin_fmaf(xv, wr[e], acc[e]);
     }
-    __syncthreads();
   }
 
+  // gather the E clean logits of token `lane` into wave 0
+  float cl[EPAD];
+  if constexpr (NW > 1) {
+#pragma unroll
+    for (int e = 0; e < EW; ++e) slog[lane * (EPAD + 1) + e0 + e] = acc[e];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int e = 0; e < EPAD; ++e) cl[e] = slog[lane * (EPAD + 1) + e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < EPAD; ++e) cl[e] = acc[e];
+  }
+
+  const int64_t t = t0 + lane;
+  const bool tok_ok = t < T_;
+  const int k = p.k;
   // noisy logits
   float nz[EPAD];
 #pragma unroll
   for (int e = 0; e < EPAD; ++e) {
-    float n = acc[e];
-    if (noise && noise_std != 0.f && (EXACT || e < E) && tok_ok) {
-      const float scaled = noise[t * E + e] * noise_std;
-      n = acc[e] + scaled;
+    float n = cl[e];
+    if (p.noise && p.noise_std != 0.f && (EXACT || e < E) && tok_ok) {
+      const float scaled = p.noise[t * E + e] * p.noise_std;
+      n = cl[e] + scaled;
     }
     nz[e] = n;
   }
@@ -132,6 +178,7 @@ __global__ __launch_bounds__(GATE_TOK) void gate_fwd_kernel(
   // top-(k+1) on the noisy logits, ties -> lowest index
   const int kp = (k + 1 < E) ? k + 1 : E;
   unsigned long long taken = 0ull, sel_k = 0ull;
+  float thr_in = 0.f, thr_out = 0.f;       // top_logits[t][k], top_logits[t][k-1]
   for (int j = 0; j < kp; ++j) {
     int best = -1;
     float bv = 0.f, bq = 0.f;
@@ -142,39 +189,122 @@ __global__ __launch_bounds__(GATE_TOK) void gate_fwd_kernel(
       }
     }
     taken |= 1ull << best;
-    const float p = bq / s;
+    const float pr = bq / s;
+    if (j == k) thr_in = pr;
+    if (j == k - 1) thr_out = pr;
     if (tok_ok) {
-      top_logits[t * kp + j] = p;
+      p.top_logits[t * kp + j] = pr;
       if (j < k) {
-        idx[t * k + j] = best;
-        if (idx32) idx32[t * k + j] = best;
-        score[t * k + j] = p;
+        p.idx[t * k + j] = best;
+        if (p.idx32) p.idx32[t * k + j] = best;
+        p.score[t * k + j] = pr;
+      } else if (p.idx_next) {
+        p.idx_next[t] = best;
       }
     }
     if (j < k) sel_k |= 1ull << best;
   }
   // dense outputs + load-balance partials
-  float imp_part = 0.f;
+  const bool prob_load = p.part_load_prob != nullptr;   // host: only when noise_std != 0 and k < E
+  const float inv_std = prob_load ? 1.f / p.noise_std : 0.f;
 #pragma unroll
   for (int e = 0; e < EPAD; ++e) {
     if (EXACT || e < E) {
       const bool sel = (sel_k >> e) & 1ull;
-      const float p = q[e] / s;
-      const float gv = (sel && tok_ok) ? p : 0.f;
+      const float pr = q[e] / s;
+      const float gv = (sel && tok_ok) ? pr : 0.f;
       if (tok_ok) {
-        if (clean) clean[t * E + e] = acc[e];
-        if (noisy_out) noisy_out[t * E + e] = nz[e];
-        if (gates) gates[t * E + e] = gv;
+        if (p.clean) p.clean[t * E + e] = cl[e];
+        if (p.noisy) p.noisy[t * E + e] = nz[e];
+        if (p.gates) p.gates[t * E + e] = gv;
       }
       const float wsum = wave_sum(gv);
       const unsigned long long b = __ballot(gv > 0.f);
+      float psum = 0.f;
+      if (prob_load) {
+        // _prob_in_top_k, vision_transformer_moe.py:33-71: thresholds are PROBABILITIES, clean/noisy are logits
+        const bool is_in = nz[e] > thr_in;
+        const float z = (cl[e] - (is_in ? thr_in : thr_out)) * inv_std;
+        psum = wave_sum(tok_ok ? normal_cdf(z) : 0.f);
+      }
       if (lane == 0) {
-        part_imp[(int64_t)blockIdx.x * E + e] = wsum;
-        part_load[(int64_t)blockIdx.x * E + e] = __popcll(b);
+        p.part_imp[(int64_t)blockIdx.x * E + e] = wsum;
+        p.part_load[(int64_t)blockIdx.x * E + e] = __popcll(b);
+        if (prob_load) p.part_load_prob[(int64_t)blockIdx.x * E + e] = psum;
       }
     }
   }
-  (void)imp_part;
+}
+
+// Reduce the per-block balance partials in fixed order and evaluate
+//   cv_loss = cv^2(importance) + cv^2(load)     (vision_transformer_moe.py:73-87,540)
+// and its gradient.  One workgroup of 64*E.. threads: thread (r, e) sums rows r, r+RL, ... of column e.
+struct BalanceDev {
+  const float *part_imp; const int32_t *part_load; const float *part_load_prob;
+  int nblk; int E;
+  float *importance; int64_t *load; float *load_prob;
+  float *loss_acc; float *loss_out;
+  float *d_importance; float *d_load_prob;
+};
+
+__device__ __forceinline__ void cv2_and_grad(const float *v, int E, float &cv, float *grad_scratch) {
+  // unbiased var / (mean^2 + 1e-10); zero for a single expert
+  float mean = 0.f;
+  for (int e = 0; e < E; ++e) mean += v[e];
+  mean /= (float)E;
+  float var = 0.f;
+  for (int e = 0; e < E; ++e) var += (v[e] - mean) * (v[e] - mean);
+  var /= (float)(E - 1);
+  const float den = mean * mean + 1e-10f;
+  cv = var / den;
+  for (int e = 0; e < E; ++e)
+    grad_scratch[e] = 2.f * (v[e] - mean) / ((float)(E - 1) * den) - var * (2.f * mean / (float)E) / (den * den);
+}
+
+__global__ __launch_bounds__(256) void balance_kernel(const BalanceDev p) {
+  __shared__ float s_imp[4][64], s_prob[4][64];
+  __shared__ int s_load[4][64];
+  __shared__ float v_imp[64], v_load[64], g_imp[64], g_load[64];
+  const int E = p.E;
+  const int e = threadIdx.x & 63, r = threadIdx.x >> 6;
+  float a = 0.f, c = 0.f;
+  int l = 0;
+  if (e < E)
+    for (int b = r; b < p.nblk; b += 4) {
+      a += p.part_imp[(int64_t)b * E + e];
+      l += p.part_load[(int64_t)b * E + e];
+      if (p.part_load_prob) c += p.part_load_prob[(int64_t)b * E + e];
+    }
+  s_imp[r][e] = a; s_load[r][e] = l; s_prob[r][e] = c;
+  __syncthreads();
+  if (r == 0 && e < E) {
+    const float imp = (s_imp[0][e] + s_imp[1][e]) + (s_imp[2][e] + s_imp[3][e]);
+    const int ld = s_load[0][e] + s_load[1][e] + s_load[2][e] + s_load[3][e];
+    const float pr = (s_prob[0][e] + s_prob[1][e]) + (s_prob[2][e] + s_prob[3][e]);
+    p.importance[e] = imp;
+    p.load[e] = ld;
+    if (p.load_prob) p.load_prob[e] = pr;
+    v_imp[e] = imp;
+    v_load[e] = p.part_load_prob ? pr : (float)ld;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float cv_i = 0.f, cv_l = 0.f;
+    if (E > 1) {
+      cv2_and_grad(v_imp, E, cv_i, g_imp);
+      cv2_and_grad(v_load, E, cv_l, g_load);
+    } else {
+      g_imp[0] = 0.f; g_load[0] = 0.f;
+    }
+    const float loss = cv_i + cv_l;
+    if (p.loss_out) *p.loss_out = loss;
+    if (p.loss_acc) *p.loss_acc += loss;
+  }
+  __syncthreads();
+  if (r == 0 && e < E) {
+    if (p.d_importance) p.d_importance[e] = g_imp[e];
+    if (p.d_load_prob) p.d_load_prob[e] = p.part_load_prob ? g_load[e] : 0.f;
+  }
 }
 
 __global__ void gate_reduce_kernel(const float *part_imp, const int32_t *part_load, int nblk, int E, float *imp,
@@ -191,31 +321,89 @@ __global__ void gate_reduce_kernel(const float *part_imp, const int32_t *part_lo
   load[e] = c;
 }
 
-// d_logits through scatter + softmax: thread per token
-__global__ void gate_bwd_logits_kernel(const float *noisy, const int64_t *idx, const float *d_score,
-                                       const float *d_imp, int64_t T_, int E, int k, float *d_logits) {
+// d_logits through scatter + softmax (+ the Normal-CDF load term): thread per token
+struct GateBwdDev {
+  const float *noisy; const float *clean; const float *top_logits;
+  const int64_t *idx; const int32_t *idx_next;
+  const float *d_score; const float *d_top; const float *d_importance; const float *d_load_prob;
+  float balance_scale; float noise_std;
+  int64_t T; int E; int k;
+  float *d_logits;
+};
+
+template <int EPAD>
+__global__ __launch_bounds__(256) void gate_bwd_logits_kernel(const GateBwdDev p) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= T_) return;
-  const float *nz = noisy + t * E;
-  float m = nz[0];
-  for (int e = 1; e < E; ++e) m = nz[e] > m ? nz[e] : m;
+  if (t >= p.T) return;
+  const int E = p.E, k = p.k;
+  const int kp = (k + 1 < E) ? k + 1 : E;
+  const float *nzp = p.noisy + t * E;
+  float pr[EPAD], dp[EPAD], g[EPAD];
+  float m = nzp[0];
+#pragma unroll
+  for (int e = 0; e < EPAD; ++e) {
+    pr[e] = e < E ? nzp[e] : 0.f;
+    dp[e] = 0.f; g[e] = 0.f;
+    if (e < E && e > 0) m = pr[e] > m ? pr[e] : m;
+  }
   float s = 0.f;
-  for (int e = 0; e < E; ++e) s = s + expf(nz[e] - m);
-  // sum_j dp_j p_j over the selected experts
-  float dot = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPAD; ++e) {
+    const float nz = pr[e];
+    pr[e] = e < E ? expf(nz - m) : 0.f;
+    s = s + pr[e];
+    // keep the noisy logit for the is_in test of the load term
+    g[e] = nz;
+  }
+  const float inv_s = 1.f / s;
+#pragma unroll
+  for (int e = 0; e < EPAD; ++e) pr[e] *= inv_s;
+
+  // Normal-CDF load term (vision_transformer_moe.py:33-71,456-457): d load_prob[e] -> clean logits and,
+  // through the two probability thresholds, the softmax
+  float d_thr_in = 0.f, d_thr_out = 0.f;
+  const bool prob_load = p.d_load_prob != nullptr;
+  if (prob_load) {
+    const float thr_in = p.top_logits[t * kp + k], thr_out = p.top_logits[t * kp + k - 1];
+    const float inv_std = 1.f / p.noise_std;
+    const float *clp = p.clean + t * E;
+#pragma unroll
+    for (int e = 0; e < EPAD; ++e) {
+      if (e < E) {
+        const bool is_in = g[e] > thr_in;
+        const float z = (clp[e] - (is_in ? thr_in : thr_out)) * inv_std;
+        const float ge = p.d_load_prob[e] * p.balance_scale * normal_pdf(z) * inv_std;
+        g[e] = ge;
+        if (is_in) d_thr_in -= ge; else d_thr_out -= ge;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < EPAD; ++e) g[e] = 0.f;
+  }
+  // d p at the selected experts
   for (int j = 0; j < k; ++j) {
-    const int e = (int)idx[t * k + j];
-    const float p = expf(nz[e] - m) / s;
-    const float dp = (d_score ? d_score[t * k + j] : 0.f) + (d_imp ? d_imp[e] : 0.f);
-    dot += dp * p;
+    const int ej = (int)p.idx[t * k + j];
+    float v = (p.d_score ? p.d_score[t * k + j] : 0.f) + (p.d_top ? p.d_top[t * kp + j] : 0.f) +
+              (p.d_importance ? p.d_importance[ej] * p.balance_scale : 0.f);
+    if (j == k - 1) v += d_thr_out;
+#pragma unroll
+    for (int e = 0; e < EPAD; ++e)
+      if (e == ej) dp[e] += v;
   }
-  for (int e = 0; e < E; ++e) {
-    const float p = expf(nz[e] - m) / s;
-    float dp = 0.f;
-    for (int j = 0; j < k; ++j)
-      if ((int)idx[t * k + j] == e) dp = (d_score ? d_score[t * k + j] : 0.f) + (d_imp ? d_imp[e] : 0.f);
-    d_logits[t * E + e] = p * (dp - dot);
+  if (kp > k && p.idx_next) {
+    const int en = p.idx_next[t];
+    const float v = (p.d_top ? p.d_top[t * kp + k] : 0.f) + d_thr_in;
+#pragma unroll
+    for (int e = 0; e < EPAD; ++e)
+      if (e == en) dp[e] += v;
   }
+  float dot = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPAD; ++e) dot += dp[e] * pr[e];
+#pragma unroll
+  for (int e = 0; e < EPAD; ++e)
+    if (e < E) p.d_logits[t * E + e] = pr[e] * (dp[e] - dot) + g[e];
 }
 
 // dW partials: lanes own d, tokens are walked; d_logits rows are wave-uniform scalars.
@@ -286,56 +474,53 @@ using namespace m3;
 extern "C" int m3_gate_num_blocks(int64_t T) { return (int)((T + GATE_TOK - 1) / GATE_TOK); }
 extern "C" int m3_gate_dw_blocks(int64_t T) { return (int)((T + GATE_DW_TOK - 1) / GATE_DW_TOK); }
 
+template <typename T, int EP, int EW>
+static void launch_gate_fwd_e(bool exact, dim3 grid, hipStream_t s, const GateFwdDev &d) {
+  constexpr int NT = GATE_TOK * (EP / EW);
+  if (exact) hipLaunchKernelGGL((gate_fwd_kernel<T, EP, EW, true>), grid, dim3(NT), 0, s, d);
+  else hipLaunchKernelGGL((gate_fwd_kernel<T, EP, EW, false>), grid, dim3(NT), 0, s, d);
+}
+
 template <typename T>
-static int launch_gate_fwd(int epad, dim3 grid, hipStream_t s, const char *x, int64_t T_, int D, int64_t ldx_b,
-                           const float *w, int E, const float *bias, const float *noise, float std, int k, int64_t *idx,
-                           int32_t *idx32, float *score, float *top, float *clean, float *noisy, float *gates,
-                           float *pi, int32_t *pl) {
-#define M3_GATE_CASE(EP)                                                                                      \
-  case EP:                                                                                                    \
-    if (E == EP)                                                                                              \
-      hipLaunchKernelGGL((gate_fwd_kernel<T, EP, true>), grid, dim3(GATE_TOK), 0, s, x, T_, D, ldx_b, w, E,    \
-                         bias, noise, std, k, idx, idx32, score, top, clean, noisy, gates, pi, pl);          \
-    else                                                                                                      \
-      hipLaunchKernelGGL((gate_fwd_kernel<T, EP, false>), grid, dim3(GATE_TOK), 0, s, x, T_, D, ldx_b, w, E,   \
-                         bias, noise, std, k, idx, idx32, score, top, clean, noisy, gates, pi, pl);          \
-    break;
+static int launch_gate_fwd(int epad, dim3 grid, hipStream_t s, const GateFwdDev &d) {
+  const bool exact = d.E == epad;
   switch (epad) {
-    M3_GATE_CASE(4)
-    M3_GATE_CASE(8)
-    M3_GATE_CASE(16)
-    M3_GATE_CASE(32)
-    M3_GATE_CASE(64)
+    case 4: launch_gate_fwd_e<T, 4, 4>(exact, grid, s, d); break;
+    case 8: launch_gate_fwd_e<T, 8, 4>(exact, grid, s, d); break;
+    case 16: launch_gate_fwd_e<T, 16, 4>(exact, grid, s, d); break;
+    case 32: launch_gate_fwd_e<T, 32, 8>(exact, grid, s, d); break;
+    case 64: launch_gate_fwd_e<T, 64, 16>(exact, grid, s, d); break;
     default: return M3_ERR_UNSUPPORTED;
   }
-#undef M3_GATE_CASE
   return check_launch("m3_gate_fwd");
 }
 
 static int epad_of(int E) { return E <= 4 ? 4 : E <= 8 ? 8 : E <= 16 ? 16 : E <= 32 ? 32 : 64; }
 static int epad8_of(int E) { return E <= 8 ? 8 : E <= 16 ? 16 : E <= 32 ? 32 : 64; }
 
-extern "C" int m3_gate_fwd(const void *x, int x_dtype, int64_t T, int D, int64_t ldx, const float *w_gate, int E,
-                           const float *logit_bias, const float *noise, float noise_std, int k, int64_t *idx,
-                           int32_t *idx32, float *score, float *top_logits, float *clean, float *noisy, float *gates,
-                           float *part_importance, int32_t *part_load, void *stream) {
-  M3_REQUIRE(x && w_gate && idx && score && top_logits && part_importance && part_load, "m3_gate_fwd: null operand");
-  M3_REQUIRE(x_dtype == M3_F32 || x_dtype == M3_F16, "m3_gate_fwd: bad dtype");
-  M3_REQUIRE(E >= 2 && E <= 64, "m3_gate_fwd: E=%d outside [2,64]", E);
-  M3_REQUIRE(k >= 1 && k <= 8 && k <= E, "m3_gate_fwd: k=%d invalid for E=%d", k, E);
-  const int es = dtype_size(x_dtype);
-  M3_REQUIRE(T >= 0 && D > 0 && (D * es) % 16 == 0 && (ldx * es) % 16 == 0 && ((uintptr_t)x % 16) == 0,
+extern "C" int m3_gate_fwd(const m3_gate_fwd_args *a, void *stream) {
+  M3_REQUIRE(a && a->x && a->w_gate && a->idx && a->score && a->top_logits && a->part_importance && a->part_load,
+             "m3_gate_fwd: null operand");
+  M3_REQUIRE(a->x_dtype == M3_F32 || a->x_dtype == M3_F16, "m3_gate_fwd: bad dtype");
+  M3_REQUIRE(a->E >= 2 && a->E <= 64, "m3_gate_fwd: E=%d outside [2,64]", a->E);
+  M3_REQUIRE(a->k >= 1 && a->k <= 8 && a->k <= a->E, "m3_gate_fwd: k=%d invalid for E=%d", a->k, a->E);
+  const int es = dtype_size(a->x_dtype);
+  M3_REQUIRE(a->T >= 0 && a->D > 0 && (a->D * es) % 16 == 0 && (a->ldx * es) % 16 == 0 && ((uintptr_t)a->x % 16) == 0,
              "m3_gate_fwd: rows must be 16-byte aligned and D*elem a multiple of 16");
-  if (T == 0) return M3_OK;
-  const dim3 grid((unsigned)m3_gate_num_blocks(T));
+  const bool noisy_run = a->noise && a->noise_std != 0.f;
+  M3_REQUIRE(!a->part_load_prob || (noisy_run && a->k < a->E && a->clean && a->noisy),
+             "m3_gate_fwd: part_load_prob (Normal-CDF load) needs noise, noise_std != 0, k < E and the dense outputs");
+  if (a->T == 0) return M3_OK;
+  GateFwdDev d;
+  d.x = (const char *)a->x; d.T = a->T; d.D = a->D; d.ldx_b = a->ldx * es;
+  d.w = a->w_gate; d.E = a->E; d.bias = a->logit_bias; d.noise = a->noise; d.noise_std = a->noise_std; d.k = a->k;
+  d.idx = a->idx; d.idx32 = a->idx32; d.idx_next = a->idx_next; d.score = a->score; d.top_logits = a->top_logits;
+  d.clean = a->clean; d.noisy = a->noisy; d.gates = a->gates;
+  d.part_imp = a->part_importance; d.part_load = a->part_load; d.part_load_prob = a->part_load_prob;
+  const dim3 grid((unsigned)m3_gate_num_blocks(a->T));
   hipStream_t s = (hipStream_t)stream;
-  if (x_dtype == M3_F16)
-    return launch_gate_fwd<half_t>(epad_of(E), grid, s, (const char *)x, T, D, ldx * es, w_gate, E, logit_bias, noise,
-                                   noise_std, k, idx, idx32, score, top_logits, clean, noisy, gates, part_importance,
-                                   part_load);
-  return launch_gate_fwd<float>(epad_of(E), grid, s, (const char *)x, T, D, ldx * es, w_gate, E, logit_bias, noise,
-                                noise_std, k, idx, idx32, score, top_logits, clean, noisy, gates, part_importance,
-                                part_load);
+  if (a->x_dtype == M3_F16) return launch_gate_fwd<half_t>(epad_of(a->E), grid, s, d);
+  return launch_gate_fwd<float>(epad_of(a->E), grid, s, d);
 }
 
 extern "C" int m3_gate_reduce(const float *part_importance, const int32_t *part_load, int nblk, int E,
@@ -347,12 +532,42 @@ extern "C" int m3_gate_reduce(const float *part_importance, const int32_t *part_
   return launch_reduce_rows_i32(part_load, nblk, E, 1, 0, load, 0, (hipStream_t)stream);
 }
 
-extern "C" int m3_gate_bwd_logits(const float *noisy, const int64_t *idx, const float *d_score,
-                                  const float *d_importance, int64_t T, int E, int k, float *d_logits, void *stream) {
-  M3_REQUIRE(noisy && idx && d_logits && E >= 2 && E <= 64 && k >= 1 && k <= E, "m3_gate_bwd_logits: bad args");
-  if (T == 0) return M3_OK;
-  hipLaunchKernelGGL(gate_bwd_logits_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     noisy, idx, d_score, d_importance, T, E, k, d_logits);
+extern "C" int m3_balance_loss(const float *part_importance, const int32_t *part_load, const float *part_load_prob,
+                               int nblk, int E, float *importance, int64_t *load, float *load_prob, float *loss_out,
+                               float *loss_acc, float *d_importance, float *d_load_prob, void *stream) {
+  M3_REQUIRE(part_importance && part_load && importance && load && E >= 1 && E <= 64 && nblk >= 0,
+             "m3_balance_loss: bad args");
+  M3_REQUIRE(!part_load_prob || load_prob, "m3_balance_loss: load_prob output needed with part_load_prob");
+  BalanceDev d;
+  d.part_imp = part_importance; d.part_load = part_load; d.part_load_prob = part_load_prob;
+  d.nblk = nblk; d.E = E; d.importance = importance; d.load = load; d.load_prob = load_prob;
+  d.loss_acc = loss_acc; d.loss_out = loss_out; d.d_importance = d_importance; d.d_load_prob = d_load_prob;
+  hipLaunchKernelGGL(balance_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d);
+  return check_launch("m3_balance_loss");
+}
+
+extern "C" int m3_gate_bwd_logits(const m3_gate_bwd_args *a, void *stream) {
+  M3_REQUIRE(a && a->noisy && a->idx && a->d_logits && a->E >= 2 && a->E <= 64 && a->k >= 1 && a->k <= a->E,
+             "m3_gate_bwd_logits: bad args");
+  const bool has_next = a->k < a->E;
+  M3_REQUIRE(!a->d_top || !has_next || a->idx_next, "m3_gate_bwd_logits: d_top needs idx_next");
+  M3_REQUIRE(!a->d_load_prob || (has_next && a->idx_next && a->clean && a->top_logits && a->noise_std != 0.f),
+             "m3_gate_bwd_logits: d_load_prob needs k < E, idx_next, clean, top_logits and noise_std != 0");
+  if (a->T == 0) return M3_OK;
+  GateBwdDev d;
+  d.noisy = a->noisy; d.clean = a->clean; d.top_logits = a->top_logits; d.idx = a->idx; d.idx_next = a->idx_next;
+  d.d_score = a->d_score; d.d_top = a->d_top; d.d_importance = a->d_importance; d.d_load_prob = a->d_load_prob;
+  d.balance_scale = a->balance_scale; d.noise_std = a->noise_std; d.T = a->T; d.E = a->E; d.k = a->k;
+  d.d_logits = a->d_logits;
+  const dim3 grid((unsigned)((a->T + 255) / 256));
+  hipStream_t s = (hipStream_t)stream;
+  switch (epad_of(a->E)) {
+    case 4: hipLaunchKernelGGL(gate_bwd_logits_kernel<4>, grid, dim3(256), 0, s, d); break;
+    case 8: hipLaunchKernelGGL(gate_bwd_logits_kernel<8>, grid, dim3(256), 0, s, d); break;
+    case 16: hipLaunchKernelGGL(gate_bwd_logits_kernel<16>, grid, dim3(256), 0, s, d); break;
+    case 32: hipLaunchKernelGGL(gate_bwd_logits_kernel<32>, grid, dim3(256), 0, s, d); break;
+    default: hipLaunchKernelGGL(gate_bwd_logits_kernel<64>, grid, dim3(256), 0, s, d); break;
+  }
   return check_launch("m3_gate_bwd_logits");
 }
 

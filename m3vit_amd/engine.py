@@ -36,25 +36,6 @@ class _Cfg:
     gate_task_specific_dim, vmoe_noisy_std)."""
 
 
-def cv_squared(x: torch.Tensor) -> torch.Tensor:
-    """cv_squared, models/moe/ckpt/vision_transformer_moe.py:73-87 (O(E) scalar math)."""
-    if x.shape[0] == 1:
-        return torch.zeros((), device=x.device)
-    x = x.float()
-    return x.var() / (x.mean() ** 2 + 1e-10)
-
-
-def cv_squared_grad(x: torch.Tensor) -> torch.Tensor:
-    """d cv_squared(x) / dx, closed form (unbiased variance)."""
-    E = x.shape[0]
-    if E == 1:
-        return torch.zeros_like(x)
-    m = x.mean()
-    v = x.var()
-    den = m * m + 1e-10
-    return 2.0 * (x - m) / ((E - 1) * den) - v * (2.0 * m / E) / (den * den)
-
-
 class BackboneEngine:
     def __init__(self, cfg, params: Dict[str, torch.Tensor], batch: int, dtype=torch.float16,
                  device="cuda:0", ep_group=None, ep_world: int = 1, ep_rank: int = 0):
@@ -168,6 +149,8 @@ class BackboneEngine:
         # task-conditioned gate (custom_moe_layer.py:161-181): one shared w_gate [D + gtsd, E] per MoE block
         self.task_cond = self.cfg.gate_task_specific_dim >= 0 and not self.cfg.multi_gate
         self.s_dl_t = self._e(T, self.E)
+        self.s_dl = self._e(T, self.E, dtype=f32)
+        self.cv_acc = torch.zeros(1, dtype=f32, device=self.dev)
 
     def cfg_d_gate(self):
         g = self.cfg.gate_task_specific_dim
@@ -268,7 +251,7 @@ class BackboneEngine:
         ops.gemm_nt(self.rows, self.wc["patch_embed.proj"], self.patch, bias=p["patch_embed.proj.bias"])
         ops.assemble_tokens(self.patch, p["cls_token"], p["pos_embed"], B, self.np_, D, self.x0)
         x = self.x0
-        total_cv = torch.zeros((), device=self.dev)
+        self.cv_acc.zero_()
         self.task_id = task_id
         for i in range(self.depth):
             a = self.act[i]
@@ -290,8 +273,9 @@ class BackboneEngine:
                 wg_tok = wg if wg.shape[0] == D else wg[:D]
                 noise = None if noises is None else noises.get(i)
                 std = (self.cfg.vmoe_noisy_std / self.E) if noise is not None else 0.0
+                # gate + balance loss (importance, load, cv^2 and its gradient) - two launches
                 g = ops.gate_fwd(a["h2"], wg_tok, self.k, logit_bias=None if tsf_bias is None else tsf_bias[i],
-                                 noise=noise, noise_std=std, dense=True)
+                                 noise=noise, noise_std=std, dense=True, loss_acc=self.cv_acc)
                 a["gate"] = g
                 if self.ep_world > 1:
                     self._experts_fwd_ep(i, a, g)
@@ -306,10 +290,9 @@ class BackboneEngine:
                                 bias=p[b + "mlp.experts.h4toh.bias"], c_row_idx=r.row_of_slot,
                                 group_offsets=r.offsets, tile_starts=r.tile_starts)
                 ops.combine_fwd(a["y"], g["score"], a["x1"], a["x2"])
-                # cv_loss = cv^2(importance) + cv^2(load)   (vision_transformer_moe.py:453-459,540)
-                total_cv = total_cv + cv_squared(g["importance"]) + cv_squared(g["load"].float())
             x = a["x2"]
-        return x.view(B, self.N, D), total_cv
+        # total cv_loss = sum over MoE blocks of cv^2(importance) + cv^2(load)  (vision_transformer_moe.py:453-459,540)
+        return x.view(B, self.N, D), self.cv_acc[0].clone()
 
     # ------------------------------------------------------------- expert parallel
     def _a2a(self, x, in_splits, out_splits):
@@ -439,9 +422,12 @@ class BackboneEngine:
                     ops.gemm_nt(dhp, self.wt[b + "mlp.experts.htoh4"], self.s_dxe, M=R, c_row_idx=r.row_of_slot,
                                 group_offsets=r.offsets, tile_starts=r.tile_starts)
                 ops.combine_fwd(self.s_dxe, self.ones_k, None, self.s_dh32)       # dh2 = sum_j dxe[t,j]
-                # gate: d score from the combine, d importance from the cv loss
-                d_imp = cv_squared_grad(g["importance"]) * cv_weight if cv_weight != 0.0 else None
-                dl = ops.gate_bwd_logits(g["noisy"], g["idx"], self.s_dscore, d_imp, k)
+                # gate: d score from the combine, d importance / d load from the cv loss
+                bal = cv_weight != 0.0
+                dl = ops.gate_bwd_logits(g["noisy"], g["idx"], self.s_dscore, g["d_importance"] if bal else None, k,
+                                         balance_scale=cv_weight, idx_next=g["idx_next"],
+                                         d_load_prob=g["d_load_prob"] if bal else None, clean=g["clean"],
+                                         top_logits=g["top_logits"], noise_std=g["noise_std"], out=self.s_dl)
                 # token rows of w_gate ([:D]; the task-conditioned rows [D:] are handled by _task_feature_bwd)
                 wg, dwg = p[a["wname"]][:D], gr[a["wname"]][:D]
                 if self.gate_via_gemm:

@@ -160,9 +160,8 @@ class AttentionCoreFn(torch.autograd.Function):
 
 class GateFn(torch.autograd.Function):
     """NoisyGate_VMoE arithmetic (noisy_gate_vmoe.py:91-93,168,197-207).  Differentiable outputs:
-    score [T,k], clean/noisy logits and the dense gates [T,E]; idx / top_logits carry no gradient
-    (the std > 0 Normal-CDF load term of vision_transformer_moe.py:456-457 is therefore treated as a
-    constant, as is exact for the std = 0 configurations of run_exps.sh:21)."""
+    score [T,k], top_logits [T,k+1] (what the Normal-CDF load term of vision_transformer_moe.py:456-457
+    thresholds on), clean/noisy logits and the dense gates [T,E]; the indices carry no gradient."""
 
     @staticmethod
     def forward(ctx, x, w_gate, k, noise, noise_std, logit_bias):
@@ -171,15 +170,15 @@ class GateFn(torch.autograd.Function):
         wg = w_gate.detach()
         wg_tok = wg if wg.shape[0] == D else wg[:D].contiguous()
         g = ops.gate_fwd(x2, wg_tok, k, logit_bias=logit_bias, noise=noise, noise_std=noise_std, dense=True)
-        ctx.save_for_backward(x2, w_gate, g["noisy"], g["idx"])
+        ctx.save_for_backward(x2, w_gate, g["noisy"], g["idx"], g["idx_next"])
         ctx.k = k
-        ctx.mark_non_differentiable(g["idx"], g["top_logits"], g["idx32"], g["importance"], g["load"])
+        ctx.mark_non_differentiable(g["idx"], g["idx32"], g["importance"], g["load"])
         return (g["idx"], g["score"], g["clean"], g["noisy"], g["top_logits"], g["gates"], g["idx32"],
                 g["importance"], g["load"])
 
     @staticmethod
     def backward(ctx, g_idx, g_score, g_clean, g_noisy, g_top, g_gates, g_idx32, g_imp, g_load):
-        x2, w_gate, noisy, idx = ctx.saved_tensors
+        x2, w_gate, noisy, idx, idx_next = ctx.saved_tensors
         T, E = noisy.shape
         k = ctx.k
         d_score = g_score.contiguous().float() if g_score is not None else None
@@ -187,7 +186,10 @@ class GateFn(torch.autograd.Function):
             # gates = zeros.scatter(1, idx, score): its gradient flows back to the selected scores
             extra = g_gates.float().gather(1, idx)
             d_score = extra if d_score is None else d_score + extra
-        dl = ops.gate_bwd_logits(noisy, idx, d_score, None, k)
+        d_top = g_top.contiguous().float() if (g_top is not None and idx_next is not None) else None
+        if g_top is not None and idx_next is None:                      # k == E: top_logits is score
+            d_score = g_top.contiguous().float() if d_score is None else d_score + g_top.float()
+        dl = ops.gate_bwd_logits(noisy, idx, d_score, None, k, d_top=d_top, idx_next=idx_next)
         if g_clean is not None:
             dl = dl + g_clean.float()
         if g_noisy is not None:

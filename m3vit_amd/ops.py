@@ -43,45 +43,64 @@ def _req(t: torch.Tensor, dtype=None, name="tensor"):
 
 
 # ----------------------------------------------------------------------------- gate
-def gate_fwd(x, w_gate, k, logit_bias=None, noise=None, noise_std=0.0, dense=True, want_idx32=True):
+def gate_fwd(x, w_gate, k, logit_bias=None, noise=None, noise_std=0.0, dense=True, want_idx32=True,
+             loss_acc=None):
     """x [T,D] f32/f16, w_gate [D,E] f32 (rows beyond D are ignored: pass w_gate[:D] + bias for
-    task conditioning).  Returns dict with idx i64 [T,k], idx32, score, top_logits, clean, noisy,
-    gates (dense only), importance f32 [E], load i64 [E]."""
+    task conditioning).  Returns dict with idx i64 [T,k], idx32, idx_next i32 [T], score, top_logits,
+    clean, noisy, gates (dense only), importance f32 [E], load i64 [E], and the block's balance loss
+    cv_loss = cv^2(importance) + cv^2(load) (0-dim) with its gradients d_importance / d_load_prob [E].
+    For noisy training (noise given, noise_std != 0, k < E; needs dense) load is the Normal-CDF form
+    load_prob f32 [E] (vision_transformer_moe.py:456-457), otherwise the count and d_load_prob is None.
+    loss_acc: optional 1-element f32 tensor the loss is also added to."""
     _req(x, name="x"); _req(w_gate, torch.float32, "w_gate")
     T, D = x.shape
     E = w_gate.shape[1]
     assert w_gate.shape[0] == D
     dev = x.device
     kp = min(k + 1, E)
+    f32 = torch.float32
     idx = torch.empty((T, k), dtype=torch.int64, device=dev)
     idx32 = torch.empty((T, k), dtype=torch.int32, device=dev) if want_idx32 else None
-    score = torch.empty((T, k), dtype=torch.float32, device=dev)
-    top = torch.empty((T, kp), dtype=torch.float32, device=dev)
-    clean = torch.empty((T, E), dtype=torch.float32, device=dev) if dense else None
-    noisy = torch.empty((T, E), dtype=torch.float32, device=dev) if dense else None
-    gates = torch.empty((T, E), dtype=torch.float32, device=dev) if dense else None
+    idx_next = torch.empty((T,), dtype=torch.int32, device=dev) if kp > k else None
+    score = torch.empty((T, k), dtype=f32, device=dev)
+    top = torch.empty((T, kp), dtype=f32, device=dev)
+    clean = torch.empty((T, E), dtype=f32, device=dev) if dense else None
+    noisy = torch.empty((T, E), dtype=f32, device=dev) if dense else None
+    gates = torch.empty((T, E), dtype=f32, device=dev) if dense else None
     nblk = lib().m3_gate_num_blocks(T)
-    pi = torch.empty((max(nblk, 1), E), dtype=torch.float32, device=dev)
+    # one allocation for the partials and the [E]-sized results
+    prob = noise is not None and float(noise_std) != 0.0 and k < E and dense
+    pi = torch.empty((max(nblk, 1), E), dtype=f32, device=dev)
     pl = torch.empty((max(nblk, 1), E), dtype=torch.int32, device=dev)
-    imp = torch.empty(E, dtype=torch.float32, device=dev)
+    pp = torch.empty((max(nblk, 1), E), dtype=f32, device=dev) if prob else None
+    small = torch.empty((4, E), dtype=f32, device=dev)
+    imp, load_prob, d_imp, d_lp = small[0], (small[1] if prob else None), small[2], (small[3] if prob else None)
     load = torch.empty(E, dtype=torch.int64, device=dev)
+    loss = torch.empty((), dtype=f32, device=dev)
     if logit_bias is not None:
-        _req(logit_bias, torch.float32, "logit_bias")
+        _req(logit_bias, f32, "logit_bias")
     if noise is not None:
-        _req(noise, torch.float32, "noise")
-    check(lib().m3_gate_fwd(_p(x), dt_code(x.dtype), T, D, x.stride(0), _p(w_gate), E, _p(logit_bias), _p(noise),
-                            float(noise_std), k, _p(idx), _p(idx32), _p(score), _p(top), _p(clean), _p(noisy),
-                            _p(gates), _p(pi), _p(pl), _stream()), "m3_gate_fwd")
-    check(lib().m3_gate_reduce(_p(pi), _p(pl), nblk, E, _p(imp), _p(load), _stream()), "m3_gate_reduce")
-    return dict(idx=idx, idx32=idx32, score=score, top_logits=top, clean=clean, noisy=noisy, gates=gates,
-                importance=imp, load=load)
+        _req(noise, f32, "noise")
+    a = _lib.GateFwdArgs(_p(x), dt_code(x.dtype), T, D, x.stride(0), _p(w_gate), E, _p(logit_bias), _p(noise),
+                         float(noise_std), k, _p(idx), _p(idx32), _p(idx_next), _p(score), _p(top), _p(clean), _p(noisy),
+                         _p(gates), _p(pi), _p(pl), _p(pp))
+    check(lib().m3_gate_fwd(byref(a), _stream()), "m3_gate_fwd")
+    check(lib().m3_balance_loss(_p(pi), _p(pl), _p(pp), nblk, E, _p(imp), _p(load),
+                                _p(load_prob), _p(loss), _p(loss_acc), _p(d_imp), _p(d_lp), _stream()),
+          "m3_balance_loss")
+    return dict(idx=idx, idx32=idx32, idx_next=idx_next, score=score, top_logits=top, clean=clean, noisy=noisy,
+                gates=gates, importance=imp, load=load, load_prob=load_prob, cv_loss=loss, d_importance=d_imp,
+                d_load_prob=d_lp, noise_std=float(noise_std) if prob else 0.0)
 
 
-def gate_bwd_logits(noisy, idx, d_score, d_importance, k):
+def gate_bwd_logits(noisy, idx, d_score, d_importance, k, *, balance_scale=1.0, d_top=None, idx_next=None,
+                    d_load_prob=None, clean=None, top_logits=None, noise_std=0.0, out=None):
+    """d_logits [T,E] from d_score [T,k], d_top [T,k+1], balance_scale * (d_importance, d_load_prob) [E]."""
     T, E = noisy.shape
-    dl = torch.empty_like(noisy)
-    check(lib().m3_gate_bwd_logits(_p(noisy), _p(idx), _p(d_score), _p(d_importance), T, E, k, _p(dl), _stream()),
-          "m3_gate_bwd_logits")
+    dl = torch.empty_like(noisy) if out is None else out
+    a = _lib.GateBwdArgs(_p(noisy), _p(clean), _p(top_logits), _p(idx), _p(idx_next), _p(d_score), _p(d_top),
+                         _p(d_importance), _p(d_load_prob), float(balance_scale), float(noise_std), T, E, k, _p(dl))
+    check(lib().m3_gate_bwd_logits(byref(a), _stream()), "m3_gate_bwd_logits")
     return dl
 
 

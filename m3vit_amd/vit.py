@@ -19,6 +19,21 @@ def _gates_to_load(gates):
     return (gates > 0).sum(0)
 
 
+def _prob_in_top_k(clean_values, noisy_values, noise_stddev, noisy_top_values, k):
+    """Probability that each expert stays in the top k under fresh noise (vision_transformer_moe.py:33-71;
+    the thresholds are the (k+1)-th / k-th entries of top_logits, i.e. probabilities, compared with logits,
+    exactly as the reference does).  [T,E] elementwise torch ops on the gate kernel's outputs, as in the
+    reference; the fused executor (m3vit_amd.engine) has this inside the gate kernels instead."""
+    thr_in = noisy_top_values[:, k:k + 1]
+    thr_out = noisy_top_values[:, k - 1:k]
+    is_in = noisy_values > thr_in
+    normal = torch.distributions.normal.Normal(torch.zeros((), device=clean_values.device),
+                                               torch.ones((), device=clean_values.device))
+    prob_if_in = normal.cdf((clean_values - thr_in) / noise_stddev)
+    prob_if_out = normal.cdf((clean_values - thr_out) / noise_stddev)
+    return torch.where(is_in, prob_if_in, prob_if_out)
+
+
 def cv_squared(x):
     eps = 1e-10
     if x.shape[0] == 1:
@@ -137,8 +152,10 @@ class Block(nn.Module):
         out, clean, noisy, std, top_logits, gates = self.mlp(normed, gate_inp, task_id, task_specific_feature, sem)
         x = x + out.to(x.dtype)
         importance = gates.sum(0)
-        # load: count form (std == 0); the Normal-CDF form (:456-457) only differs for std > 0
-        load = _gates_to_load(gates)
+        if self.mlp.top_k < gates.shape[1] and abs(std) > 1e-6:          # :456-459
+            load = _prob_in_top_k(clean, noisy, std, top_logits, self.mlp.top_k).sum(0)
+        else:
+            load = _gates_to_load(gates)
         cv_loss = (cv_squared(importance) + cv_squared(load)) if self.training else 0
         return x, cv_loss
 

@@ -11,7 +11,7 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def _check_backbone(cfg, dtype, tol, tasks, B=3, seed=5, follow_routing=False):
+def _check_backbone(cfg, dtype, tol, tasks, B=3, seed=5, follow_routing=False, noisy=False):
     """follow_routing (fp16 runs with many experts, where a 1e-3 perturbation of the gate input flips
     near-tied experts): the engine's indices must be EXACTLY the oracle gate's top-k on the engine's own
     gate input, may differ from the float64 run's indices for a few near-tied tokens only, and the values
@@ -28,14 +28,19 @@ def _check_backbone(cfg, dtype, tol, tasks, B=3, seed=5, follow_routing=False):
     eng.zero_grad()
     Pr = {k: v.clone().double().requires_grad_() for k, v in P.items()}
     tot = 0.0
+    moe_blocks = [i for i in range(cfg.depth) if cfg.is_moe(i)]
     for task in tasks:
-        tok, cv = eng.forward(img.cuda(), task)
-        moe_blocks = [i for i in range(cfg.depth) if cfg.is_moe(i)]
+        noises = None
+        if noisy:       # caller-supplied N(0,1) draws (randn_like at noisy_gate_vmoe.py:168), one tensor per MoE block
+            gen = torch.Generator().manual_seed(100 + task)
+            noises = {i: torch.randn(B * cfg.num_tokens, cfg.moe_experts, generator=gen) for i in moe_blocks}
+        tok, cv = eng.forward(img.cuda(), task, noises=None if noises is None else {i: n.cuda() for i, n in noises.items()})
+        nz64 = None if noises is None else {i: n.double() for i, n in noises.items()}
         if follow_routing:
             ovr = {i: eng.act[i]["gate"]["idx"].cpu() for i in moe_blocks}
-            tok_ref, cv_ref, aux = R.backbone_forward(Pr, cfg, img.double(), task, route_override=ovr)
+            tok_ref, cv_ref, aux = R.backbone_forward(Pr, cfg, img.double(), task, route_override=ovr, noises=nz64)
             with torch.no_grad():
-                free = R.backbone_forward(Pr, cfg, img.double(), task)[2]
+                free = R.backbone_forward(Pr, cfg, img.double(), task, noises=nz64)[2]
             for i in moe_blocks:
                 h2 = eng.act[i]["h2"].double().cpu()
                 gx = torch.cat((h2, aux[i]["gate_x"][:, D:].detach()), 1)      # + tsf columns when task-conditioned
@@ -44,7 +49,7 @@ def _check_backbone(cfg, dtype, tol, tasks, B=3, seed=5, follow_routing=False):
                 flipped = (ovr[i] != free[i]["idx"]).any(1).float().mean()
                 assert float(flipped) < 0.2, f"block {i}: {float(flipped):.2%} of the tokens routed differently"
         else:
-            tok_ref, cv_ref, aux = R.backbone_forward(Pr, cfg, img.double(), task)
+            tok_ref, cv_ref, aux = R.backbone_forward(Pr, cfg, img.double(), task, noises=nz64)
             # identical routing in every MoE block, then values
             for i in moe_blocks:
                 assert torch.equal(eng.act[i]["gate"]["idx"].cpu(), aux[i]["idx"]), f"routing differs in block {i}"
@@ -75,6 +80,18 @@ def test_backbone_fwd_bwd_matches_oracle(dtype, tol):
     cfg = R.BackboneCfg(img_size=(32, 48), embed_dim=64, depth=4, num_heads=2, mlp_ratio=4.0, moe_mlp_ratio=1.0,
                         moe_experts=4, moe_top_k=2, gate_dim=66, multi_gate=True)
     _check_backbone(cfg, dtype, tol, tasks=(0, 1))
+
+
+def test_backbone_noisy_training_matches_oracle():
+    """vmoe_noisy_std = 1 (the reference's training default): noisy logits select the experts and the load
+    term of the balance loss is the Normal-CDF form (vision_transformer_moe.py:33-71,456-457), whose gradient
+    reaches w_gate and the tokens through the clean logits and both probability thresholds."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import ref_torch as R
+    cfg = R.BackboneCfg(img_size=(32, 48), embed_dim=64, depth=4, num_heads=2, mlp_ratio=4.0, moe_mlp_ratio=1.0,
+                        moe_experts=8, moe_top_k=2, gate_dim=66, multi_gate=True, vmoe_noisy_std=1.0)
+    _check_backbone(cfg, torch.float32, 2e-4, tasks=(0, 1), noisy=True)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float16, 4e-3)])

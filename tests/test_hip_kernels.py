@@ -276,6 +276,63 @@ def test_gate_backward(ops, dtype):
     assert rel(dx - dx0, xr.grad) < 1e-4
 
 
+@pytest.mark.parametrize("E,k,T", [(16, 4, 1000), (64, 4, 333), (4, 2, 70), (5, 2, 129)])
+def test_balance_loss_count_form(ops, E, k, T):
+    """cv_loss = cv^2(gates.sum(0)) + cv^2((gates > 0).sum(0)) (vision_transformer_moe.py:453-459,540)
+    and d cv_loss / d importance against the oracle's cv_squared + autograd."""
+    from oracle import ref_torch as R
+    x = rnd(T, 64, seed=61)
+    w = rnd(64, E, scale=0.3, seed=62)
+    acc = torch.full((1,), 2.5, device=dev())
+    out = ops.gate_fwd(x, w, k, loss_acc=acc)
+    gates = out["gates"].double().cpu()
+    imp = gates.sum(0).requires_grad_()
+    load = R.gates_to_load(gates)
+    assert torch.equal(out["load"].cpu(), load)
+    assert rel(out["importance"], imp.detach()) < 1e-6
+    ref = R.cv_squared(imp) + R.cv_squared(load.double())
+    assert abs(float(out["cv_loss"]) - float(ref)) < 1e-5 * max(1.0, float(ref))
+    assert abs(float(acc) - 2.5 - float(ref)) < 1e-5 * max(1.0, float(ref))
+    ref.backward()
+    assert rel(out["d_importance"], imp.grad) < 1e-4
+    assert out["d_load_prob"] is None and out["load_prob"] is None
+
+
+@pytest.mark.parametrize("E,k,T,std", [(16, 4, 1000, 1.0 / 16), (64, 4, 200, 1.0 / 64), (8, 2, 77, 0.5)])
+def test_noisy_gate_normal_cdf_load_fwd_bwd(ops, E, k, T, std):
+    """Noisy training: load = _prob_in_top_k(clean, noisy, std, top_logits, k).sum(0)
+    (vision_transformer_moe.py:33-71,456-457).  Forward value, the balance loss, and d_logits through the
+    scores, BOTH thresholds (top_logits[:, k] and [:, k-1] -> softmax) and the direct clean-logit term,
+    against float64 autograd over the oracle's functions."""
+    from oracle import ref_torch as R
+    D = 64
+    x = rnd(T, D, seed=71)
+    w = rnd(D, E, scale=0.3, seed=72)
+    noise = rnd(T, E, seed=73)
+    out = ops.gate_fwd(x, w, k, noise=noise, noise_std=std)
+    clean = out["clean"].double().cpu().requires_grad_()
+    nz = clean + noise.double().cpu() * std
+    p = torch.softmax(nz, 1)
+    top_logits, top_idx = p.topk(k + 1, dim=1)
+    assert torch.equal(top_idx[:, :k], out["idx"].cpu()) and torch.equal(top_idx[:, k].int(), out["idx_next"].cpu())
+    score = top_logits[:, :k]
+    gates = torch.zeros_like(p).scatter(1, top_idx[:, :k], score)
+    imp = gates.sum(0)
+    load = R.prob_in_top_k(clean, nz, std, top_logits, k).sum(0)
+    assert rel(out["load_prob"], load) < 1e-5
+    cv = R.cv_squared(imp) + R.cv_squared(load)
+    assert abs(float(out["cv_loss"]) - float(cv)) < 1e-4 * max(1.0, float(cv))
+    d_score = rnd(T, k, seed=74)
+    d_top = rnd(T, k + 1, seed=75)
+    scale = 0.37
+    dl = ops.gate_bwd_logits(out["noisy"], out["idx"], d_score, out["d_importance"], k, balance_scale=scale,
+                             d_top=d_top, idx_next=out["idx_next"], d_load_prob=out["d_load_prob"],
+                             clean=out["clean"], top_logits=out["top_logits"], noise_std=std)
+    loss = (score * d_score.double().cpu()).sum() + (top_logits * d_top.double().cpu()).sum() + scale * cv
+    loss.backward()
+    assert rel(dl, clean.grad) < 2e-4
+
+
 # ----------------------------------------------------------------- combine / layernorm
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_combine_fwd_bwd(ops, dtype):

@@ -15,15 +15,19 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
-def test_vit_mirror_matches_oracle_fwd_bwd():
+@pytest.mark.parametrize("std", [0.0, 1.0])
+def test_vit_mirror_matches_oracle_fwd_bwd(std):
+    """std = 1: the module draws the gate noise itself (torch.randn on the GPU, noisy_gate_vmoe.py:168);
+    the test re-draws the same tensors from the same seed for the oracle.  The load term is then the
+    Normal-CDF form computed from the gate outputs (vision_transformer_moe.py:456-457)."""
     _need_gpu()
     from m3vit_amd.vit import VisionTransformerMoE
     from oracle import ref_torch as R
-    kw = dict(img_size=(32, 48), embed_dim=64, depth=4, num_heads=2, moe_experts=4, moe_top_k=2, gate_dim=66,
-              multi_gate=True)
-    cfg = R.BackboneCfg(mlp_ratio=4.0, moe_mlp_ratio=1.0, **kw)
+    kw = dict(img_size=(32, 48), embed_dim=64, depth=4, num_heads=2, moe_experts=8 if std else 4, moe_top_k=2,
+              gate_dim=66, multi_gate=True)
+    cfg = R.BackboneCfg(mlp_ratio=4.0, moe_mlp_ratio=1.0, vmoe_noisy_std=std, **kw)
     P = R.init_backbone_params(cfg, seed=9)
-    m = VisionTransformerMoE(mlp_ratio=4.0, moe_mlp_ratio=1, vmoe_noisy_std=0, **kw).cuda()
+    m = VisionTransformerMoE(mlp_ratio=4.0, moe_mlp_ratio=1, vmoe_noisy_std=std, **kw).cuda()
     m.load_state_dict(P)                                        # reference key names and shapes
     m.train()
     img = torch.randn(3, 3, 32, 48)
@@ -31,8 +35,13 @@ def test_vit_mirror_matches_oracle_fwd_bwd():
     Pr = {k: v.clone().double().requires_grad_() for k, v in P.items()}
     loss_ref = 0.0
     for task in (0, 1):
+        torch.manual_seed(50 + task)
         tok, cv = m(img.cuda(), task_id=task)
-        tr, cr, _ = R.backbone_forward(Pr, cfg, img.double(), task)
+        noises = None
+        if std:
+            torch.manual_seed(50 + task)
+            noises = {i: torch.randn(3 * cfg.num_tokens, cfg.moe_experts, device="cuda").double().cpu() for i in (1, 3)}
+        tr, cr, _ = R.backbone_forward(Pr, cfg, img.double(), task, noises=noises)
         assert rel(tok, tr) < 2e-4
         assert abs(float(cv) - float(cr)) < 1e-3 * max(1.0, float(cr))
         ((tok * dtok.cuda()).sum() + 0.01 * cv).backward()
