@@ -240,6 +240,15 @@ int m3_attention_bwd(const void *qkv, const void *o, const void *d_o, const floa
  *   dst[g][c][r] = (T) src[g][r][c]  when transpose, else dst = (T) src. */
 int m3_cast_matrix(const float *src, int G, int rows, int cols, int transpose,
                    void *dst, int dst_dtype, void *stream);
+/* The same for many matrices in ONE launch (all operand copies of a model per optimizer step):
+ * descs_dev is a DEVICE array of n_desc descriptors, tile_start = running sum of
+ * G * ceil(rows/32) * ceil(cols/32) over the preceding descriptors, total_tiles = the full sum. */
+typedef struct m3_cast_desc {
+  const float *src; void *dst;
+  int32_t G, rows, cols, transpose;
+  int32_t tile_start, pad;
+} m3_cast_desc;
+int m3_cast_batch(const m3_cast_desc *descs_dev, int n_desc, int total_tiles, int dst_dtype, void *stream);
 /* dst(T)[i] = src(f32)[i] ; n elements */
 int m3_cast_f32(const float *src, int64_t n, void *dst, int dst_dtype, void *stream);
 /* patchify: images [B,3,H,W] fp32 NCHW -> rows [B*(H/P)*(W/P), 3*P*P] act dtype in

@@ -53,6 +53,11 @@ class WgradArgs(Structure):
     ]
 
 
+class CastDesc(Structure):
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("G", c_int32), ("rows", c_int32), ("cols", c_int32),
+                ("transpose", c_int32), ("tile_start", c_int32), ("pad", c_int32)]
+
+
 class GateFwdArgs(Structure):
     _fields_ = [
         ("x", c_void_p), ("x_dtype", c_int32), ("T", c_int64), ("D", c_int32), ("ldx", c_int64),
@@ -108,6 +113,7 @@ SIGNATURES = {
     "m3_attention_bwd_ws_elems": (c_int64, [_I, _I, _I, _I]),
     "m3_attention_bwd": (c_int, [_V, _V, _V, _V, _I, _I, _I, _I, _I, _V, _V, _V]),
     "m3_cast_matrix": (c_int, [_V, _I, _I, _I, _I, _V, _I, _V]),
+    "m3_cast_batch": (c_int, [_V, _I, _I, _I, _V]),
     "m3_cast_f32": (c_int, [_V, _L, _V, _I, _V]),
     "m3_im2row": (c_int, [_V, _I, _I, _I, _I, _I, _V, _I, _V]),
     "m3_assemble_tokens": (c_int, [_V, _V, _V, _I, _I, _I, _V, _V]),

@@ -202,6 +202,50 @@ __global__ void cast_matrix_kernel(const float *__restrict__ src, int rows, int 
   }
 }
 
+// many matrices in one launch: block -> descriptor by binary search over the tile prefix
+struct CastDesc {            // = m3_cast_desc
+  const float *src; void *dst;
+  int32_t G, rows, cols, transpose;
+  int32_t tile_start, pad;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_batch_kernel(const CastDesc *__restrict__ descs, int n_desc) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = n_desc - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].tile_start <= b) lo = mid; else hi = mid - 1;
+  }
+  const CastDesc d = descs[lo];
+  const int tcols = (d.cols + 31) / 32, trows = (d.rows + 31) / 32;
+  int rest = b - d.tile_start;
+  const int g = rest / (tcols * trows);
+  rest -= g * tcols * trows;
+  const int r0 = (rest / tcols) * 32, c0 = (rest % tcols) * 32;
+  const int64_t goff = (int64_t)g * d.rows * d.cols;
+  const float *src = d.src + goff;
+  T *dst = (T *)d.dst + goff;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  if (!d.transpose) {
+    for (int i = ty; i < 32; i += 8) {
+      const int r = r0 + i, c = c0 + tx;
+      if (r < d.rows && c < d.cols) dst[(int64_t)r * d.cols + c] = (T)src[(int64_t)r * d.cols + c];
+    }
+    return;
+  }
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < d.rows && c < d.cols) ? src[(int64_t)r * d.cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;   // dst[c][r]
+    if (r < d.rows && c < d.cols) dst[(int64_t)c * d.rows + r] = (T)tile[tx][i];
+  }
+}
+
 template <typename T>
 __global__ void cast_f32_kernel(const float *__restrict__ src, int64_t n4, T *__restrict__ dst) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -329,6 +373,17 @@ extern "C" int m3_cast_matrix(const float *src, int G, int rows, int cols, int t
   if (dst_dtype == M3_F16) hipLaunchKernelGGL(cast_matrix_kernel<half_t>, grid, block, 0, s, src, rows, cols, transpose, (half_t *)dst);
   else hipLaunchKernelGGL(cast_matrix_kernel<float>, grid, block, 0, s, src, rows, cols, transpose, (float *)dst);
   return check_launch("m3_cast_matrix");
+}
+
+extern "C" int m3_cast_batch(const m3_cast_desc *descs_dev, int n_desc, int total_tiles, int dst_dtype, void *stream) {
+  static_assert(sizeof(m3_cast_desc) == sizeof(CastDesc), "descriptor layout");
+  M3_REQUIRE(descs_dev && n_desc >= 1 && total_tiles >= 1, "m3_cast_batch: bad args");
+  M3_REQUIRE(dst_dtype == M3_F32 || dst_dtype == M3_F16, "m3_cast_batch: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  const CastDesc *d = (const CastDesc *)descs_dev;
+  if (dst_dtype == M3_F16) hipLaunchKernelGGL(cast_batch_kernel<half_t>, dim3(total_tiles), dim3(256), 0, s, d, n_desc);
+  else hipLaunchKernelGGL(cast_batch_kernel<float>, dim3(total_tiles), dim3(256), 0, s, d, n_desc);
+  return check_launch("m3_cast_batch");
 }
 
 extern "C" int m3_cast_f32(const float *src, int64_t n, void *dst, int dst_dtype, void *stream) {

@@ -170,27 +170,30 @@ class BackboneEngine:
 
     def prepare_weights(self):
         """Refresh the activation-dtype operand copies W [.., N, K] and W^T [.., K, N] of every
-        Linear / FMoELinear weight from the fp32 masters (once per optimizer step)."""
+        Linear / FMoELinear weight (and the w_gate copies) from the fp32 masters: one batched launch
+        per optimizer step."""
         if not hasattr(self, "wc"):
-            self.wc, self.wt = {}, {}
+            self.wc, self.wt, self.wgate_c = {}, {}, {}
+            jobs = []
             for n in self._linear_names():
                 w = self.params[n + ".weight"]
                 w2 = w.reshape(w.shape[0], -1) if n == "patch_embed.proj" else w
-                self.wc[n] = w2 if self.dt == torch.float32 else torch.empty_like(w2, dtype=self.dt)
+                if self.dt == torch.float32:
+                    self.wc[n] = w2
+                else:
+                    self.wc[n] = torch.empty_like(w2, dtype=self.dt)
+                    jobs.append((w2, self.wc[n], False))
                 if n != "patch_embed.proj":
                     self.wt[n] = torch.empty(*w2.shape[:-2], w2.shape[-1], w2.shape[-2], dtype=self.dt, device=self.dev)
-        for n in self._linear_names():
-            w = self.params[n + ".weight"]
-            w2 = w.reshape(w.shape[0], -1) if n == "patch_embed.proj" else w
+                    jobs.append((w2, self.wt[n], True))
             if self.dt != torch.float32:
-                ops.cast_matrix(w2, self.wc[n], transpose=False)
-            if n in self.wt:
-                ops.cast_matrix(w2, self.wt[n], transpose=True)
-        if self.dt != torch.float32:
-            if not hasattr(self, "wgate_c"):
-                self.wgate_c = {n: torch.empty_like(p, dtype=self.dt) for n, p in self.params.items() if n.endswith("w_gate")}
-            for n, c in self.wgate_c.items():
-                ops.cast_matrix(self.params[n], c, transpose=False)
+                for n, p in self.params.items():
+                    if n.endswith("w_gate"):
+                        self.wgate_c[n] = torch.empty_like(p, dtype=self.dt)
+                        jobs.append((p, self.wgate_c[n], False))
+            self.cast_plan = ops.CastPlan(jobs, self.dt) if jobs else None
+        if self.cast_plan is not None:
+            self.cast_plan.run()
 
     def zero_grad(self):
         self.flat_grads.zero_()

@@ -306,6 +306,33 @@ def cast_matrix(src, dst, transpose=False):
     return dst
 
 
+class CastPlan:
+    """Device-resident descriptor table for m3_cast_batch: every (fp32 master -> operand copy) pair of a
+    model, converted by ONE launch per optimizer step."""
+
+    def __init__(self, jobs, dst_dtype):
+        # jobs: list of (src fp32 [.., rows, cols], dst [.., rows, cols] or [.., cols, rows], transpose)
+        import ctypes
+        arr = (_lib.CastDesc * len(jobs))()
+        t0 = 0
+        self.keep = []
+        for d, (src, dst, tr) in zip(arr, jobs):
+            _req(src, torch.float32, "src"); _req(dst, dst_dtype, "dst")
+            rows, cols = src.shape[-2], src.shape[-1]
+            G = src.numel() // (rows * cols)
+            assert dst.numel() == src.numel()
+            d.src, d.dst, d.G, d.rows, d.cols, d.transpose, d.tile_start = (src.data_ptr(), dst.data_ptr(), G, rows,
+                                                                              cols, int(bool(tr)), t0)
+            t0 += G * ((rows + 31) // 32) * ((cols + 31) // 32)
+            self.keep += [src, dst]
+        self.n, self.total, self.dtype = len(jobs), t0, dst_dtype
+        raw = bytes(arr)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(jobs[0][0].device)
+
+    def run(self):
+        check(lib().m3_cast_batch(_p(self.table), self.n, self.total, dt_code(self.dtype), _stream()), "m3_cast_batch")
+
+
 def cast_f32(src, dst):
     check(lib().m3_cast_f32(_p(src), src.numel(), _p(dst), dt_code(dst.dtype), _stream()), "m3_cast_f32")
     return dst

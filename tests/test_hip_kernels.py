@@ -423,6 +423,18 @@ def test_cast_and_patchify(ops):
     dst2 = torch.empty(3, 70, 45, dtype=torch.float32, device=dev())
     ops.cast_matrix(src, dst2)
     assert torch.equal(dst2, src)
+    # the same through one batched launch (ragged shapes, grouped matrices, both orientations)
+    srcs = [rnd(3, 70, 45, seed=87), rnd(33, 100, seed=88), rnd(1, 5, 7, seed=89), rnd(64, 16, seed=90)]
+    jobs, want = [], []
+    for i, sm in enumerate(srcs):
+        tr = i % 2 == 0
+        shape = (*sm.shape[:-2], sm.shape[-1], sm.shape[-2]) if tr else sm.shape
+        d = torch.zeros(shape, dtype=torch.float16, device=dev())
+        jobs.append((sm, d, tr))
+        want.append((sm.transpose(-1, -2) if tr else sm).to(torch.float16))
+    ops.CastPlan(jobs, torch.float16).run()
+    for (_, d, _), w_ in zip(jobs, want):
+        assert torch.equal(d, w_)
     img = rnd(2, 3, 32, 48, seed=82)
     P = 16
     rows = torch.empty(2 * 2 * 3, 3 * P * P, dtype=torch.float32, device=dev())
