@@ -176,10 +176,14 @@ typedef struct {
   float *ws;                       /* [splits][G][N][K] */
   int32_t dtype;
   float *bias_ws;                  /* optional [splits][G][N]: bias-grad column sums of dC, fused into the
-                                      same pass (one extra MFMA row); reduce with m3_wgrad_bias_reduce */
+                                      same pass (one extra MFMA row); reduced by m3_wgrad_reduce (same launch as
+                                      the weight slabs) or m3_wgrad_bias_reduce */
 } m3_wgrad_args;
 int m3_wgrad_tn(const m3_wgrad_args *args, void *stream);
-int m3_wgrad_reduce(const float *ws, int splits, int64_t elems, float *dW, int beta, void *stream);
+/* dW (+)= sum over the splits of the weight slabs, fixed order; optionally db (+)= the same over
+ * the bias slabs (bias_ws NULL to skip). */
+int m3_wgrad_reduce(const float *ws, int splits, int64_t elems, float *dW, int beta,
+                    const float *bias_ws, int64_t bias_elems, float *db, int beta_db, void *stream);
 /* db[g][n] (+)= sum_s bias_ws[s][g][n], elems = G*N */
 int m3_wgrad_bias_reduce(const float *bias_ws, int splits, int64_t elems, float *db, int beta, void *stream);
 /* Column sums for bias grads: db[g][n] (+)= sum_{m in group g} dC[crow(m), n].

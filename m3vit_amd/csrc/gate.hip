@@ -261,26 +261,51 @@ __device__ __forceinline__ void cv2_and_grad(const float *v, int E, float &cv, f
     grad_scratch[e] = 2.f * (v[e] - mean) / ((float)(E - 1) * den) - var * (2.f * mean / (float)E) / (den * den);
 }
 
-__global__ __launch_bounds__(256) void balance_kernel(const BalanceDev p) {
-  __shared__ float s_imp[4][64], s_prob[4][64];
-  __shared__ int s_load[4][64];
+__global__ __launch_bounds__(1024) void balance_kernel(const BalanceDev p) {
+  // thread (r, e): e = tid % E, r = tid / E sums rows r, r + RL, ... (4 independent loads in flight),
+  // then the RL row-lanes are added in lane order by thread (0, e)
+  __shared__ float s_imp[1024], s_prob[1024];
+  __shared__ int s_load[1024];
   __shared__ float v_imp[64], v_load[64], g_imp[64], g_load[64];
   const int E = p.E;
-  const int e = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const int RL = 1024 / E;
+  const int e = threadIdx.x % E, r = threadIdx.x / E;
   float a = 0.f, c = 0.f;
   int l = 0;
-  if (e < E)
-    for (int b = r; b < p.nblk; b += 4) {
+  if (r < RL) {
+    int b = r;
+    for (; b + 3 * RL < p.nblk; b += 4 * RL) {
+      const int64_t i0 = (int64_t)b * E + e, i1 = i0 + (int64_t)RL * E, i2 = i1 + (int64_t)RL * E, i3 = i2 + (int64_t)RL * E;
+      const float a0 = p.part_imp[i0], a1 = p.part_imp[i1], a2 = p.part_imp[i2], a3 = p.part_imp[i3];
+      const int l0 = p.part_load[i0], l1 = p.part_load[i1], l2 = p.part_load[i2], l3 = p.part_load[i3];
+      a += a0; a += a1; a += a2; a += a3;
+      l += l0 + l1 + l2 + l3;
+      if (p.part_load_prob) {
+        const float c0 = p.part_load_prob[i0], c1 = p.part_load_prob[i1], c2 = p.part_load_prob[i2], c3 = p.part_load_prob[i3];
+        c += c0; c += c1; c += c2; c += c3;
+      }
+    }
+    for (; b < p.nblk; b += RL) {
       a += p.part_imp[(int64_t)b * E + e];
       l += p.part_load[(int64_t)b * E + e];
       if (p.part_load_prob) c += p.part_load_prob[(int64_t)b * E + e];
     }
-  s_imp[r][e] = a; s_load[r][e] = l; s_prob[r][e] = c;
+  }
+  s_imp[threadIdx.x] = a; s_load[threadIdx.x] = l; s_prob[threadIdx.x] = c;
   __syncthreads();
-  if (r == 0 && e < E) {
-    const float imp = (s_imp[0][e] + s_imp[1][e]) + (s_imp[2][e] + s_imp[3][e]);
-    const int ld = s_load[0][e] + s_load[1][e] + s_load[2][e] + s_load[3][e];
-    const float pr = (s_prob[0][e] + s_prob[1][e]) + (s_prob[2][e] + s_prob[3][e]);
+  // tree over the row-lanes (fixed shape -> deterministic)
+  int top = 1;
+  while (top < RL) top <<= 1;
+  for (int stride = top >> 1; stride >= 1; stride >>= 1) {
+    if (r < stride && r + stride < RL) {
+      const int i = r * E + e, j = (r + stride) * E + e;
+      s_imp[i] += s_imp[j]; s_load[i] += s_load[j]; s_prob[i] += s_prob[j];
+    }
+    __syncthreads();
+  }
+  if (r == 0) {
+    const float imp = s_imp[e], pr = s_prob[e];
+    const int ld = s_load[e];
     p.importance[e] = imp;
     p.load[e] = ld;
     if (p.load_prob) p.load_prob[e] = pr;
@@ -301,7 +326,7 @@ __global__ __launch_bounds__(256) void balance_kernel(const BalanceDev p) {
     if (p.loss_acc) *p.loss_acc += loss;
   }
   __syncthreads();
-  if (r == 0 && e < E) {
+  if (r == 0) {
     if (p.d_importance) p.d_importance[e] = g_imp[e];
     if (p.d_load_prob) p.d_load_prob[e] = p.part_load_prob ? g_load[e] : 0.f;
   }
@@ -542,7 +567,7 @@ extern "C" int m3_balance_loss(const float *part_importance, const int32_t *part
   d.part_imp = part_importance; d.part_load = part_load; d.part_load_prob = part_load_prob;
   d.nblk = nblk; d.E = E; d.importance = importance; d.load = load; d.load_prob = load_prob;
   d.loss_acc = loss_acc; d.loss_out = loss_out; d.d_importance = d_importance; d.d_load_prob = d_load_prob;
-  hipLaunchKernelGGL(balance_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d);
+  hipLaunchKernelGGL(balance_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d);
   return check_launch("m3_balance_loss");
 }
 

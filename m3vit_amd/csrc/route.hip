@@ -37,19 +37,34 @@ __global__ __launch_bounds__(RT_THREADS) void route_hist_kernel(const int32_t *i
   for (int e = threadIdx.x; e < E; e += RT_THREADS) blk_counts[(int64_t)blockIdx.x * E + e] = h[e];
 }
 
-__global__ void route_scan_kernel(const int32_t *blk_counts, int nblk, int E, int32_t *blk_base, int32_t *counts,
-                                  int32_t *offsets, int32_t *tile_starts, int64_t *counts64) {
+// exclusive scan of the per-block histograms along the block axis, one WAVE per expert (64 blocks per
+// step, shuffle scan), then the expert offsets / tile prefix by one thread
+constexpr int RT_SCAN_THREADS = 1024;
+__global__ __launch_bounds__(RT_SCAN_THREADS) void route_scan_kernel(const int32_t *blk_counts, int nblk, int E,
+                                                                     int32_t *blk_base, int32_t *counts,
+                                                                     int32_t *offsets, int32_t *tile_starts,
+                                                                     int64_t *counts64) {
   __shared__ int32_t tot[RT_MAX_E];
-  const int e = threadIdx.x;
-  if (e < E) {
-    int32_t run = 0;
-    for (int b = 0; b < nblk; ++b) {
-      blk_base[(int64_t)b * E + e] = run;
-      run += blk_counts[(int64_t)b * E + e];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int e = wave; e < E; e += RT_SCAN_THREADS / 64) {
+    int32_t carry = 0;
+    for (int b0 = 0; b0 < nblk; b0 += 64) {
+      const int b = b0 + lane;
+      const int32_t v = b < nblk ? blk_counts[(int64_t)b * E + e] : 0;
+      int32_t inc = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int32_t up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+      }
+      if (b < nblk) blk_base[(int64_t)b * E + e] = carry + inc - v;
+      carry += __shfl(inc, 63, 64);
     }
-    tot[e] = run;
-    counts[e] = run;
-    if (counts64) counts64[e] = run;
+    if (lane == 0) {
+      tot[e] = carry;
+      counts[e] = carry;
+      if (counts64) counts64[e] = carry;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -122,7 +137,7 @@ extern "C" int m3_route_build(const int32_t *idx32, int64_t n, int E, int32_t *c
   hipLaunchKernelGGL(route_hist_kernel, dim3(nblk), dim3(RT_THREADS), 0, s, idx32, n, E, blk_counts);
   int rc = check_launch("m3_route_build(hist)");
   if (rc) return rc;
-  hipLaunchKernelGGL(route_scan_kernel, dim3(1), dim3(RT_MAX_E), 0, s, blk_counts, nblk, E, blk_base, counts, offsets,
+  hipLaunchKernelGGL(route_scan_kernel, dim3(1), dim3(RT_SCAN_THREADS), 0, s, blk_counts, nblk, E, blk_base, counts, offsets,
                      tile_starts, counts64);
   rc = check_launch("m3_route_build(scan)");
   if (rc) return rc;

@@ -101,24 +101,26 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_fwd_kernel(const float 
 
 // dx = dx_res + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)); per-block partial
 // dgamma/dbeta (rows of a block summed in row order).
-constexpr int LNB_ROWS = 32;   // rows per workgroup in the backward (4 waves x 8 rows)
+constexpr int LNB_WAVES = 8;               // waves per workgroup in the backward
+constexpr int LNB_THREADS = LNB_WAVES * 64;
+constexpr int LNB_ROWS = LNB_WAVES * 8;    // rows per workgroup (8 per wave): half the dgamma/dbeta partial rows of a 4-wave block
 
 template <typename T, typename TA>
-__global__ __launch_bounds__(ROW_THREADS) void layernorm_bwd_kernel(const T *__restrict__ dy, const float *__restrict__ x,
+__global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(const T *__restrict__ dy, const float *__restrict__ x,
                                                                     const float *__restrict__ mean,
                                                                     const float *__restrict__ rstd,
                                                                     const float *__restrict__ gamma,
                                                                     const float *__restrict__ dx_res, int64_t T_, int D,
                                                                     float *__restrict__ dx, float *__restrict__ part,
                                                                     TA *__restrict__ dx_act) {
-  extern __shared__ float sred[];   // [4 waves][2][D]
+  extern __shared__ float sred[];   // [LNB_WAVES][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nblk = gridDim.x;
   f32x4 dg[4], db[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { dg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; db[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  for (int r = 0; r < LNB_ROWS / 4; ++r) {
-    const int64_t t = (int64_t)blockIdx.x * LNB_ROWS + wave * (LNB_ROWS / 4) + r;
+  for (int r = 0; r < LNB_ROWS / LNB_WAVES; ++r) {
+    const int64_t t = (int64_t)blockIdx.x * LNB_ROWS + wave * (LNB_ROWS / LNB_WAVES) + r;
     if (t >= T_) break;
     const float mu = mean[t], rs = rstd[t];
     f32x4 gdy[4], xh[4];
@@ -159,9 +161,9 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_bwd_kernel(const T *__r
     }
   }
   __syncthreads();
-  for (int d = threadIdx.x; d < D; d += ROW_THREADS) {
+  for (int d = threadIdx.x; d < D; d += LNB_THREADS) {
     float a = 0.f, b = 0.f;
-    for (int w = 0; w < 4; ++w) { a += sred[(w * 2 + 0) * D + d]; b += sred[(w * 2 + 1) * D + d]; }
+    for (int w = 0; w < LNB_WAVES; ++w) { a += sred[(w * 2 + 0) * D + d]; b += sred[(w * 2 + 1) * D + d]; }
     part[(int64_t)blockIdx.x * D + d] = a;
     part[((int64_t)nblk + blockIdx.x) * D + d] = b;
   }
@@ -351,10 +353,10 @@ extern "C" int m3_layernorm_bwd(const void *dy, int dy_dtype, const float *x, co
   if (T == 0) return M3_OK;
   hipStream_t s = (hipStream_t)stream;
   const int nblk = m3_ln_bwd_blocks(T);
-  const size_t lds = (size_t)8 * D * sizeof(float);
+  const size_t lds = (size_t)2 * LNB_WAVES * D * sizeof(float);
   const bool a16 = dx_act && dx_act_dtype == M3_F16;
 #define M3_LNB(TT, TA)                                                                                         \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<TT, TA>), dim3(nblk), dim3(ROW_THREADS), lds, s, (const TT *)dy, x, \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<TT, TA>), dim3(nblk), dim3(LNB_THREADS), lds, s, (const TT *)dy, x, \
                      mean, rstd, gamma, dx_res, T, D, dx, ws, (TA *)dx_act)
   if (dy_dtype == M3_F16) { if (a16) M3_LNB(half_t, half_t); else M3_LNB(half_t, float); }
   else { if (a16) M3_LNB(float, half_t); else M3_LNB(float, float); }

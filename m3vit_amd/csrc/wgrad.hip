@@ -266,8 +266,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float *ws, int splits, int64_t elems4, float *dW, int beta) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// slabs -> dW (blocks [0, nb_w)) and, in the same launch, bias slabs -> db (blocks [nb_w, ...)); splits in order
+__global__ void wgrad_reduce_kernel(const float *ws, int splits, int64_t elems4, float *dW, int beta, int nb_w,
+                                    const float *bias_ws, int64_t belems4, float *db, int beta_db) {
+  int64_t blk = blockIdx.x;
+  if (blk >= nb_w) {
+    blk -= nb_w; ws = bias_ws; elems4 = belems4; dW = db; beta = beta_db;
+  }
+  const int64_t i = blk * blockDim.x + threadIdx.x;
   if (i >= elems4) return;
   f32x4 s = beta ? ((const f32x4 *)dW)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
   for (int sp = 0; sp < splits; ++sp) s += ((const f32x4 *)ws)[(int64_t)sp * elems4 + i];
@@ -376,13 +382,18 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   return check_launch("m3_wgrad_tn");
 }
 
-extern "C" int m3_wgrad_reduce(const float *ws, int splits, int64_t elems, float *dW, int beta, void *stream) {
+extern "C" int m3_wgrad_reduce(const float *ws, int splits, int64_t elems, float *dW, int beta, const float *bias_ws,
+                               int64_t bias_elems, float *db, int beta_db, void *stream) {
   M3_REQUIRE(ws && dW && splits >= 1 && elems >= 0 && elems % 4 == 0, "m3_wgrad_reduce: bad args");
   M3_REQUIRE(((uintptr_t)ws % 16) == 0 && ((uintptr_t)dW % 16) == 0, "m3_wgrad_reduce: alignment");
+  M3_REQUIRE(!bias_ws || (db && bias_elems > 0 && bias_elems % 4 == 0 && ((uintptr_t)bias_ws % 16) == 0 &&
+                          ((uintptr_t)db % 16) == 0),
+             "m3_wgrad_reduce: bias slabs need db, 16-byte alignment and a multiple of 4 elements");
   if (elems == 0) return M3_OK;
-  const int64_t e4 = elems / 4;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((e4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws,
-                     splits, e4, dW, beta);
+  const int64_t e4 = elems / 4, b4 = bias_ws ? bias_elems / 4 : 0;
+  const int nb_w = (int)((e4 + 255) / 256), nb_b = (int)((b4 + 255) / 256);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nb_w + nb_b)), dim3(256), 0, (hipStream_t)stream, ws,
+                     splits, e4, dW, beta, nb_w, bias_ws, b4, db, beta_db);
   return check_launch("m3_wgrad_reduce");
 }
 

@@ -211,11 +211,15 @@ def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None,
     bias_ws = ws[splits * G * N * K:] if db is not None else None
     a.bias_ws = bias_ws.data_ptr() if bias_ws is not None else None
     check(lib().m3_wgrad_tn(byref(a), _stream()), "m3_wgrad_tn")
-    check(lib().m3_wgrad_reduce(_p(ws), splits, G * N * K, _p(dW), beta, _stream()), "m3_wgrad_reduce")
+    bdb = beta if beta_db is None else beta_db
+    fuse = False
     if db is not None:
         _req(db, torch.float32, "db")
-        check(lib().m3_wgrad_bias_reduce(_p(bias_ws), splits, G * N, _p(db), beta if beta_db is None else beta_db,
-                                         _stream()), "m3_wgrad_bias_reduce")
+        fuse = db.data_ptr() % 16 == 0 and bias_ws.data_ptr() % 16 == 0      # both slab reductions in one launch
+    check(lib().m3_wgrad_reduce(_p(ws), splits, G * N * K, _p(dW), beta, _p(bias_ws) if fuse else None, G * N,
+                                _p(db) if fuse else None, bdb, _stream()), "m3_wgrad_reduce")
+    if db is not None and not fuse:
+        check(lib().m3_wgrad_bias_reduce(_p(bias_ws), splits, G * N, _p(db), bdb, _stream()), "m3_wgrad_bias_reduce")
     return dW
 
 
