@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--serial-tasks", action="store_true", help="run the task passes one after the other on one "
+                    "stream (default: one HIP stream per task pass, gradients summed at the end)")
     ap.add_argument("--ep", action="store_true", help="N > 1: shard the experts over the ranks (expert parallel, "
                     "all-to-all over RCCL) instead of replicating them")
     return ap.parse_args()
@@ -147,13 +149,37 @@ def main():
     ntasks = cfg.num_tasks
 
     flat = eng.flat_grads                                   # one flat fp32 gradient buffer
+    # The task passes of one step are independent until their gradients are added (models/models.py:299-301
+    # runs them one after the other): give each its own engine context (activations, scratch, gradient
+    # buffer; parameters and operand copies shared) and its own HIP stream, so that kernels of different
+    # passes overlap (one pass's store-bound phases under the other's MFMA phases, and the ragged last
+    # round of workgroups of one kernel filled by the other's).
+    par_tasks = (not args.serial_tasks) and not use_ep and ntasks > 1
+    engs = [eng] + [BackboneEngine(cfg, None, batch=args.batch, dtype=dtype, device=str(dev), share=eng)
+                    for _ in range(ntasks - 1)] if par_tasks else [eng]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(ntasks - 1)] if par_tasks else []
 
     def compute_step():
         eng.prepare_weights()
-        eng.zero_grad()
+        if not par_tasks:
+            eng.zero_grad()
+            for task in range(ntasks):
+                eng.forward(images, task)
+                eng.backward(dtok, cv_weight=CV_WEIGHT)
+            return
+        main = torch.cuda.current_stream()
+        for st in streams:
+            st.wait_stream(main)
         for task in range(ntasks):
-            eng.forward(images, task)
-            eng.backward(dtok, cv_weight=CV_WEIGHT)
+            with torch.cuda.stream(main if task == 0 else streams[task - 1]):
+                e = engs[task]
+                e.zero_grad()
+                e.forward(images, task)
+                e.backward(dtok, cv_weight=CV_WEIGHT)
+        for st in streams:
+            main.wait_stream(st)
+        for e in engs[1:]:
+            ops.add_f32(flat, e.flat_grads)                 # flat += grads of the other passes
 
     def sync_grads():
         eng.sync_grads(world=world)                         # RCCL over xGMI; mean over ranks (experts stay local under EP)
@@ -253,6 +279,7 @@ def main():
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "task_passes": ntasks,
                    "tokens_per_image": cfg.num_tokens, "cv_loss_weight": CV_WEIGHT,
                    "launch": "hipGraph replay" if graph is not None else "eager",
+                   "task_streams": ntasks if par_tasks else 1,
                    "parallelism": "single" if world == 1 else (f"dp{world}+ep{world} (experts sharded, RCCL all-to-all + all-reduce)"
                                                                     if use_ep else f"dp{world} (replicated experts, RCCL all-reduce)")},
         "model_tflops": round(step_flops * args.steps / dt / 1e12 * world, 2),

@@ -253,6 +253,9 @@ typedef struct m3_cast_desc {
   int32_t tile_start, pad;
 } m3_cast_desc;
 int m3_cast_batch(const m3_cast_desc *descs_dev, int n_desc, int total_tiles, int dst_dtype, void *stream);
+/* dst[i] += src[i] (fp32, n elements): sums the flat gradient buffers of task passes that ran
+ * concurrently (the reference accumulates them through autograd, train/train_utils.py:437-457). */
+int m3_add_f32(float *dst, const float *src, int64_t n, void *stream);
 /* dst(T)[i] = src(f32)[i] ; n elements */
 int m3_cast_f32(const float *src, int64_t n, void *dst, int dst_dtype, void *stream);
 /* patchify: images [B,3,H,W] fp32 NCHW -> rows [B*(H/P)*(W/P), 3*P*P] act dtype in

@@ -114,6 +114,7 @@ SIGNATURES = {
     "m3_attention_bwd": (c_int, [_V, _V, _V, _V, _I, _I, _I, _I, _I, _V, _V, _V]),
     "m3_cast_matrix": (c_int, [_V, _I, _I, _I, _I, _V, _I, _V]),
     "m3_cast_batch": (c_int, [_V, _I, _I, _I, _V]),
+    "m3_add_f32": (c_int, [_V, _V, _L, _V]),
     "m3_cast_f32": (c_int, [_V, _L, _V, _I, _V]),
     "m3_im2row": (c_int, [_V, _I, _I, _I, _I, _I, _V, _I, _V]),
     "m3_assemble_tokens": (c_int, [_V, _V, _V, _I, _I, _I, _V, _V]),

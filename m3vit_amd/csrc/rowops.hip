@@ -248,6 +248,15 @@ __global__ __launch_bounds__(256) void cast_batch_kernel(const CastDesc *__restr
   }
 }
 
+__global__ void add_f32_kernel(float *__restrict__ dst, const float *__restrict__ src, int64_t n4, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) {
+    ((f32x4 *)dst)[i] += ((const f32x4 *)src)[i];
+  } else if (i == n4) {
+    for (int64_t j = n4 * 4; j < n; ++j) dst[j] += src[j];
+  }
+}
+
 template <typename T>
 __global__ void cast_f32_kernel(const float *__restrict__ src, int64_t n4, T *__restrict__ dst) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -386,6 +395,16 @@ extern "C" int m3_cast_batch(const m3_cast_desc *descs_dev, int n_desc, int tota
   if (dst_dtype == M3_F16) hipLaunchKernelGGL(cast_batch_kernel<half_t>, dim3(total_tiles), dim3(256), 0, s, d, n_desc);
   else hipLaunchKernelGGL(cast_batch_kernel<float>, dim3(total_tiles), dim3(256), 0, s, d, n_desc);
   return check_launch("m3_cast_batch");
+}
+
+extern "C" int m3_add_f32(float *dst, const float *src, int64_t n, void *stream) {
+  M3_REQUIRE(dst && src && n >= 0, "m3_add_f32: bad args");
+  M3_REQUIRE(((uintptr_t)dst % 16) == 0 && ((uintptr_t)src % 16) == 0, "m3_add_f32: 16-byte alignment");
+  if (n == 0) return M3_OK;
+  const int64_t n4 = n / 4;
+  hipLaunchKernelGGL(add_f32_kernel, dim3((unsigned)((n4 + 1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, src,
+                     n4, n);
+  return check_launch("m3_add_f32");
 }
 
 extern "C" int m3_cast_f32(const float *src, int64_t n, void *dst, int dst_dtype, void *stream) {

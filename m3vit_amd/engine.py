@@ -38,10 +38,13 @@ class _Cfg:
 
 class BackboneEngine:
     def __init__(self, cfg, params: Dict[str, torch.Tensor], batch: int, dtype=torch.float16,
-                 device="cuda:0", ep_group=None, ep_world: int = 1, ep_rank: int = 0):
+                 device="cuda:0", ep_group=None, ep_world: int = 1, ep_rank: int = 0, share: "BackboneEngine" = None):
         """params: GLOBAL parameters (all E experts).  With ep_world > 1 this rank keeps experts
         [ep_rank*E/W, (ep_rank+1)*E/W) (utils/common_config.py:179-185) and exchanges routed rows with
-        the other ranks over torch.distributed (RCCL) - see _experts_fwd_ep."""
+        the other ranks over torch.distributed (RCCL) - see _experts_fwd_ep.
+        share: another engine of the same configuration whose parameters and operand copies this one
+        uses (params is ignored); it gets its own activations, scratch and gradient buffer, so the two
+        can run different task passes concurrently on different HIP streams."""
         self.cfg = cfg
         self.dev = torch.device(device)
         self.dt = dtype
@@ -65,9 +68,12 @@ class BackboneEngine:
         self.E_loc = self.E // self.ep_world
         is_exp = lambda n: ".mlp.experts." in n                                  # noqa: E731
         lo, hi = self.ep_rank * self.E_loc, (self.ep_rank + 1) * self.E_loc
-        names = [n for n in params if not is_exp(n)] + [n for n in params if is_exp(n)]     # experts last
-        self.params = {n: (params[n][lo:hi] if (is_exp(n) and self.ep_world > 1) else params[n])
-                       .to(self.dev, torch.float32).contiguous() for n in names}
+        if share is not None:
+            self.params = share.params
+        else:
+            names = [n for n in params if not is_exp(n)] + [n for n in params if is_exp(n)]     # experts last
+            self.params = {n: (params[n][lo:hi] if (is_exp(n) and self.ep_world > 1) else params[n])
+                           .to(self.dev, torch.float32).contiguous() for n in names}
         self.n_dense = sum(p.numel() for n, p in self.params.items() if not is_exp(n))
         # one flat fp32 gradient buffer (views per parameter): zeroing is one memset and the data-parallel
         # sync is one RCCL all-reduce (xGMI is point-to-point: few large collectives)
@@ -80,7 +86,10 @@ class BackboneEngine:
         dense_only = bool(getattr(cfg, "dense_only", False))
         self.is_moe = [(i % 2 == 1) and not dense_only for i in range(self.depth)]
         self._alloc()
-        self.prepare_weights()
+        if share is not None:
+            self.wc, self.wt, self.wgate_c, self.cast_plan = share.wc, share.wt, share.wgate_c, None
+        else:
+            self.prepare_weights()
 
     # ------------------------------------------------------------------ buffers
     def _e(self, *shape, dtype=None):

@@ -337,6 +337,14 @@ class CastPlan:
         check(lib().m3_cast_batch(_p(self.table), self.n, self.total, dt_code(self.dtype), _stream()), "m3_cast_batch")
 
 
+def add_f32(dst, src):
+    """dst += src (flat fp32 buffers)."""
+    _req(dst, torch.float32, "dst"); _req(src, torch.float32, "src")
+    assert dst.numel() == src.numel()
+    check(lib().m3_add_f32(_p(dst), _p(src), dst.numel(), _stream()), "m3_add_f32")
+    return dst
+
+
 def cast_f32(src, dst):
     check(lib().m3_cast_f32(_p(src), src.numel(), _p(dst), dt_code(dst.dtype), _stream()), "m3_cast_f32")
     return dst

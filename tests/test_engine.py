@@ -160,3 +160,50 @@ def test_config0_dense_vit_tiny_plumbing():
     (tr * dtok).sum().backward()
     bad = [(n, rel(g, Pr[n].grad)) for n, g in eng.grads.items() if rel(g, Pr[n].grad) > 2e-3]
     assert not bad, bad
+
+
+def test_task_passes_on_two_streams_match_serial():
+    """bench.py runs the task passes of a step concurrently: one engine context + HIP stream per pass
+    (parameters and operand copies shared), gradient buffers added at the end.  Same gradients as the
+    serial accumulation (up to fp32 summation order)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from m3vit_amd import ops
+    from m3vit_amd.engine import BackboneEngine
+    from oracle import ref_torch as R
+    cfg = R.BackboneCfg(img_size=(64, 64), embed_dim=64, depth=4, num_heads=2, mlp_ratio=4.0, moe_mlp_ratio=1.0,
+                        moe_experts=8, moe_top_k=2, gate_dim=66, multi_gate=True)
+    B = 8
+    P = R.init_backbone_params(cfg, seed=3)
+    torch.manual_seed(2)
+    img = torch.randn(B, 3, 64, 64).cuda()
+    dtok = (torch.randn(B, cfg.num_tokens, 64) * 0.1).cuda()
+    serial = BackboneEngine(cfg, P, batch=B, dtype=torch.float16)
+    serial.zero_grad()
+    toks = []
+    for task in (0, 1):
+        tok, cv = serial.forward(img, task)
+        toks.append((tok.clone(), float(cv)))
+        serial.backward(dtok, cv_weight=0.01)
+    e0 = BackboneEngine(cfg, P, batch=B, dtype=torch.float16)
+    e1 = BackboneEngine(cfg, None, batch=B, dtype=torch.float16, share=e0)
+    assert e1.params is e0.params and e1.wc is e0.wc
+    side = torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+    for _ in range(2):                                   # twice: buffers are reused step after step
+        e0.prepare_weights()
+        side.wait_stream(main)
+        outs = [None, None]
+        for task, (e, st) in enumerate(((e0, main), (e1, side))):
+            with torch.cuda.stream(st):
+                e.zero_grad()
+                tok, cv = e.forward(img, task)
+                outs[task] = (tok, cv)
+                e.backward(dtok, cv_weight=0.01)
+        main.wait_stream(side)
+        ops.add_f32(e0.flat_grads, e1.flat_grads)
+        torch.cuda.synchronize()
+        for task in (0, 1):
+            assert torch.equal(outs[task][0], toks[task][0])
+            assert abs(float(outs[task][1]) - toks[task][1]) < 1e-6
+        assert rel(e0.flat_grads, serial.flat_grads) < 1e-5
