@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--serial-tasks", action="store_true", help="run the task passes one after the other on one "
                     "stream (default: one HIP stream per task pass, gradients summed at the end)")
+    ap.add_argument("--wgrad-streams", action="store_true", help="also launch the weight-gradient GEMMs of each "
+                    "pass on their own stream (eager launch only: hipGraph capture of that pattern crashes in ROCm 7.2)")
     ap.add_argument("--ep", action="store_true", help="N > 1: shard the experts over the ranks (expert parallel, "
                     "all-to-all over RCCL) instead of replicating them")
     return ap.parse_args()
@@ -141,8 +143,9 @@ def main():
     dtype = torch.float16 if args.dtype == "f16" else torch.float32
     params = init_params(cfg, seed=1)                       # same weights on every rank
     use_ep = args.ep and world > 1
+    wg_stream = args.wgrad_streams and not use_ep
     eng = BackboneEngine(cfg, params, batch=args.batch, dtype=dtype, device=str(dev),
-                         ep_world=world if use_ep else 1, ep_rank=rank if use_ep else 0)
+                         ep_world=world if use_ep else 1, ep_rank=rank if use_ep else 0, wgrad_stream=wg_stream)
     g = torch.Generator().manual_seed(1000 + rank)          # each rank its own images
     images = torch.randn(args.batch, 3, *cfg.img_size, generator=g).to(dev)
     dtok = (torch.randn(args.batch, cfg.num_tokens, cfg.embed_dim, generator=g) * 0.05).to(dev)
@@ -155,18 +158,21 @@ def main():
     # passes overlap (one pass's store-bound phases under the other's MFMA phases, and the ragged last
     # round of workgroups of one kernel filled by the other's).
     par_tasks = (not args.serial_tasks) and not use_ep and ntasks > 1
-    engs = [eng] + [BackboneEngine(cfg, None, batch=args.batch, dtype=dtype, device=str(dev), share=eng)
-                    for _ in range(ntasks - 1)] if par_tasks else [eng]
+    engs = [eng] + [BackboneEngine(cfg, None, batch=args.batch, dtype=dtype, device=str(dev), share=eng,
+                                   wgrad_stream=wg_stream) for _ in range(ntasks - 1)] if par_tasks else [eng]
     streams = [torch.cuda.Stream(device=dev) for _ in range(ntasks - 1)] if par_tasks else []
 
-    def compute_step():
+    def serial_step():
         eng.prepare_weights()
+        eng.zero_grad()
+        for task in range(ntasks):
+            eng.forward(images, task)
+            eng.backward(dtok, cv_weight=CV_WEIGHT)
+
+    def compute_step():
         if not par_tasks:
-            eng.zero_grad()
-            for task in range(ntasks):
-                eng.forward(images, task)
-                eng.backward(dtok, cv_weight=CV_WEIGHT)
-            return
+            return serial_step()
+        eng.prepare_weights()
         main = torch.cuda.current_stream()
         for st in streams:
             st.wait_stream(main)
@@ -205,7 +211,7 @@ def main():
     # into a hipGraph and replay it (the launch-bound inner loop is the graph, not the Python loop).
     run = step
     graph = None
-    if not args.no_graph and not use_ep:       # EP reads the per-layer counts on the host: not capturable
+    if not args.no_graph and not use_ep and not wg_stream:       # EP reads the per-layer counts on the host: not capturable
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -245,12 +251,21 @@ def main():
     value = world * args.batch * args.steps / dt
 
     # ---- roofline of the dominant kernel (gemm_nt_kernel: every Linear / FMoELinear fwd + dgrad),
-    # measured with HIP events around each launch in a few extra instrumented steps
+    # measured with HIP events around each launch (on the launch stream) in a few extra instrumented steps:
+    # (a) launched exactly as in the timed region (task passes on concurrent streams: a launch then shares the
+    # CUs with the other pass's kernels, so its duration is longer than its resource time), and (b) serially on
+    # one stream (the kernel by itself).
+    n_inst = min(3, args.steps)
     with GemmTimer(ops) as gt:
-        for _ in range(min(3, args.steps)):
+        for _ in range(n_inst):
             step()
         torch.cuda.synchronize()
     gs = gt.summary()
+    with GemmTimer(ops) as gt1:
+        for _ in range(n_inst):
+            serial_step()
+        torch.cuda.synchronize()
+    g1 = gt1.summary()
     peak = PEAK[args.dtype]
     # HBM traffic per launch of that kernel: PMC numbers cannot be read from inside the process; they come from
     # the committed rocprofv3 --pmc passes over this same command (profiles/r01_pmc_traffic.json)
@@ -264,10 +279,16 @@ def main():
         traffic = None
     roofline = {"kernel": "gemm_nt_kernel", "bound": "mfma", "achieved": round(gs["tflops"], 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(gs["tflops"] / peak, 4), "traffic": traffic,
-                "avg_launch_us": round(gs["avg_us"], 2), "launches_per_step": gs["launches"] // min(3, args.steps),
+                "avg_launch_us": round(gs["avg_us"], 2), "launches_per_step": gs["launches"] // n_inst,
                 "flops_per_launch": gs["flops_per_launch"],
                 "expert_grouped_gemm_tflops": round(gs["grouped_tflops"], 2),
-                "expert_grouped_gemm_frac": round(gs["grouped_tflops"] / peak, 4)}
+                "expert_grouped_gemm_frac": round(gs["grouped_tflops"] / peak, 4),
+                "launch_mode": f"as timed: {ntasks} concurrent task streams" if par_tasks else "as timed: one stream",
+                "isolated": {"achieved": round(g1["tflops"], 2), "frac": round(g1["tflops"] / peak, 4),
+                             "avg_launch_us": round(g1["avg_us"], 2),
+                             "expert_grouped_gemm_tflops": round(g1["grouped_tflops"], 2),
+                             "expert_grouped_gemm_frac": round(g1["grouped_tflops"] / peak, 4),
+                             "launch_mode": "same launches, one stream, nothing else on the GPU"}}
 
     step_flops = 3.0 * cfg.fwd_flops_per_image() * args.batch * ntasks
     out = {
@@ -279,7 +300,7 @@ def main():
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "task_passes": ntasks,
                    "tokens_per_image": cfg.num_tokens, "cv_loss_weight": CV_WEIGHT,
                    "launch": "hipGraph replay" if graph is not None else "eager",
-                   "task_streams": ntasks if par_tasks else 1,
+                   "task_streams": ntasks if par_tasks else 1, "wgrad_streams": len(engs) if wg_stream else 0,
                    "parallelism": "single" if world == 1 else (f"dp{world}+ep{world} (experts sharded, RCCL all-to-all + all-reduce)"
                                                                     if use_ep else f"dp{world} (replicated experts, RCCL all-reduce)")},
         "model_tflops": round(step_flops * args.steps / dt / 1e12 * world, 2),

@@ -295,6 +295,167 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (fast path: K*elem a multiple of 64 bytes, staged epilogue shapes).
+// Same tile / wave layout / epilogue as gemm_nt_kernel, but the operands go global -> LDS directly
+// (global_load_lds_dwordx4: one wave instruction fills 16 rows x 64 B = 1 KiB of the image, lane-linear
+// in LDS, with the XOR swizzle applied on the per-lane SOURCE address), in 64-byte K slices:
+//   - no staging registers and no ds_write pass: <= 128 VGPRs and 32 KiB of LDS per workgroup, so FOUR
+//     workgroups share a CU instead of two - their load / MFMA / store phases interleave, which is what
+//     the K = 384 shapes of this model need (a tile spends more time in its prologue and in the
+//     bandwidth-bound store phase than in MFMAs);
+//   - double buffer, one barrier per K step: the DMA of step k+1 flies under the MFMAs of step k; the
+//     __syncthreads() at the end of the step is also the vmcnt(0) that retires it (hipcc drains LDS-DMA at
+//     a barrier) - exactly where this scheme needs the wait.
+constexpr int DMA_RB = 64;                 // bytes of a row slice
+constexpr int DMA_OPB = BM * DMA_RB;       // one operand image (8 KiB)
+
+__device__ __forceinline__ int dma_swz(int row) { return (0 - (row >> 2)) & 3; }
+
+template <typename T>
+__global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const GemmDev p) {
+  typedef Mma<T> MM;
+  typedef typename MM::frag frag;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [buf][A|B][128 rows * 64 B] = 32 KiB
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = t / p.n_tiles, nt = t - mt * p.n_tiles;
+  int g = 0;
+  int64_t m_begin, m_end;
+  if (p.tile_starts) {
+    const int total = p.tile_starts[p.G];
+    if (mt >= total) return;
+    while (g + 1 < p.G && p.tile_starts[g + 1] <= mt) ++g;
+    m_begin = (int64_t)p.group_offsets[g] + (int64_t)(mt - p.tile_starts[g]) * BM;
+    m_end = p.group_offsets[g + 1];
+  } else {
+    m_begin = (int64_t)mt * BM;
+    m_end = p.M;
+    if (m_begin >= m_end) return;
+  }
+  const int n0 = nt * BN;
+
+  // DMA assignment: wave w, piece j (0,1) fills image rows (2w + j)*16 .. +15; lane l -> row + (l >> 2),
+  // LDS slot l & 3, which holds source chunk (l & 3) ^ swz(row).  Rows past the end are clamped (never stored).
+  const char *a_src[2], *b_src[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (2 * wave + j) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ dma_swz(row);
+    int64_t m = m_begin + row;
+    if (m >= m_end) m = m_end - 1;
+    int64_t src = m;
+    if (p.a_row_idx) src = (int64_t)(p.a_row_idx[m] / p.a_row_div);
+    a_src[j] = p.A + src * p.lda_b + c * 16;
+    int n = n0 + row;
+    if (n >= p.N) n = p.N - 1;
+    b_src[j] = p.B + (int64_t)g * p.b_group_b + (int64_t)n * p.ldb_b + c * 16;
+  }
+  const int nk = (p.K * (int)sizeof(T)) / DMA_RB;
+
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  auto dma = [&](int ks, int buf) {
+    char *dst = smem + buf * (2 * DMA_OPB) + (2 * wave) * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __builtin_amdgcn_global_load_lds((glb_void *)(a_src[j] + ks * DMA_RB), (lds_void *)(dst + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void *)(b_src[j] + ks * DMA_RB), (lds_void *)(dst + j * 1024 + DMA_OPB), 16, 0, 0);
+    }
+  };
+
+  const int rdA = (wr * 64 + li) * DMA_RB + ((lg ^ dma_swz(li)) << 4);               // + i*16*64
+  const int rdB = (wc * 64 + li) * DMA_RB + ((lg ^ dma_swz(li)) << 4) + DMA_OPB;
+
+  f32x4 acc[4][4];   // [ni][mi]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  dma(0, 0);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int buf = ks & 1;
+    if (ks + 1 < nk) dma(ks + 1, buf ^ 1);
+    const char *sb = smem + buf * (2 * DMA_OPB);
+    frag fa[4], fb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[i] = *(const frag *)(sb + rdA + i * 16 * DMA_RB);
+      fb[i] = *(const frag *)(sb + rdB + i * 16 * DMA_RB);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = MM::mma(fb[ni], fa[mi], acc[ni][mi]);
+    __syncthreads();
+  }
+
+  // ---- epilogue: the fp32 tile goes through the (now free) 32 KiB in two 64-row halves (half h = waves wr == h),
+  // every lane then owns 8 consecutive n of one row
+  const float *bias = p.bias ? p.bias + (int64_t)g * p.N : nullptr;
+  const int cg = tid & 15, r16 = tid >> 4;
+  const int n = n0 + cg * 8;
+  f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
+  if (bias && n < p.N) { b0 = *(const f32x4 *)(bias + n); b1 = *(const f32x4 *)(bias + n + 4); }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h) __syncthreads();
+    if (wr == h) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int lrow = mi * 16 + li;
+          const int chunk = wc * 16 + ni * 4 + lg;
+          *(f32x4 *)(smem + lrow * 512 + ((chunk ^ (lrow & 31)) << 4)) = acc[ni][mi];
+        }
+    }
+    __syncthreads();
+    if (n < p.N) {
+#pragma unroll 2
+      for (int ps = 0; ps < 4; ++ps) {
+        const int lrow = ps * 16 + r16;
+        const int64_t m = m_begin + h * 64 + lrow;
+        if (m >= m_end) break;
+        const int64_t crow = p.c_row_idx ? (int64_t)p.c_row_idx[m] : m;
+        const int sw = lrow & 31;
+        f32x4 v0 = *(const f32x4 *)(smem + lrow * 512 + (((2 * cg) ^ sw) << 4));
+        f32x4 v1 = *(const f32x4 *)(smem + lrow * 512 + (((2 * cg + 1) ^ sw) << 4));
+        v0 += b0; v1 += b1;
+        if (p.pre_out) Vec8<T>::store((T *)p.pre_out + crow * p.ld_pre + n, v0, v1);
+        if (p.act == M3_ACT_GELU) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v0[j] = gelu_f(v0[j]); v1[j] = gelu_f(v1[j]); }
+        }
+        if (p.gpre) {
+          f32x4 p0, p1;
+          Vec8<T>::load((const T *)p.gpre + crow * p.ld_gpre + n, p0, p1);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v0[j] *= gelu_grad_f(p0[j]); v1[j] *= gelu_grad_f(p1[j]); }
+        }
+        if (p.residual) {
+          v0 += *(const f32x4 *)(p.residual + crow * p.ld_res + n);
+          v1 += *(const f32x4 *)(p.residual + crow * p.ld_res + n + 4);
+        }
+        if (p.c_f32) {
+          *(f32x4 *)((float *)p.C + crow * p.ldc + n) = v0;
+          *(f32x4 *)((float *)p.C + crow * p.ldc + n + 4) = v1;
+        } else {
+          Vec8<T>::store((T *)p.C + crow * p.ldc + n, v0, v1);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace m3
 
 using namespace m3;
@@ -345,6 +506,21 @@ extern "C" int m3_gemm_nt(const m3_gemm_args *a, void *stream) {
   // 32-bit per-lane byte offsets: A rows (gathered source rows must be < M) and one B group must fit 4 GiB
   M3_REQUIRE((a->M + 1) * a->lda * es < ((int64_t)1 << 32) && (int64_t)a->N * a->ldb * es < ((int64_t)1 << 32),
              "m3_gemm_nt: operand panel exceeds the 4 GiB reach of the 32-bit lane offsets");
+  // variant: M3_GEMM_DMA=1/0 forces the LDS-DMA / register-staged kernel (diagnostics); default by shape
+  static int dma_mode = -1;
+  if (dma_mode < 0) { const char *e = getenv("M3_GEMM_DMA"); dma_mode = e ? (atoi(e) ? 1 : 0) : 2; }
+  const bool dma_ok = d.vec8 && (a->K * es) % DMA_RB == 0;
+  // default: fp16 with a short contraction (K*elem <= M3_GEMM_DMA_MAXKB, 1 KiB); long-K shapes amortise the
+  // register-staged kernel's longer K step and are a little faster there (measured: profiles/README.md)
+  static int dma_maxkb = -1;
+  if (dma_maxkb < 0) { const char *e = getenv("M3_GEMM_DMA_MAXKB"); dma_maxkb = e ? atoi(e) : 1024; }
+  const bool use_dma = dma_ok && (dma_mode == 1 || (dma_mode == 2 && a->dtype == M3_F16 && a->K * es <= dma_maxkb));
+  if (use_dma) {
+    const size_t lds_dma = 4 * DMA_OPB;   // 32 KiB
+    if (a->dtype == M3_F16) hipLaunchKernelGGL((gemm_nt_dma_kernel<half_t>), grid, block, lds_dma, s, d);
+    else hipLaunchKernelGGL((gemm_nt_dma_kernel<float>), grid, block, lds_dma, s, d);
+    return check_launch("m3_gemm_nt");
+  }
   const bool ktail = (a->K * es) % ROWB != 0;
   if (a->dtype == M3_F16) {
     if (ktail) hipLaunchKernelGGL((gemm_nt_kernel<half_t, true>), grid, block, lds, s, d);

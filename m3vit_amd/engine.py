@@ -38,13 +38,16 @@ class _Cfg:
 
 class BackboneEngine:
     def __init__(self, cfg, params: Dict[str, torch.Tensor], batch: int, dtype=torch.float16,
-                 device="cuda:0", ep_group=None, ep_world: int = 1, ep_rank: int = 0, share: "BackboneEngine" = None):
+                 device="cuda:0", ep_group=None, ep_world: int = 1, ep_rank: int = 0, share: "BackboneEngine" = None,
+                 wgrad_stream: bool = False):
         """params: GLOBAL parameters (all E experts).  With ep_world > 1 this rank keeps experts
         [ep_rank*E/W, (ep_rank+1)*E/W) (utils/common_config.py:179-185) and exchanges routed rows with
         the other ranks over torch.distributed (RCCL) - see _experts_fwd_ep.
         share: another engine of the same configuration whose parameters and operand copies this one
         uses (params is ignored); it gets its own activations, scratch and gradient buffer, so the two
-        can run different task passes concurrently on different HIP streams."""
+        can run different task passes concurrently on different HIP streams.
+        wgrad_stream: launch the weight-gradient GEMMs of backward() on a second HIP stream - they hang off
+        the dgrad chain (nothing downstream reads them), so they can fill the chain's memory-bound phases."""
         self.cfg = cfg
         self.dev = torch.device(device)
         self.dt = dtype
@@ -85,6 +88,8 @@ class BackboneEngine:
             o += p.numel()
         dense_only = bool(getattr(cfg, "dense_only", False))
         self.is_moe = [(i % 2 == 1) and not dense_only for i in range(self.depth)]
+        self.wg_stream = torch.cuda.Stream(device=self.dev) if (wgrad_stream and self.ep_world == 1) else None
+        self._readers, self._ev_pool, self._ev_i = {}, [], 0
         self._alloc()
         if share is not None:
             self.wc, self.wt, self.wgate_c, self.cast_plan = share.wc, share.wt, share.wgate_c, None
@@ -391,16 +396,53 @@ class BackboneEngine:
         buf.div_(world)
 
     # ----------------------------------------------------------------- backward
-    def _wgrad(self, dC, A, name, M=None, bias=None, **kw):
+    def _fork(self, reads, fn):
+        """Run fn() - weight-gradient launches - on the wgrad stream, ordered after everything queued so far
+        on the current stream; `reads` names the scratch buffers it reads, which the main chain may only
+        overwrite after _before_write(name)."""
+        if self.wg_stream is None:
+            fn()
+            return
+        ready = self._event()
+        ready.record(torch.cuda.current_stream())
+        self.wg_stream.wait_event(ready)
+        with torch.cuda.stream(self.wg_stream):
+            fn()
+            done = self._event()
+            done.record(self.wg_stream)
+        for r in reads:
+            self._readers[r] = done
+
+    def _event(self):
+        # events come from a pool that lives as long as the engine (none is destroyed while a hipGraph
+        # capture that recorded it is open) and is walked in the same order every backward()
+        if self._ev_i == len(self._ev_pool):
+            self._ev_pool.append(torch.cuda.Event())
+        self._ev_i += 1
+        return self._ev_pool[self._ev_i - 1]
+
+    def _before_write(self, *names):
+        for n in names:
+            ev = self._readers.pop(n, None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+
+    def _join_wgrad(self):
+        if self.wg_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.wg_stream)
+            self._readers.clear()
+
+    def _wgrad(self, dC, A, name, M=None, bias=None, reads=(), **kw):
         """weight grad (+ fused bias grad) accumulated into self.grads"""
-        ops.wgrad_tn(dC, A, self.grads[name], M=M, beta=1, ws=self.ws_wgrad,
-                     db=self.grads[bias] if bias is not None else None, **kw)
+        self._fork(reads, lambda: ops.wgrad_tn(dC, A, self.grads[name], M=M, beta=1, ws=self.ws_wgrad,
+                                               db=self.grads[bias] if bias is not None else None, **kw))
 
     def backward(self, d_tokens: torch.Tensor, cv_weight: float = 0.0):
         """Accumulates parameter gradients of  <tokens, d_tokens> + cv_weight * total_cv_loss
         into self.grads (beta = 1: the joint multi-task backward, train/train_utils.py:437-457)."""
         p, gr = self.params, self.grads
         B, T, D, R, k = self.B, self.T, self.D, self.R, self.k
+        self._ev_i = 0
         dx = self.s_dxa
         dx.copy_(d_tokens.reshape(T, D))
         other = self.s_dxb
@@ -410,32 +452,37 @@ class BackboneEngine:
             b = f"blocks.{i}."
             if not self.is_moe[i]:
                 if not have_dx_t:
+                    self._before_write("dx_t")
                     ops.cast_f32(dx, self.s_dx_t)
                 dpre = self.s_dpre[: T * self.Hd].view(T, self.Hd)
-                self._wgrad(self.s_dx_t, a["u"], b + "mlp.fc2.weight", bias=b + "mlp.fc2.bias")
+                self._wgrad(self.s_dx_t, a["u"], b + "mlp.fc2.weight", bias=b + "mlp.fc2.bias", reads=("dx_t",))
+                self._before_write("dpre")
                 ops.gemm_nt(self.s_dx_t, self.wt[b + "mlp.fc2"], dpre, gelu_grad_pre=a["pre"])
-                self._wgrad(dpre, a["h2"], b + "mlp.fc1.weight", bias=b + "mlp.fc1.bias")
+                self._wgrad(dpre, a["h2"], b + "mlp.fc1.weight", bias=b + "mlp.fc1.bias", reads=("dpre",))
                 ops.gemm_nt(dpre, self.wt[b + "mlp.fc1"], self.s_dh)
                 dh2 = self.s_dh
             else:
                 g, r = a["gate"], a["route"]
+                self._before_write("dy")
                 ops.combine_bwd(dx, a["y"], g["score"], self.s_dy, self.s_dscore)
                 if self.ep_world > 1:
                     self._experts_bwd_ep(i, a)
                 else:
                     dhp = self.s_dpre[: R * self.Hm].view(R, self.Hm)
                     self._wgrad(self.s_dy, a["hid"], b + "mlp.experts.h4toh.weight", M=R, c_row_idx=r.row_of_slot,
-                                group_offsets=r.offsets, bias=b + "mlp.experts.h4toh.bias")
+                                group_offsets=r.offsets, bias=b + "mlp.experts.h4toh.bias", reads=("dy",))
+                    self._before_write("dpre")
                     ops.gemm_nt(self.s_dy, self.wt[b + "mlp.experts.h4toh"], dhp, M=R, gelu_grad_pre=a["hid_pre"],
                                 a_row_idx=r.row_of_slot, a_row_div=1, group_offsets=r.offsets,
                                 tile_starts=r.tile_starts)
                     self._wgrad(dhp, a["h2"], b + "mlp.experts.htoh4.weight", M=R, a_row_idx=r.row_of_slot,
-                                a_row_div=k, group_offsets=r.offsets, bias=b + "mlp.experts.htoh4.bias")
+                                a_row_div=k, group_offsets=r.offsets, bias=b + "mlp.experts.htoh4.bias", reads=("dpre",))
                     ops.gemm_nt(dhp, self.wt[b + "mlp.experts.htoh4"], self.s_dxe, M=R, c_row_idx=r.row_of_slot,
                                 group_offsets=r.offsets, tile_starts=r.tile_starts)
                 ops.combine_fwd(self.s_dxe, self.ones_k, None, self.s_dh32)       # dh2 = sum_j dxe[t,j]
                 # gate: d score from the combine, d importance / d load from the cv loss
                 bal = cv_weight != 0.0
+                self._before_write("dl")
                 dl = ops.gate_bwd_logits(g["noisy"], g["idx"], self.s_dscore, g["d_importance"] if bal else None, k,
                                          balance_scale=cv_weight, idx_next=g["idx_next"],
                                          d_load_prob=g["d_load_prob"] if bal else None, clean=g["clean"],
@@ -448,7 +495,7 @@ class BackboneEngine:
                         dl_t, wg_t = dl, wg
                     else:
                         dl_t, wg_t = ops.cast_f32(dl, self.s_dl_t), self.wgate_c[a["wname"]][:D]
-                    ops.wgrad_tn(a["h2"], dl_t, dwg, beta=1, ws=self.ws_wgrad)
+                    self._fork(("dl",), lambda: ops.wgrad_tn(a["h2"], dl_t, dwg, beta=1, ws=self.ws_wgrad))
                     ops.gemm_nt(dl_t, wg_t, self.s_dh32, residual=self.s_dh32)
                 else:
                     ops.gate_bwd_params(a["h2"], wg, dl, d_w_gate=dwg, beta_dw=1, dx=self.s_dh32,
@@ -456,17 +503,21 @@ class BackboneEngine:
                 if self._tsf is not None:
                     a["d_logit_bias"] = ops.colsum(dl, torch.empty(self.E, device=self.dev), ws=self.ws_colsum)
                 dh2 = self.s_dh32
+            self._before_write("dx_t")
             ops.layernorm_bwd(dh2, a["x1"], a["mean2"], a["rstd2"], p[b + "norm2.weight"], dx, other,
                               gr[b + "norm2.weight"], gr[b + "norm2.bias"], beta=1, ws=self.ws_ln,
                               dx_act=self.s_dx_t)                        # also emits the activation-dtype copy
             dx, other = other, dx                                        # dx = d x1
-            self._wgrad(self.s_dx_t, a["o"], b + "attn.proj.weight", bias=b + "attn.proj.bias")
+            self._wgrad(self.s_dx_t, a["o"], b + "attn.proj.weight", bias=b + "attn.proj.bias", reads=("dx_t",))
             ops.gemm_nt(self.s_dx_t, self.wt[b + "attn.proj"], self.s_do)
+            self._before_write("dqkv")
             ops.attention_bwd(a["qkv"], a["o"], self.s_do, a["lse"], B, self.N, self.heads, self.dh, self.s_dqkv,
                               dq_ws=self.ws_dq)
-            self._wgrad(self.s_dqkv, a["h1"], b + "attn.qkv.weight", bias=b + "attn.qkv.bias")
+            self._wgrad(self.s_dqkv, a["h1"], b + "attn.qkv.weight", bias=b + "attn.qkv.bias", reads=("dqkv",))
             ops.gemm_nt(self.s_dqkv, self.wt[b + "attn.qkv"], self.s_dh)
             nxt_dense = i > 0 and not self.is_moe[i - 1]                 # the block below consumes dx_t directly
+            if nxt_dense:
+                self._before_write("dx_t")
             ops.layernorm_bwd(self.s_dh, a["x_in"], a["mean1"], a["rstd1"], p[b + "norm1.weight"], dx, other,
                               gr[b + "norm1.weight"], gr[b + "norm1.bias"], beta=1, ws=self.ws_ln,
                               dx_act=self.s_dx_t if nxt_dense else None)
@@ -475,7 +526,9 @@ class BackboneEngine:
         # patch embedding / cls / pos
         ops.tokens_bwd(dx, B, self.np_, D, self.s_dpatch, gr["pos_embed"].view(self.N, D), gr["cls_token"].view(D), beta=1)
         gw = gr["patch_embed.proj.weight"].view(D, -1)
-        ops.wgrad_tn(self.s_dpatch, self.rows, gw, beta=1, ws=self.ws_wgrad, db=gr["patch_embed.proj.bias"])
+        self._fork((), lambda: ops.wgrad_tn(self.s_dpatch, self.rows, gw, beta=1, ws=self.ws_wgrad,
+                                            db=gr["patch_embed.proj.bias"]))
+        self._join_wgrad()
         if self._tsf is not None:
             self._task_feature_bwd()
         return dx

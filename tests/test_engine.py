@@ -164,8 +164,9 @@ def test_config0_dense_vit_tiny_plumbing():
 
 def test_task_passes_on_two_streams_match_serial():
     """bench.py runs the task passes of a step concurrently: one engine context + HIP stream per pass
-    (parameters and operand copies shared), gradient buffers added at the end.  Same gradients as the
-    serial accumulation (up to fp32 summation order)."""
+    (parameters and operand copies shared), gradient buffers added at the end, and each pass launches its
+    weight-gradient GEMMs on a further stream.  Same gradients as the serial accumulation (up to fp32
+    summation order)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from m3vit_amd import ops
@@ -185,8 +186,8 @@ def test_task_passes_on_two_streams_match_serial():
         tok, cv = serial.forward(img, task)
         toks.append((tok.clone(), float(cv)))
         serial.backward(dtok, cv_weight=0.01)
-    e0 = BackboneEngine(cfg, P, batch=B, dtype=torch.float16)
-    e1 = BackboneEngine(cfg, None, batch=B, dtype=torch.float16, share=e0)
+    e0 = BackboneEngine(cfg, P, batch=B, dtype=torch.float16, wgrad_stream=True)
+    e1 = BackboneEngine(cfg, None, batch=B, dtype=torch.float16, share=e0, wgrad_stream=True)
     assert e1.params is e0.params and e1.wc is e0.wc
     side = torch.cuda.Stream()
     main = torch.cuda.current_stream()
