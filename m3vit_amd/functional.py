@@ -327,16 +327,14 @@ class GroupedFFNFn(torch.autograd.Function):
         dscore = torch.empty_like(sc)
         ops.combine_bwd(g.contiguous().float(), y, sc, dy, dscore)
         dw2 = torch.empty(w2.shape, dtype=torch.float32, device=dev)
-        ops.wgrad_tn(dy, hid, dw2, M=R, c_row_idx=ros, group_offsets=offsets)
-        db2 = ops.colsum(dy, torch.empty(w2.shape[0], w2.shape[1], dtype=torch.float32, device=dev), M=R,
-                         c_row_idx=ros, group_offsets=offsets)
+        db2 = torch.empty(w2.shape[0], w2.shape[1], dtype=torch.float32, device=dev)
+        ops.wgrad_tn(dy, hid, dw2, M=R, c_row_idx=ros, group_offsets=offsets, db=db2)     # bias grad in the same pass
         dpre = torch.empty_like(pre)
         ops.gemm_nt(dy, _wcopy(w2, dt, transpose=True), dpre, M=R, gelu_grad_pre=pre, a_row_idx=ros, a_row_div=1,
                     group_offsets=offsets, tile_starts=tile_starts)
         dw1 = torch.empty(w1.shape, dtype=torch.float32, device=dev)
-        ops.wgrad_tn(dpre, x2, dw1, M=R, a_row_idx=ros, a_row_div=k, group_offsets=offsets)
-        db1 = ops.colsum(dpre, torch.empty(w1.shape[0], w1.shape[1], dtype=torch.float32, device=dev), M=R,
-                         group_offsets=offsets)
+        db1 = torch.empty(w1.shape[0], w1.shape[1], dtype=torch.float32, device=dev)
+        ops.wgrad_tn(dpre, x2, dw1, M=R, a_row_idx=ros, a_row_div=k, group_offsets=offsets, db=db1)
         dxe = torch.empty(R, D, dtype=dt, device=dev)
         ops.gemm_nt(dpre, _wcopy(w1, dt, transpose=True), dxe, M=R, c_row_idx=ros, group_offsets=offsets,
                     tile_starts=tile_starts)

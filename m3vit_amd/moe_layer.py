@@ -127,3 +127,38 @@ class FMoETransformerMLP(FMoE):
                                                self.world_size)
             out = CombineFn.apply(fwd.view(-1, self.top_k, fwd.shape[-1]), score.reshape(-1, self.top_k)).to(moe_inp.dtype)
         return out, clean, noisy, std, top_logits, gates
+
+
+class TokenFMoETransformerMLP(FMoE):
+    """Pre-routed MoE MLP (models/moe/token/custom_moe_layer.py:55-156): the Block owns the gate and hands the
+    layer `gate_top_k_idx [T,k]` and `gate_score [T,k]`; the layer only dispatches, runs the experts and
+    combines - on any subset of tokens (the token-MoE branch gathers the tokens selected by its compute mask
+    before calling it, token/vision_transformer_moe.py:730-812).  Same constructor, attributes and state_dict
+    keys as the reference; same kernels as FMoETransformerMLP behind it."""
+
+    def __init__(self, num_expert=32, d_model=1024, d_gate=1024, d_hidden=4096, activation=torch.nn.GELU(),
+                 expert_dp_comm="none", expert_rank=0, world_size=1, top_k=2, **kwargs):
+        # a dummy gate for the parent, as in the reference (:76-77)
+        super().__init__(num_expert=num_expert, d_model=d_model, gate=NaiveGate, world_size=world_size, top_k=top_k,
+                         **kwargs)
+        self.our_d_model = d_model
+        self.num_expert = num_expert
+        self.experts = _Expert(num_expert, d_model, d_hidden, activation, rank=expert_rank)
+        self.mark_parallel_comm(expert_dp_comm)
+
+    def forward(self, inp, gate_top_k_idx, gate_score):
+        original_shape = inp.shape
+        moe_inp = inp.reshape(-1, self.d_model)
+        return self.forward_moe(moe_inp, gate_top_k_idx, gate_score).reshape(original_shape)
+
+    def forward_moe(self, moe_inp, gate_top_k_idx, gate_score):
+        T = moe_inp.shape[0]
+        idx = gate_top_k_idx.reshape(T, self.top_k)
+        score = gate_score.reshape(T, self.top_k)
+        e = self.experts
+        if self.world_size == 1 and _is_plain_gelu(e.activation) and self.mask is None:
+            out = GroupedFFNFn.apply(moe_inp, idx.to(torch.int32), score, e.htoh4.weight, e.htoh4.bias,
+                                     e.h4toh.weight, e.h4toh.bias)
+            return out.to(moe_inp.dtype)
+        fwd = _fmoe_general_global_forward(moe_inp, idx, self.expert_fn, self.num_expert, self.world_size)
+        return CombineFn.apply(fwd.view(-1, self.top_k, fwd.shape[-1]), score).to(moe_inp.dtype)

@@ -61,3 +61,17 @@ def test_layer_mirror_signature_and_state_dict_keys():
     assert set(vit.state_dict().keys()) == set(R.init_backbone_params(cfg).keys())
     # utils/moe_utils.py:128-134,191-198 key filters keep working
     assert any("mlp.experts.htoh4" in k for k in vit.state_dict()) and any("mlp.experts.h4toh" in k for k in vit.state_dict())
+
+
+def test_pre_routed_layer_signature_and_keys():
+    """TokenFMoETransformerMLP (models/moe/token/custom_moe_layer.py:55-156): gate routing is done by the Block."""
+    from m3vit_amd.moe_layer import TokenFMoETransformerMLP
+    want = ["num_expert", "d_model", "d_gate", "d_hidden", "activation", "expert_dp_comm", "expert_rank", "world_size",
+            "top_k"]
+    assert list(inspect.signature(TokenFMoETransformerMLP.__init__).parameters)[1:1 + len(want)] == want     # :64-75
+    assert list(inspect.signature(TokenFMoETransformerMLP.forward).parameters)[1:] == ["inp", "gate_top_k_idx", "gate_score"]
+    layer = TokenFMoETransformerMLP(num_expert=4, d_model=32, d_hidden=48, top_k=2)
+    keys = {k for k in layer.state_dict().keys() if k.startswith("experts.")}
+    assert keys == {"experts.htoh4.weight", "experts.htoh4.bias", "experts.h4toh.weight", "experts.h4toh.bias"}
+    assert layer.our_d_model == 32 and layer.num_expert == 4 and layer.top_k == 2
+    assert all(getattr(p, "dp_comm") == "none" for p in layer.experts.parameters())

@@ -111,3 +111,45 @@ def test_task_conditioned_layer_matches_oracle():
     assert rel(out.reshape(T, D), o_ref) < 2e-5
     (o_ref * gout.double().cpu().reshape(T, D)).sum().backward()
     assert rel(x.grad, xr.grad) < 1e-4 and rel(tsf.grad, tr.grad) < 1e-4 and rel(layer.gate.w_gate.grad, wg.grad) < 1e-4
+
+
+@pytest.mark.parametrize("act", ["gelu", "relu"])
+def test_pre_routed_layer_on_a_token_subset(act):
+    """TokenFMoETransformerMLP.forward(inp, idx, score) (models/moe/token/custom_moe_layer.py:88-156) on the tokens a
+    compute mask kept: the caller's routing is used as given (indices need not be a top-k of anything, scores need
+    not be normalised), gradients reach the tokens, the scores and the expert parameters.  GELU experts run the
+    fused grouped-FFN path, any other activation the composable scatter / FMoELinear / gather path."""
+    _need_gpu()
+    from m3vit_amd.moe_layer import TokenFMoETransformerMLP
+    from oracle import ref_torch as R
+    torch.manual_seed(4)
+    E, D, H, k, T = 6, 64, 48, 3, 150
+    fn = torch.nn.GELU() if act == "gelu" else torch.nn.ReLU()
+    layer = TokenFMoETransformerMLP(num_expert=E, d_model=D, d_hidden=H, activation=fn, top_k=k).cuda()
+    for p_ in layer.experts.parameters():
+        torch.nn.init.normal_(p_, std=0.1)
+    full = torch.randn(2, 100, D, device="cuda")
+    keep = torch.randperm(200, device="cuda")[:T]                    # the compute-mask gather
+    x = full.reshape(-1, D)[keep].clone().requires_grad_()
+    idx = torch.stack([torch.randperm(E, device="cuda")[:k] for _ in range(T)])
+    idx[:, 0] = 2                                                    # a crowded expert; expert 5 may stay empty
+    idx[idx == 5] = 1
+    score = torch.rand(T, k, device="cuda").requires_grad_()
+    out = layer(x.view(1, T, D), idx, score).view(T, D)
+    w1, b1, w2, b2 = [p_.detach().double().cpu().requires_grad_() for p_ in
+                      (layer.experts.htoh4.weight, layer.experts.htoh4.bias, layer.experts.h4toh.weight, layer.experts.h4toh.bias)]
+    xr = x.detach().double().cpu().requires_grad_(); sr = score.detach().double().cpu().requires_grad_()
+    ref = torch.zeros(T, D, dtype=torch.float64)
+    f = R.gelu_erf if act == "gelu" else torch.relu
+    for j in range(k):
+        e = idx[:, j].cpu()
+        h = f(torch.einsum("td,thd->th", xr, w1[e]) + b1[e])
+        ref = ref + sr[:, j:j + 1] * (torch.einsum("th,tdh->td", h, w2[e]) + b2[e])
+    assert rel(out, ref) < 2e-5
+    g = torch.randn(T, D, device="cuda")
+    out.backward(g)
+    ref.backward(g.double().cpu())
+    assert rel(x.grad, xr.grad) < 1e-4 and rel(score.grad, sr.grad) < 1e-4
+    for p_, r_ in ((layer.experts.htoh4.weight, w1), (layer.experts.htoh4.bias, b1), (layer.experts.h4toh.weight, w2),
+                   (layer.experts.h4toh.bias, b2)):
+        assert rel(p_.grad, r_.grad) < 1e-4
