@@ -153,3 +153,65 @@ def test_pre_routed_layer_on_a_token_subset(act):
     for p_, r_ in ((layer.experts.htoh4.weight, w1), (layer.experts.htoh4.bias, b1), (layer.experts.h4toh.weight, w2),
                    (layer.experts.h4toh.bias, b2)):
         assert rel(p_.grad, r_.grad) < 1e-4
+
+
+def _cls_cfg(**kw):
+    from m3vit_amd.cls import MoEViTConfig
+    base = dict(img_size=32, embed_dim=64, depth=2, num_heads=2, num_classes=16, moe_experts=4, moe_top_k=2,
+                gate_dim=64, vmoe_noisy_std=0.0)
+    base.update(kw)
+    return MoEViTConfig(**base)
+
+
+def test_classification_wrapper_matches_oracle():
+    """MoEViTForImageNet (pretrain/models/moe_vit_cls.py:45-212): encoder -> LayerNorm(eps 1e-5) -> cls head;
+    logits, cv_loss and every gradient of CE + 0.01 cv against the oracle backbone + torch head."""
+    _need_gpu()
+    import torch.nn.functional as F
+    from m3vit_amd.cls import MoEViTForImageNet
+    from oracle import ref_torch as R
+    torch.manual_seed(6)
+    m = MoEViTForImageNet(_cls_cfg()).cuda().train()
+    assert set(k.split(".")[0] for k in m.state_dict()) == {"encoder", "norm", "head"}      # :48,95-96
+    cfg = R.BackboneCfg(img_size=(32, 32), embed_dim=64, depth=2, num_heads=2, mlp_ratio=4.0, moe_mlp_ratio=1.0,
+                        moe_experts=4, moe_top_k=2, gate_dim=64, multi_gate=False)
+    Pr = {k[len("encoder."):]: v.detach().double().cpu().requires_grad_() for k, v in m.state_dict().items()
+          if k.startswith("encoder.")}
+    hw = {k: v.detach().double().cpu().requires_grad_() for k, v in m.state_dict().items() if not k.startswith("encoder.")}
+    x = torch.randn(5, 3, 32, 32)
+    y = torch.randint(0, 16, (5,))
+    out = m(x.cuda())
+    tok, cv, _ = R.backbone_forward(Pr, cfg, x.double(), None)
+    cls = F.layer_norm(tok[:, 0], (64,), hw["norm.weight"], hw["norm.bias"], 1e-5)
+    logits = F.linear(cls, hw["head.weight"], hw["head.bias"])
+    assert out["logits"].shape == (5, 16) and rel(out["logits"], logits) < 2e-4
+    assert abs(float(out["cv_loss"].detach()) - float(cv.detach())) < 1e-3 * max(1.0, float(cv.detach()))
+    (F.cross_entropy(out["logits"], y.cuda()) + 0.01 * out["cv_loss"]).backward()
+    (F.cross_entropy(logits, y) + 0.01 * cv).backward()
+    ref = {**{"encoder." + k: v for k, v in Pr.items()}, **hw}
+    bad = [(n, rel(p.grad, ref[n].grad)) for n, p in m.named_parameters() if ref[n].grad is not None and rel(p.grad, ref[n].grad) > 2e-3]
+    assert not bad, bad
+
+
+def test_amp_training_step_fp16():
+    """The AMP iteration of pretrain/engine/train_one_epoch.py:35-61 (GradScaler: scale, unscale, clip, step, update)
+    on fp16 activations: the loss goes down, no step is skipped at a sane scale, an absurd scale is detected
+    (fp16 gradient overflow -> inf -> step skipped, scale halved) exactly as autocast training behaves."""
+    _need_gpu()
+    import torch.nn.functional as F
+    from m3vit_amd.cls import MoEViTForImageNet, amp_train_step
+    torch.manual_seed(7)
+    m = MoEViTForImageNet(_cls_cfg(vmoe_noisy_std=1.0), act_dtype=torch.float16).cuda().train()
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-3, weight_decay=0.05)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    x = torch.randn(16, 3, 32, 32, device="cuda")
+    y = torch.randint(0, 16, (16,), device="cuda")
+    crit = lambda samples, logits, targets: F.cross_entropy(logits, targets)          # noqa: E731
+    losses = [amp_train_step(m, crit, opt, scaler, x, y, moe_cv_weight=0.01, clip_grad=1.0)[0] for _ in range(12)]
+    assert all(l == l for l in losses) and losses[-1] < 0.7 * losses[0], losses
+    assert scaler.get_scale() == 1024.0                                               # nothing overflowed
+    before = [p.detach().clone() for p in m.parameters()]
+    big = torch.amp.GradScaler("cuda", init_scale=2.0 ** 40)
+    amp_train_step(m, crit, opt, big, x, y)
+    assert big.get_scale() == 2.0 ** 39                                               # inf found: halved ...
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, m.parameters()))    # ... and the step skipped
