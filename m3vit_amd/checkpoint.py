@@ -1,0 +1,182 @@
+"""Checkpoint formats of the expert-parallel path, so that state_dicts written by the
+reference's trainers load here and vice versa.  Pure host-side dict / file logic on CPU tensors.
+
+Formats (reference file:line):
+  * rank-shard directory `<dir>/{rank}.pth` of train_fastmoe.py (utils/moe_utils.py:164-175): rank 0 stores the
+    whole state (its E/W experts + every shared tensor), every other rank only its expert tensors
+    (`filter_state` :128-134).  Expert tensors are `...mlp.experts.htoh4.*` / `...mlp.experts.h4toh.*`, experts
+    along dim 0 (utils/helpers.py:645-662).
+  * single file with GLOBAL experts (all E along dim 0) plus `meta = {expert_format, moe_experts_global,
+    moe_experts_local, world_size, source}` (pretrain/utils/moe_checkpoint.py:81-112); `expert_format` may also
+    have to be inferred from shapes (:131-171).
+  * loading a global state on rank r of W keeps experts [r*E/W, (r+1)*E/W) (`read_specific_group_experts`,
+    utils/moe_utils.py:191-198).
+  * gate adaptation when the checkpoint and the model differ in gate layout (utils/common_config.py:47-68):
+    a single `mlp.gate.w_gate` is copied to every `mlp.gate.{t}.w_gate` of a multi-gate model; for task-one-hot /
+    task-conditioned gates zero rows are appended to w_gate for the extra gate-input dimensions.
+  * position-embedding resize for a different token grid (utils/common_config.py:71-92).
+"""
+from collections import OrderedDict
+import os
+import re
+from typing import Dict, Optional, Tuple
+
+import torch
+
+_EXPERT_MARKS = ("mlp.experts.htoh4", "mlp.experts.h4toh")
+_WRAPPERS = ("module.", "backbone.", "encoder.")
+
+
+def is_expert_key(key: str) -> bool:
+    return any(m in key for m in _EXPERT_MARKS)
+
+
+def strip_wrapper_prefix(key: str) -> str:
+    """drop DDP / wrapper prefixes ('module.', 'backbone.', 'encoder.') however they are stacked"""
+    changed = True
+    while changed:
+        changed = False
+        for w in _WRAPPERS:
+            if key.startswith(w):
+                key = key[len(w):]
+                changed = True
+    return key
+
+
+def first_expert_dim0(state: Dict[str, torch.Tensor]) -> Optional[int]:
+    for k, v in state.items():
+        if torch.is_tensor(v) and is_expert_key(k) and v.dim() >= 1:
+            return int(v.shape[0])
+    return None
+
+
+def unwrap(checkpoint, model_key: Optional[str] = None):
+    """(checkpoint dict, its model state_dict): under `model_key`, 'state_dict', 'model', or the dict itself"""
+    if not isinstance(checkpoint, dict):
+        raise ValueError(f"checkpoint must be a dict, got {type(checkpoint)}")
+    for k in ([model_key] if model_key else []) + ["state_dict", "model"]:
+        if k in checkpoint and isinstance(checkpoint[k], dict):
+            return checkpoint, checkpoint[k]
+    return checkpoint, checkpoint
+
+
+# ------------------------------------------------------------------ expert sharding
+def shard_experts(state, rank: int, num_local: int):
+    """global state -> what rank `rank` holds: experts [rank*num_local, (rank+1)*num_local), the rest as is"""
+    out = OrderedDict()
+    for k, v in state.items():
+        out[k] = v[rank * num_local:(rank + 1) * num_local] if (torch.is_tensor(v) and is_expert_key(k)) else v
+    return out
+
+
+def expert_only(state):
+    return OrderedDict((k, v) for k, v in state.items() if is_expert_key(k))
+
+
+def save_rank_shard(checkpoint: dict, dirname: str, rank: int, state_key: str = "state_dict") -> str:
+    """train_fastmoe-style shard: `<dirname>/<rank>.pth`; ranks > 0 keep only their expert tensors.  The caller
+    synchronises the ranks (rank 0 creates the directory first)."""
+    os.makedirs(dirname, exist_ok=True)
+    ck = dict(checkpoint)
+    if rank != 0:
+        ck[state_key] = expert_only(ck[state_key])
+    path = os.path.join(dirname, f"{rank}.pth")
+    torch.save(ck, path)
+    return path
+
+
+def merge_rank_shards(dirname: str) -> Tuple[dict, "OrderedDict[str, torch.Tensor]", int]:
+    """(rank-0 checkpoint, merged GLOBAL state, number of shards): expert tensors concatenated in rank order"""
+    ranks = sorted(int(m.group(1)) for m in (re.fullmatch(r"(\d+)\.pth", n) for n in os.listdir(dirname)) if m)
+    if not ranks or ranks[0] != 0:
+        raise ValueError(f"{dirname}: expected rank shards 0.pth, 1.pth, ...")
+    if ranks != list(range(len(ranks))):
+        raise ValueError(f"{dirname}: rank shards are not contiguous: {ranks}")
+    base, state0 = unwrap(torch.load(os.path.join(dirname, "0.pth"), map_location="cpu"))
+    merged = OrderedDict(state0)
+    for r in ranks[1:]:
+        _, st = unwrap(torch.load(os.path.join(dirname, f"{r}.pth"), map_location="cpu"))
+        for k, v in st.items():
+            if is_expert_key(k):
+                merged[k] = torch.cat([merged[k], v], dim=0) if k in merged else v
+            elif k not in merged:
+                merged[k] = v
+    return base, merged, len(ranks)
+
+
+def build_meta(state, source: str, world_size: int = 1, moe_experts_global: Optional[int] = None) -> dict:
+    d0 = first_expert_dim0(state)
+    glob = int(moe_experts_global if moe_experts_global is not None else (d0 or 0))
+    local = 0 if d0 is None else (glob // world_size if world_size > 0 and glob % world_size == 0 else glob)
+    return {"expert_format": "global", "moe_experts_global": glob, "moe_experts_local": int(local),
+            "world_size": int(world_size), "source": str(source)}
+
+
+def infer_expert_format(checkpoint, state, expected_global_experts: Optional[int] = None,
+                        expected_world_size: Optional[int] = None) -> str:
+    """'global' | 'local' | 'dense' | 'unknown'; an explicit meta.expert_format wins, then the expert dim 0 against
+    the expected expert count (or checkpoint['args'])."""
+    meta = checkpoint.get("meta", {}) if isinstance(checkpoint, dict) else {}
+    if isinstance(meta, dict) and meta.get("expert_format") in ("global", "local"):
+        return meta["expert_format"]
+    d0 = first_expert_dim0(state)
+    if d0 is None:
+        return "dense"
+    args = checkpoint.get("args", {}) if isinstance(checkpoint, dict) else {}
+    if isinstance(args, dict):
+        expected_global_experts = args.get("moe_experts", None) if expected_global_experts is None else expected_global_experts
+        expected_world_size = args.get("world_size", None) if expected_world_size is None else expected_world_size
+    if expected_global_experts is not None:
+        if d0 == int(expected_global_experts):
+            return "global"
+        if expected_world_size is not None and int(expected_world_size) > 1 and \
+                d0 * int(expected_world_size) == int(expected_global_experts):
+            return "local"
+    return "unknown"
+
+
+# -------------------------------------------------------------------- key adaptation
+def adapt_gates(state, multi_gate: bool, num_tasks: int, extra_gate_rows: int = 0):
+    """single-gate checkpoint -> the model's gate layout: `extra_gate_rows` zero rows appended to every
+    `mlp.gate.w_gate` (task one-hot: num_tasks rows; task-conditioned: gate_task_specific_dim rows), or one copy
+    per task under `mlp.gate.{t}.w_gate` for a multi-gate model."""
+    out = OrderedDict()
+    for k, v in state.items():
+        if k.endswith("mlp.gate.w_gate"):
+            if multi_gate:
+                for t in range(num_tasks):
+                    out[k[:-len("w_gate")] + f"{t}.w_gate"] = v.clone()
+                continue
+            if extra_gate_rows > 0:
+                v = torch.cat((v, torch.zeros(extra_gate_rows, v.shape[-1], dtype=v.dtype)), dim=0)
+        out[k] = v
+    return out
+
+
+def resize_pos_embed(pos_embed: torch.Tensor, grid_hw: Tuple[int, int], align_corners: bool = False) -> torch.Tensor:
+    """[1, 1 + h0*w0, C] -> [1, 1 + h*w, C]: cls row kept, the patch grid resized bilinearly"""
+    n, tokens, c = pos_embed.shape
+    side = int(round((tokens - 1) ** 0.5))
+    if side * side != tokens - 1:
+        raise ValueError(f"pos_embed with {tokens - 1} patch positions is not a square grid")
+    grid = pos_embed[:, 1:].transpose(1, 2).reshape(n, c, side, side)
+    grid = torch.nn.functional.interpolate(grid, size=tuple(grid_hw), mode="bilinear", align_corners=align_corners)
+    return torch.cat((pos_embed[:, :1], grid.reshape(n, c, -1).transpose(1, 2)), dim=1)
+
+
+def to_backbone_state(checkpoint, rank: int = 0, world_size: int = 1, expected_global_experts: Optional[int] = None,
+                      multi_gate: bool = False, num_tasks: int = 0, extra_gate_rows: int = 0,
+                      grid_hw: Optional[Tuple[int, int]] = None, model_key: Optional[str] = None):
+    """Everything above in the order the reference applies it (utils/common_config.py:31-100): unwrap, strip
+    prefixes, adapt gates, resize pos_embed, then keep this rank's experts when the state is global."""
+    ck, state = unwrap(checkpoint, model_key)
+    state = OrderedDict((strip_wrapper_prefix(k), v) for k, v in state.items() if torch.is_tensor(v))
+    fmt = infer_expert_format(ck, state, expected_global_experts, world_size)
+    state = adapt_gates(state, multi_gate, num_tasks, extra_gate_rows)
+    if grid_hw is not None and "pos_embed" in state and state["pos_embed"].shape[1] != 1 + grid_hw[0] * grid_hw[1]:
+        state["pos_embed"] = resize_pos_embed(state["pos_embed"], grid_hw)
+    if world_size > 1 and fmt in ("global", "unknown"):
+        d0 = first_expert_dim0(state)
+        if d0 is not None and d0 % world_size == 0 and (expected_global_experts in (None, d0)):
+            state = shard_experts(state, rank, d0 // world_size)
+    return state, fmt

@@ -212,6 +212,28 @@ class BackboneEngine:
     def zero_grad(self):
         self.flat_grads.zero_()
 
+    # ------------------------------------------------------------- checkpoints
+    def state_dict(self):
+        """This rank's parameters as CPU tensors under the reference's key names (experts: the LOCAL slice under
+        expert parallelism, as train_fastmoe's rank shards hold them - m3vit_amd/checkpoint.py)."""
+        from collections import OrderedDict
+        return OrderedDict((n, p.detach().cpu().clone()) for n, p in self.params.items())
+
+    def load_state(self, state, strict: bool = True):
+        """Copy a state_dict (local expert slices, e.g. from checkpoint.to_backbone_state) into the fp32 masters
+        and refresh the operand copies.  Returns the keys of `state` that were not used."""
+        missing = [n for n in self.params if n not in state]
+        if strict and missing:
+            raise KeyError(f"state_dict lacks {missing[:5]}{'...' if len(missing) > 5 else ''}")
+        for n, p in self.params.items():
+            if n in state:
+                src = state[n]
+                if tuple(src.shape) != tuple(p.shape):
+                    raise ValueError(f"{n}: checkpoint shape {tuple(src.shape)} != parameter shape {tuple(p.shape)}")
+                p.copy_(src.to(p.device, torch.float32))
+        self.prepare_weights()
+        return [k for k in state if k not in self.params]
+
     # ------------------------------------------------------------------ forward
     def _gate_weight(self, i, task_id):
         b = f"blocks.{i}.mlp.gate."

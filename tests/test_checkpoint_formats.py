@@ -1,0 +1,80 @@
+"""CPU: expert-parallel checkpoint formats (m3vit_amd/checkpoint.py) - rank-shard directories, global single files
+with meta, expert-format inference, gate / pos_embed adaptation (utils/moe_utils.py:128-198,
+pretrain/utils/moe_checkpoint.py:57-212, utils/common_config.py:31-100)."""
+import os
+
+import pytest
+import torch
+
+from m3vit_amd import checkpoint as C
+from m3vit_amd.config import BackboneConfig, init_params
+
+
+def _state(E=8, multi_gate=False):
+    cfg = BackboneConfig(img_size=(32, 32), embed_dim=32, depth=2, num_heads=2, moe_experts=E, moe_top_k=2,
+                         gate_dim=34 if multi_gate else 32, multi_gate=multi_gate)
+    return cfg, init_params(cfg, seed=3, zero_bias=False)
+
+
+def test_rank_shard_directory_round_trip(tmp_path):
+    cfg, P = _state()
+    W = 4
+    d = str(tmp_path / "checkpoint.pth.tar")
+    for r in range(W):                                        # what each rank of train_fastmoe would write
+        C.save_rank_shard({"state_dict": C.shard_experts(P, r, cfg.moe_experts // W), "epoch": 3}, d, r)
+    assert sorted(os.listdir(d)) == [f"{r}.pth" for r in range(W)]
+    r1 = torch.load(os.path.join(d, "1.pth"))["state_dict"]
+    assert r1 and all(C.is_expert_key(k) for k in r1)         # ranks > 0: expert tensors only
+    assert r1["blocks.1.mlp.experts.htoh4.weight"].shape[0] == 2
+    base, merged, n = C.merge_rank_shards(d)
+    assert n == W and base["epoch"] == 3 and set(merged) == set(P)
+    assert all(torch.equal(merged[k], P[k]) for k in P)
+    os.remove(os.path.join(d, "2.pth"))
+    with pytest.raises(ValueError):
+        C.merge_rank_shards(d)
+
+
+def test_expert_format_inference_and_meta():
+    cfg, P = _state()
+    loc = C.shard_experts(P, 1, 2)
+    assert C.first_expert_dim0(P) == 8 and C.first_expert_dim0(loc) == 2
+    assert C.infer_expert_format({"meta": {"expert_format": "local"}}, P) == "local"          # meta wins
+    assert C.infer_expert_format({}, P, expected_global_experts=8) == "global"
+    assert C.infer_expert_format({}, loc, expected_global_experts=8, expected_world_size=4) == "local"
+    assert C.infer_expert_format({"args": {"moe_experts": 8, "world_size": 4}}, loc) == "local"
+    assert C.infer_expert_format({}, loc, expected_global_experts=8) == "unknown"
+    dense = {k: v for k, v in P.items() if not C.is_expert_key(k)}
+    assert C.infer_expert_format({}, dense) == "dense"
+    meta = C.build_meta(P, source="train_fastmoe", world_size=4)
+    assert meta == {"expert_format": "global", "moe_experts_global": 8, "moe_experts_local": 2, "world_size": 4,
+                    "source": "train_fastmoe"}
+
+
+def test_gate_and_prefix_adaptation():
+    cfg, P = _state()
+    wrapped = {"module.backbone." + k: v for k, v in P.items()}
+    st, fmt = C.to_backbone_state({"state_dict": wrapped}, rank=1, world_size=2, expected_global_experts=8,
+                                  multi_gate=True, num_tasks=2)
+    assert fmt == "global" and "blocks.1.mlp.gate.0.w_gate" in st and "blocks.1.mlp.gate.w_gate" not in st
+    assert torch.equal(st["blocks.1.mlp.gate.1.w_gate"], P["blocks.1.mlp.gate.w_gate"])
+    assert torch.equal(st["blocks.1.mlp.experts.h4toh.bias"], P["blocks.1.mlp.experts.h4toh.bias"][4:8])   # rank 1 of 2
+    assert torch.equal(st["blocks.0.attn.qkv.weight"], P["blocks.0.attn.qkv.weight"])
+    tc = C.adapt_gates(P, multi_gate=False, num_tasks=5, extra_gate_rows=16)               # task-conditioned gate
+    w = tc["blocks.1.mlp.gate.w_gate"]
+    assert w.shape == (32 + 16, 8) and torch.equal(w[:32], P["blocks.1.mlp.gate.w_gate"]) and float(w[32:].abs().sum()) == 0
+    # a local state is left alone
+    st2, fmt2 = C.to_backbone_state({"meta": {"expert_format": "local"}, "model": C.shard_experts(P, 0, 4)}, rank=0,
+                                    world_size=2)
+    assert fmt2 == "local" and st2["blocks.1.mlp.experts.htoh4.weight"].shape[0] == 4
+
+
+def test_pos_embed_resize():
+    pe = torch.randn(1, 1 + 14 * 14, 8)
+    same = C.resize_pos_embed(pe, (14, 14))
+    assert torch.allclose(same, pe, atol=1e-6)
+    big = C.resize_pos_embed(pe, (30, 40))
+    assert big.shape == (1, 1 + 30 * 40, 8) and torch.equal(big[:, 0], pe[:, 0])
+    const = torch.ones(1, 1 + 4, 3) * 2.5
+    assert torch.allclose(C.resize_pos_embed(const, (7, 5)), torch.full((1, 36, 3), 2.5))
+    with pytest.raises(ValueError):
+        C.resize_pos_embed(torch.randn(1, 1 + 12, 4), (4, 4))
