@@ -11,9 +11,9 @@
 // HBM-bound by design: each token row is read once (coalesced 16-byte loads, staged
 // through LDS so that every LANE then owns one TOKEN).  A workgroup is 64 tokens x up to
 // 4 waves; wave w accumulates the logits of experts [w*EW, (w+1)*EW) for all 64 tokens
-// (w_gate rows are wave-uniform and come through the scalar cache), then wave 0 gathers
-// the E logits of each token into that lane's registers, so softmax and the top-(k+1)
-// selection need no cross-lane traffic at all.
+// (the w_gate rows of a step are staged in LDS too and read as wave-wide broadcasts), then
+// wave 0 gathers the E logits of each token into that lane's registers, so softmax and the
+// top-(k+1) selection need no cross-lane traffic at all.
 //
 // Arithmetic order is pinned (and mirrored by oracle/gate_route.c) so that expert
 // indices are bit-exact: sequential fmaf chain over d starting from the bias, selection
@@ -50,7 +50,9 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
   constexpr int CPR = GATE_ROWB / 16;              // 16-byte chunks per row per step
   constexpr int EPC = 16 / (int)sizeof(T);         // elements per chunk
   constexpr int NCH = GATE_TOK * CPR / NT;         // chunks per thread per step
+  constexpr int NWE = (DC * EPAD + NT - 1) / NT;   // w_gate slice elements per thread per step
   __shared__ float sx[2][GATE_TOK * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float sw[2][DC * EPAD];   // w_gate rows of the step, zero-padded to EPAD
   __shared__ float slog[NW > 1 ? GATE_TOK * (EPAD + 1) : 1];
 
   const int tid = threadIdx.x;
@@ -70,7 +72,15 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
 
   // staging: chunk q = tid + NT*i -> row q / CPR, c = q % CPR; rows past T and bytes past D read as zero
   u32x4 pre[NCH];
+  float prew[NWE];
   auto fetch = [&](int step) {
+#pragma unroll
+    for (int i = 0; i < NWE; ++i) {
+      const int q = tid + NT * i;                  // element (dd, e) of the slice
+      const int dd = q / EPAD, e = q - dd * EPAD;
+      const int d = step * DC + dd;
+      prew[i] = (q < DC * EPAD && d < D && e < E) ? p.w[(int64_t)d * E + e] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int q = tid + NT * i;
@@ -81,6 +91,11 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
     }
   };
   auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NWE; ++i) {
+      const int q = tid + NT * i;
+      if (q < DC * EPAD) sw[buf][q] = prew[i];
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int q = tid + NT * i;
@@ -107,31 +122,14 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
     const float *xs = &sx[buf][lane * LDS_STRIDE];
     const int d0 = step * DC;
     const int dn = (D - d0 < DC) ? (D - d0) : DC;
-    int dd = 0;
-    if constexpr (EXACT) {
-      // 4 rows of w_gate fetched by back-to-back scalar loads, then 4 x EW fmas (chain order kept)
-      for (; dd + 4 <= dn; dd += 4) {
-        float wv[4][EW];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float *wr = p.w + (int64_t)(d0 + dd + u) * EPAD + e0;
-#pragma unroll
-          for (int e = 0; e < EW; ++e) wv[u][e] = wr[e];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float xv = xs[dd + u];
-#pragma unroll
-          for (int e = 0; e < EW; ++e) acc[e] = __builtin_fmaf(xv, wv[u][e], acc[e]);
-        }
-      }
-    }
-    for (; dd < dn; ++dd) {
+    // the step's w_gate rows come from LDS (all lanes read the same address: broadcast), x from the
+    // lane's own LDS row; per logit the fma chain runs over d in order, as the oracle's
+    const float *ws = &sw[buf][e0];
+#pragma unroll 8
+    for (int dd = 0; dd < dn; ++dd) {
       const float xv = xs[dd];
-      const float *wr = p.w + (int64_t)(d0 + dd) * E + e0;   // wave-uniform -> scalar loads
 #pragma unroll
-      for (int e = 0; e < EW; ++e)
-        if (EXACT || e0 + e < E) acc[e] = __builtin_fmaf(xv, wr[e], acc[e]);
+      for (int e = 0; e < EW; ++e) acc[e] = __builtin_fmaf(xv, ws[dd * EPAD + e], acc[e]);
     }
   }
 
