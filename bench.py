@@ -169,30 +169,82 @@ def main():
             eng.forward(images, task)
             eng.backward(dtok, cv_weight=CV_WEIGHT)
 
-    def compute_step():
+    def run_tasks(fn_per_engine):
+        """fn(engine, task) for every task pass, each on its own stream (or serially), joined on the current stream"""
         if not par_tasks:
-            return serial_step()
-        eng.prepare_weights()
+            for task in range(ntasks):
+                fn_per_engine(eng, task)
+            return
         main = torch.cuda.current_stream()
         for st in streams:
             st.wait_stream(main)
         for task in range(ntasks):
             with torch.cuda.stream(main if task == 0 else streams[task - 1]):
-                e = engs[task]
-                e.zero_grad()
-                e.forward(images, task)
-                e.backward(dtok, cv_weight=CV_WEIGHT)
+                fn_per_engine(engs[task], task)
         for st in streams:
             main.wait_stream(st)
+
+    def fwd_bwd_upper(e, task):
+        e.zero_grad()
+        e.forward(images, task)
+        e.backward_begin(dtok, cv_weight=CV_WEIGHT)
+        e.backward_blocks(e.depth - 1, e.split_block)
+        e.backward_sync_wgrad()
+
+    def bwd_lower(e, task):
+        e.backward_blocks(e.split_block - 1, 0)
+        e.backward_end()
+
+    def add_slices(lo, hi):
         for e in engs[1:]:
-            ops.add_f32(flat, e.flat_grads)                 # flat += grads of the other passes
+            ops.add_f32(flat[lo:hi], e.flat_grads[lo:hi])      # flat += gradients of the other passes
+
+    # A step in two halves, so that under data parallelism the all-reduce of the upper blocks' gradients
+    # (flat[:n_upper], final after part A) runs on RCCL's stream while part B computes.  With serial task
+    # passes the halves cannot be separated (pass 1's forward needs pass 0's backward to be over): one part.
+    two_parts = par_tasks and world > 1
+    n_up = eng.n_upper if two_parts else 0
+
+    def part_a():
+        eng.prepare_weights()
+        if two_parts:
+            run_tasks(fwd_bwd_upper)
+            add_slices(0, n_up)
+        elif par_tasks:
+            run_tasks(lambda e, t: (e.zero_grad(), e.forward(images, t), e.backward(dtok, cv_weight=CV_WEIGHT)))
+            add_slices(0, flat.numel())
+        else:
+            serial_body()
+
+    def part_b():
+        run_tasks(bwd_lower)
+        add_slices(n_up, flat.numel())
+
+    def serial_body():
+        eng.zero_grad()
+        for task in range(ntasks):
+            eng.forward(images, task)
+            eng.backward(dtok, cv_weight=CV_WEIGHT)
+
+    def compute_step():
+        part_a()
+        if two_parts:
+            part_b()
 
     def sync_grads():
         eng.sync_grads(world=world)                         # RCCL over xGMI; mean over ranks (experts stay local under EP)
 
     def step():
-        compute_step()
-        sync_grads()
+        if not two_parts:
+            compute_step()
+            sync_grads()
+            return
+        part_a()
+        w1 = dist.all_reduce(flat[:n_up], async_op=True)     # overlaps part B
+        part_b()
+        w2 = dist.all_reduce(flat[n_up:], async_op=True)
+        w1.wait(); w2.wait()
+        flat.div_(world)
 
     def barrier():
         if world > 1:
@@ -221,12 +273,24 @@ def main():
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                compute_step()
+                part_a()
+            graph_b = None
+            if two_parts:
+                graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_b):
+                    part_b()
 
-            def run():                                      # collective stays outside the graph
+            def run():                                      # collectives stay outside the graphs
                 graph.replay()
-                sync_grads()
-            log("step captured into a hipGraph")
+                if graph_b is None:
+                    sync_grads()
+                    return
+                w1 = dist.all_reduce(flat[:n_up], async_op=True)
+                graph_b.replay()
+                w2 = dist.all_reduce(flat[n_up:], async_op=True)
+                w1.wait(); w2.wait()
+                flat.div_(world)
+            log("step captured into a hipGraph" + (" (two halves around the first all-reduce)" if two_parts else ""))
         except Exception as e:          # capture is an optimisation, never a requirement
             graph = None
             run = step

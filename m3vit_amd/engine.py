@@ -74,10 +74,17 @@ class BackboneEngine:
         if share is not None:
             self.params = share.params
         else:
-            names = [n for n in params if not is_exp(n)] + [n for n in params if is_exp(n)]     # experts last
+            if self.ep_world > 1:
+                names = [n for n in params if not is_exp(n)] + [n for n in params if is_exp(n)]     # experts last
+            else:
+                # replicated experts: everything is all-reduced, so order the flat buffer by WHEN a gradient is
+                # final in backward() - the parameters of the upper half of the blocks first (one contiguous
+                # slice that can be all-reduced while the lower half still runs), then the rest
+                names = [n for n in params if self._is_upper(n)] + [n for n in params if not self._is_upper(n)]
             self.params = {n: (params[n][lo:hi] if (is_exp(n) and self.ep_world > 1) else params[n])
                            .to(self.dev, torch.float32).contiguous() for n in names}
         self.n_dense = sum(p.numel() for n, p in self.params.items() if not is_exp(n))
+        self.n_upper = 0 if self.ep_world > 1 else sum(p.numel() for n, p in self.params.items() if self._is_upper(n))
         # one flat fp32 gradient buffer (views per parameter): zeroing is one memset and the data-parallel
         # sync is one RCCL all-reduce (xGMI is point-to-point: few large collectives)
         total = sum(p.numel() for p in self.params.values())
@@ -95,6 +102,16 @@ class BackboneEngine:
             self.wc, self.wt, self.wgate_c, self.cast_plan = share.wc, share.wt, share.wgate_c, None
         else:
             self.prepare_weights()
+
+    @property
+    def split_block(self):
+        """first block of the 'upper half' (its gradients occupy flat_grads[:n_upper])"""
+        return self.cfg.depth // 2
+
+    def _is_upper(self, name: str) -> bool:
+        if not name.startswith("blocks."):
+            return False
+        return int(name.split(".")[1]) >= self.cfg.depth // 2
 
     # ------------------------------------------------------------------ buffers
     def _e(self, *shape, dtype=None):
@@ -462,14 +479,26 @@ class BackboneEngine:
     def backward(self, d_tokens: torch.Tensor, cv_weight: float = 0.0):
         """Accumulates parameter gradients of  <tokens, d_tokens> + cv_weight * total_cv_loss
         into self.grads (beta = 1: the joint multi-task backward, train/train_utils.py:437-457)."""
-        p, gr = self.params, self.grads
-        B, T, D, R, k = self.B, self.T, self.D, self.R, self.k
+        self.backward_begin(d_tokens, cv_weight)
+        self.backward_blocks(self.depth - 1, 0)
+        return self.backward_end()
+
+    # The backward in three resumable pieces, so that a data-parallel trainer can all-reduce the gradients
+    # of the upper blocks (complete after backward_blocks(depth-1, s)) while the lower blocks still run.
+    def backward_begin(self, d_tokens: torch.Tensor, cv_weight: float = 0.0):
         self._ev_i = 0
         dx = self.s_dxa
-        dx.copy_(d_tokens.reshape(T, D))
-        other = self.s_dxb
-        have_dx_t = False
-        for i in reversed(range(self.depth)):
+        dx.copy_(d_tokens.reshape(self.T, self.D))
+        self._bw = dict(dx=dx, other=self.s_dxb, have_dx_t=False, cv_weight=cv_weight)
+
+    def backward_blocks(self, hi: int, lo: int):
+        """blocks hi, hi-1, ..., lo (inclusive); after it the gradients of every parameter of those blocks
+        are final on the wgrad stream (backward_sync_wgrad) / current stream."""
+        p, gr = self.params, self.grads
+        B, T, D, R, k = self.B, self.T, self.D, self.R, self.k
+        st = self._bw
+        dx, other, have_dx_t, cv_weight = st["dx"], st["other"], st["have_dx_t"], st["cv_weight"]
+        for i in range(hi, lo - 1, -1):
             a = self.act[i]
             b = f"blocks.{i}."
             if not self.is_moe[i]:
@@ -545,6 +574,16 @@ class BackboneEngine:
                               dx_act=self.s_dx_t if nxt_dense else None)
             dx, other = other, dx
             have_dx_t = nxt_dense
+        st.update(dx=dx, other=other, have_dx_t=have_dx_t)
+
+    def backward_sync_wgrad(self):
+        """make the current stream wait for the weight-gradient launches issued so far (no-op without a wgrad stream)"""
+        self._join_wgrad()
+
+    def backward_end(self):
+        p, gr = self.params, self.grads
+        B, D = self.B, self.D
+        dx = self._bw["dx"]
         # patch embedding / cls / pos
         ops.tokens_bwd(dx, B, self.np_, D, self.s_dpatch, gr["pos_embed"].view(self.N, D), gr["cls_token"].view(D), beta=1)
         gw = gr["patch_embed.proj.weight"].view(D, -1)

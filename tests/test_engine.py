@@ -236,3 +236,37 @@ def test_engine_state_round_trip_through_rank_shards(tmp_path):
     assert fresh.load_state(merged) == [] and n == 2
     got, _ = fresh.forward(img, 1)
     assert torch.equal(got, want)
+
+
+def test_split_backward_and_gradient_slices():
+    """backward_begin / backward_blocks(upper) / backward_blocks(lower) / backward_end == backward(), and after
+    the upper part flat_grads[:n_upper] (exactly the parameters of blocks >= depth/2) is already final - what a
+    data-parallel step all-reduces while the lower blocks run (bench.py, N > 1)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from m3vit_amd.engine import BackboneEngine
+    from oracle import ref_torch as R
+    cfg = R.BackboneCfg(img_size=(32, 32), embed_dim=64, depth=4, num_heads=2, mlp_ratio=4.0, moe_mlp_ratio=1.0,
+                        moe_experts=4, moe_top_k=2, gate_dim=66, multi_gate=True)
+    P = R.init_backbone_params(cfg, seed=13)
+    torch.manual_seed(3)
+    img = torch.randn(3, 3, 32, 32).cuda()
+    dtok = (torch.randn(3, cfg.num_tokens, 64) * 0.1).cuda()
+    for wg in (False, True):
+        a = BackboneEngine(cfg, P, batch=3, dtype=torch.float16, wgrad_stream=wg)
+        b = BackboneEngine(cfg, P, batch=3, dtype=torch.float16, wgrad_stream=wg)
+        upper = [n for n in a.params if n.startswith("blocks.") and int(n.split(".")[1]) >= 2]
+        assert list(a.params)[:len(upper)] == upper and a.split_block == 2
+        assert a.n_upper == sum(a.params[n].numel() for n in upper)
+        a.zero_grad(); a.forward(img, 1); a.backward(dtok, cv_weight=0.01)
+        b.zero_grad(); b.forward(img, 1)
+        b.backward_begin(dtok, cv_weight=0.01)
+        b.backward_blocks(3, 2)
+        b.backward_sync_wgrad()
+        torch.cuda.synchronize()
+        assert torch.equal(b.flat_grads[:b.n_upper], a.flat_grads[:a.n_upper])         # upper slice final already
+        assert float(b.flat_grads[b.n_upper:].abs().max()) == 0.0
+        b.backward_blocks(1, 0)
+        b.backward_end()
+        torch.cuda.synchronize()
+        assert torch.equal(b.flat_grads, a.flat_grads)
