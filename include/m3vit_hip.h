@@ -231,9 +231,10 @@ int m3_layernorm_bwd(const void *dy, int dy_dtype, const float *x, const float *
  * dh in {32, 64}. */
 int m3_attention_fwd(const void *qkv, int dtype, int B, int N, int heads, int dh,
                      void *o, float *lse, void *stream);
-/* dqkv [B*N, 3*C] from do [B*N, C].  One workgroup per (image, head) sweeps 256-key blocks;
- * for N > 256 dQ is accumulated across key blocks in dq_ws (fp32
- * [m3_attention_bwd_ws_elems(B,N,heads,dh)], contents need no initialisation; NULL when N <= 256). */
+/* dqkv [B*N, 3*C] from do [B*N, C].  One workgroup per (image, head, 256-key block); for N > 256 the
+ * key blocks' dQ contributions go to fp32 slabs in dq_ws ([ceil(N/256)][B*heads][N][dh] =
+ * m3_attention_bwd_ws_elems(B,N,heads,dh) floats, contents need no initialisation; NULL when N <= 256)
+ * and are summed in key-block order by a second launch. */
 int64_t m3_attention_bwd_ws_elems(int B, int N, int heads, int dh);
 int m3_attention_bwd(const void *qkv, const void *o, const void *d_o, const float *lse,
                      int dtype, int B, int N, int heads, int dh, void *dqkv, float *dq_ws,

@@ -196,7 +196,11 @@ __global__ __launch_bounds__(AT_THREADS, ((DH == 32 && sizeof(T) == 2) ? 2 : 1))
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / heads, h = bh - b * heads;   // heads of an image share lines
+  // one workgroup per (image, head, 256-key block); the key blocks of one (image, head) read the same Q / dO
+  // rows and neighbouring heads share lines: consecutive logical ids -> one XCD
+  const int nkb = (N + AB_KEYS - 1) / AB_KEYS;
+  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = wid / nkb, kbi = wid - bh * nkb, b = bh / heads, h = bh - b * heads;
   const int C = heads * DH;
   const int64_t ld = 3 * (int64_t)C;
   const T *qbase = qkv + (int64_t)b * N * ld + h * DH;
@@ -207,12 +211,13 @@ __global__ __launch_bounds__(AT_THREADS, ((DH == 32 && sizeof(T) == 2) ? 2 : 1))
   const float *lbase = lse + ((int64_t)b * heads + h) * N;
   const int kw0 = wave * 64;
 
-  // Sequences longer than AB_KEYS keys are processed one 256-key block at a time by the SAME workgroup:
-  // dK/dV of a key block are complete after its sweep; dQ is accumulated across key blocks in an fp32
-  // workspace that only this workgroup touches, by the same lane each time (no atomics, deterministic).
-  float *dqw = dq_ws ? dq_ws + ((int64_t)b * heads + h) * N * DH : nullptr;
-  for (int kb0 = 0; kb0 < N; kb0 += AB_KEYS) {
-  const bool first_kb = kb0 == 0, last_kb = kb0 + AB_KEYS >= N;
+  // Sequences longer than AB_KEYS keys: each 256-key block has its own workgroup.  dK/dV of a key block are
+  // complete after its sweep over the queries; its dQ contribution goes to an fp32 slab
+  // dq_ws[key block][image, head][N][DH], summed in key-block order by attention_dq_reduce_kernel (deterministic).
+  const int64_t nbh = gridDim.x / nkb;
+  float *dqw = dq_ws ? dq_ws + ((int64_t)kbi * nbh + bh) * N * DH : nullptr;
+  const int kb0 = kbi * AB_KEYS;
+  {
   __syncthreads();
   // ---- K^T image (all keys) + this wave's K / V fragments
   for (int q = tid; q < AB_KEYS * CPR; q += AT_THREADS) {
@@ -361,12 +366,8 @@ __global__ __launch_bounds__(AT_THREADS, ((DH == 32 && sizeof(T) == 2) ? 2 : 1))
       }
       const int qr = qs + qt * 16 + li;
       if (qr < N) {
-        if (dqw) {
-          float *w = dqw + (int64_t)qr * DH + dt * 16 + 4 * lg;
-          if (!first_kb) acc += *(const f32x4 *)w;
-          if (!last_kb) *(f32x4 *)w = acc;
-        }
-        if (last_kb) Vec4<T>::store(dqbase + (int64_t)qr * ld + dt * 16 + 4 * lg, acc);
+        if (dqw) *(f32x4 *)(dqw + (int64_t)qr * DH + dt * 16 + 4 * lg) = acc;
+        else Vec4<T>::store(dqbase + (int64_t)qr * ld + dt * 16 + 4 * lg, acc);
       }
     }
   }
@@ -383,7 +384,25 @@ __global__ __launch_bounds__(AT_THREADS, ((DH == 32 && sizeof(T) == 2) ? 2 : 1))
       }
     }
   }
-  }   // key blocks
+  }
+}
+
+// dq[b, n, h, :] = sum over key blocks of the fp32 slabs (key-block order), written into the q slot of dqkv
+template <typename T>
+__global__ void attention_dq_reduce_kernel(const float *__restrict__ ws, int nkb, int B, int N, int heads, int DH,
+                                           T *__restrict__ dqkv) {
+  const int64_t per = (int64_t)B * heads * N * DH;
+  const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= per) return;
+  f32x4 s = *(const f32x4 *)(ws + i4);
+  for (int kb = 1; kb < nkb; ++kb) s += *(const f32x4 *)(ws + kb * per + i4);
+  const int d = (int)(i4 % DH);
+  const int64_t row = i4 / DH;                  // (b*heads + h)*N + n
+  const int n = (int)(row % N);
+  const int64_t bh = row / N;
+  const int h = (int)(bh % heads);
+  const int64_t b = bh / heads;
+  Vec4<T>::store(dqkv + ((b * N + n) * 3) * (int64_t)(heads * DH) + h * DH + d, s);
 }
 
 template <typename T, int DH>
@@ -432,13 +451,19 @@ static int launch_attn_bwd(const void *qkv, const void *o, const void *d_o, cons
       (void)hipFuncSetAttribute((const void *)attention_bwd_kernel<T, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((attention_bwd_kernel<T, DH>), dim3(B * heads), dim3(AT_THREADS), lds, s, (const T *)qkv,
+  const int nkb = (N + AB_KEYS - 1) / AB_KEYS;
+  hipLaunchKernelGGL((attention_bwd_kernel<T, DH>), dim3(B * heads * nkb), dim3(AT_THREADS), lds, s, (const T *)qkv,
                      (const T *)o, (const T *)d_o, lse, B, N, heads, (T *)dqkv, dq_ws, scale);
-  return check_launch("m3_attention_bwd");
+  int rc = check_launch("m3_attention_bwd");
+  if (rc || nkb == 1) return rc;
+  const int64_t n4 = (int64_t)B * heads * N * DH / 4;
+  hipLaunchKernelGGL((attention_dq_reduce_kernel<T>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dq_ws, nkb, B, N,
+                     heads, DH, (T *)dqkv);
+  return check_launch("m3_attention_bwd(dq reduce)");
 }
 
 extern "C" int64_t m3_attention_bwd_ws_elems(int B, int N, int heads, int dh) {
-  return N > AB_KEYS ? (int64_t)B * heads * N * dh : 0;
+  return N > AB_KEYS ? (int64_t)((N + AB_KEYS - 1) / AB_KEYS) * B * heads * N * dh : 0;
 }
 
 extern "C" int m3_attention_bwd(const void *qkv, const void *o, const void *d_o, const float *lse, int dtype, int B,
