@@ -1,0 +1,103 @@
+"""GPU: BASELINE configs[1] at FULL size (ViT-S/16 + MoE E=16 k=4, 224x224, batch 128) through the C ABI.
+
+The float64 oracle cannot run 128 images in test time, so the full-size run is checked through properties that do
+not depend on the size:
+  * images of a batch only interact through the balance loss, so with its weight at 0 the tokens of image i and
+    the parameter gradients produced by a d_tokens that is non-zero on two images only are exactly what the oracle
+    computes for those two images alone (oracle at batch 2);
+  * routing metadata is a permutation (every routed row has exactly one slot) and the counts add up;
+  * the balance loss equals cv^2 of the column sums of the dense gates the kernel wrote;
+  * the backward is linear in d_tokens and the whole step is deterministic (bit-identical when repeated);
+  * fp16: the same two images through a batch-2 engine give bit-identical tokens (no dependence on where a row
+    sits in a tile / expert group)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = a.detach().double().cpu().flatten(); b = b.detach().double().cpu().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _setup(dtype):
+    from m3vit_amd.config import VIT_SMALL_MOE, BackboneConfig, init_params
+    from m3vit_amd.engine import BackboneEngine
+    cfg = BackboneConfig(**VIT_SMALL_MOE)
+    P = init_params(cfg, seed=1, zero_bias=False)
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(128, 3, 224, 224, generator=g)
+    eng = BackboneEngine(cfg, P, batch=128, dtype=dtype)
+    return cfg, P, img, eng
+
+
+def test_full_size_fp32_matches_oracle_on_two_images():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import ref_torch as R
+    cfg, P, img, eng = _setup(torch.float32)
+    pick = [3, 101]
+    task = 1
+    tok, cv = eng.forward(img.cuda(), task)
+    ocfg = R.BackboneCfg(**{k: getattr(cfg, k) for k in ("img_size", "embed_dim", "depth", "num_heads", "mlp_ratio",
+                                                           "moe_mlp_ratio", "moe_experts", "moe_top_k", "gate_dim",
+                                                           "multi_gate")})
+    Pr = {k: v.clone().double().requires_grad_() for k, v in P.items()}
+    tok_ref, _, aux = R.backbone_forward(Pr, ocfg, img[pick].double(), task)
+    assert rel(tok[pick], tok_ref) < 2e-4
+    N = cfg.num_tokens
+    for i in range(1, cfg.depth, 2):                        # routing of those images' tokens: identical indices
+        got = eng.act[i]["gate"]["idx"].view(128, N, -1)[pick].reshape(-1, cfg.moe_top_k).cpu()
+        assert torch.equal(got, aux[i]["idx"]), f"block {i}"
+        # routing metadata of the whole batch: a permutation, counts add up
+        r = eng.act[i]["route"]
+        Rr = 128 * N * cfg.moe_top_k
+        assert int(r.counts.sum()) == Rr and int(r.offsets[-1]) == Rr
+        assert torch.equal(torch.sort(r.row_of_slot).values.cpu(), torch.arange(Rr, dtype=torch.int32))
+        assert torch.equal(r.row_of_slot[r.pos.long()].cpu(), torch.arange(Rr, dtype=torch.int32))
+    # balance loss of the whole batch from the dense gates the kernel wrote
+    want_cv = 0.0
+    for i in range(1, cfg.depth, 2):
+        gts = eng.act[i]["gate"]["gates"].double().cpu()
+        want_cv += float(R.cv_squared(gts.sum(0)) + R.cv_squared(R.gates_to_load(gts).double()))
+    assert abs(float(cv) - want_cv) < 1e-4 * max(1.0, want_cv)
+    # backward: d_tokens on the two images only, balance weight 0 -> the oracle's batch-2 gradients
+    dsel = torch.randn(2, N, cfg.embed_dim, generator=torch.Generator().manual_seed(6)) * 0.1
+    dtok = torch.zeros(128, N, cfg.embed_dim)
+    dtok[pick] = dsel
+    eng.zero_grad()
+    eng.backward(dtok.cuda(), cv_weight=0.0)
+    (tok_ref * dsel.double()).sum().backward()
+    bad = []
+    for name, gr in eng.grads.items():
+        ref = Pr[name].grad
+        if ref is None:           # the other task's gate
+            assert float(gr.abs().max()) == 0.0, name
+            continue
+        e = rel(gr, ref)
+        if e > 1e-3:
+            bad.append((name, e))
+    assert not bad, bad
+    # linearity in d_tokens and determinism of the whole backward
+    g1 = eng.flat_grads.clone()
+    eng.zero_grad()
+    eng.backward((2.0 * dtok).cuda(), cv_weight=0.0)
+    assert rel(eng.flat_grads, 2.0 * g1) < 1e-5
+    eng.zero_grad()
+    eng.backward(dtok.cuda(), cv_weight=0.0)
+    assert torch.equal(eng.flat_grads, g1)
+
+
+def test_full_size_fp16_rows_do_not_depend_on_batch_position():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from m3vit_amd.engine import BackboneEngine
+    cfg, P, img, eng = _setup(torch.float16)
+    pick = [0, 77]
+    tok, cv = eng.forward(img.cuda(), 0)
+    small = BackboneEngine(cfg, P, batch=2, dtype=torch.float16)
+    tok2, _ = small.forward(img[pick].cuda(), 0)
+    assert torch.equal(tok[pick], tok2)
+    tok_again, cv_again = eng.forward(img.cuda(), 0)
+    assert torch.equal(tok_again, tok) and float(cv_again) == float(cv)
