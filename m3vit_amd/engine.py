@@ -378,22 +378,21 @@ class BackboneEngine:
         x_recv = self._a2a(x_send, plan.in_splits, plan.out_splits)
         ep = dict(plan=plan, n=n)
         ep["rg"] = torch.tensor(plan.regroup, dtype=torch.int32, device=dev)
-        ep["rgi"] = torch.tensor(plan.regroup_inv, dtype=torch.int32, device=dev)
         cnt = torch.tensor(plan.fwd_expert_count, dtype=torch.int32, device=dev)
         z = torch.zeros(1, dtype=torch.int32, device=dev)
         ep["offsets"] = torch.cat((z, torch.cumsum(cnt, 0).to(torch.int32))).contiguous()
         ep["tile_starts"] = torch.cat((z, torch.cumsum((cnt + 127) // 128, 0).to(torch.int32))).contiguous()
         y_recv = self._e(n, D)
+        ep["x_recv"] = x_recv
         if n > 0:
-            ep["x_exp"] = ops.gather_rows(x_recv, ep["rg"], self._e(n, D))
+            # the (src, expert) -> (expert, src) regroup is the A-row gather of FC1 and the C-row scatter of FC2:
+            # expert-major slot i reads x_recv[rg[i]] and writes y_recv[rg[i]] - no regrouped copies
             ep["hid_pre"], ep["hid"] = self._e(n, self.Hm), self._e(n, self.Hm)
-            ops.gemm_nt(ep["x_exp"], self.wc[b + "mlp.experts.htoh4"], ep["hid"], M=n,
+            ops.gemm_nt(x_recv, self.wc[b + "mlp.experts.htoh4"], ep["hid"], M=n,
                         bias=p[b + "mlp.experts.htoh4.bias"], act=M3_ACT_GELU, pre_out=ep["hid_pre"],
-                        group_offsets=ep["offsets"], tile_starts=ep["tile_starts"])
-            y_exp = self._e(n, D)
-            ops.gemm_nt(ep["hid"], self.wc[b + "mlp.experts.h4toh"], y_exp, M=n, bias=p[b + "mlp.experts.h4toh.bias"],
-                        group_offsets=ep["offsets"], tile_starts=ep["tile_starts"])
-            ops.gather_rows(y_exp, ep["rgi"], y_recv)
+                        a_row_idx=ep["rg"], a_row_div=1, group_offsets=ep["offsets"], tile_starts=ep["tile_starts"])
+            ops.gemm_nt(ep["hid"], self.wc[b + "mlp.experts.h4toh"], y_recv, M=n, bias=p[b + "mlp.experts.h4toh.bias"],
+                        c_row_idx=ep["rg"], group_offsets=ep["offsets"], tile_starts=ep["tile_starts"])
         y_send = self._a2a(y_recv, plan.out_splits, plan.in_splits)
         ops.gather_rows(y_send, r.pos, a["y"])                       # back to token-major [T*k, D]
         a["ep"] = ep
@@ -408,18 +407,16 @@ class BackboneEngine:
         dy_recv = self._a2a(dy_send, plan.in_splits, plan.out_splits)
         dx_recv = self._e(n, D)
         if n > 0:
-            dy_exp = ops.gather_rows(dy_recv, ep["rg"], self._e(n, D))
-            self._wgrad(dy_exp, ep["hid"], b + "mlp.experts.h4toh.weight", M=n, group_offsets=ep["offsets"],
-                        bias=b + "mlp.experts.h4toh.bias")
+            rg = ep["rg"]
+            self._wgrad(dy_recv, ep["hid"], b + "mlp.experts.h4toh.weight", M=n, c_row_idx=rg,
+                        group_offsets=ep["offsets"], bias=b + "mlp.experts.h4toh.bias")
             dhp = self._e(n, self.Hm)
-            ops.gemm_nt(dy_exp, self.wt[b + "mlp.experts.h4toh"], dhp, M=n, gelu_grad_pre=ep["hid_pre"],
+            ops.gemm_nt(dy_recv, self.wt[b + "mlp.experts.h4toh"], dhp, M=n, gelu_grad_pre=ep["hid_pre"],
+                        a_row_idx=rg, a_row_div=1, group_offsets=ep["offsets"], tile_starts=ep["tile_starts"])
+            self._wgrad(dhp, ep["x_recv"], b + "mlp.experts.htoh4.weight", M=n, a_row_idx=rg, a_row_div=1,
+                        group_offsets=ep["offsets"], bias=b + "mlp.experts.htoh4.bias")
+            ops.gemm_nt(dhp, self.wt[b + "mlp.experts.htoh4"], dx_recv, M=n, c_row_idx=rg,
                         group_offsets=ep["offsets"], tile_starts=ep["tile_starts"])
-            self._wgrad(dhp, ep["x_exp"], b + "mlp.experts.htoh4.weight", M=n, group_offsets=ep["offsets"],
-                        bias=b + "mlp.experts.htoh4.bias")
-            dx_exp = self._e(n, D)
-            ops.gemm_nt(dhp, self.wt[b + "mlp.experts.htoh4"], dx_exp, M=n, group_offsets=ep["offsets"],
-                        tile_starts=ep["tile_starts"])
-            ops.gather_rows(dx_exp, ep["rgi"], dx_recv)
         dx_send = self._a2a(dx_recv, plan.out_splits, plan.in_splits)
         ops.gather_rows(dx_send, r.pos, self.s_dxe)
 
