@@ -297,27 +297,38 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
 
 
 // ------------------------------------------------------------------------------------------------
-// LDS-DMA variant (fast path: K*elem a multiple of 64 bytes, staged epilogue shapes).
+// LDS-DMA variant (fp16 fast path: K*elem a multiple of 128 bytes, staged epilogue shapes).
 // Same tile / wave layout / epilogue as gemm_nt_kernel, but the operands go global -> LDS directly
-// (global_load_lds_dwordx4: one wave instruction fills 16 rows x 64 B = 1 KiB of the image, lane-linear
-// in LDS, with the XOR swizzle applied on the per-lane SOURCE address), in 64-byte K slices:
+// (global_load_lds_dwordx4: one wave instruction fills 8 rows x 128 B = 1 KiB of the image, lane-linear
+// in LDS, with the XOR swizzle applied on the per-lane SOURCE address):
 //   - no staging registers and no ds_write pass: <= 128 VGPRs and 32 KiB of LDS per workgroup, so FOUR
 //     workgroups share a CU instead of two - their load / MFMA / store phases interleave, which is what
 //     the K = 384 shapes of this model need (a tile spends more time in its prologue and in the
 //     bandwidth-bound store phase than in MFMAs);
-//   - double buffer, one barrier per K step: the DMA of step k+1 flies under the MFMAs of step k; the
-//     __syncthreads() at the end of the step is also the vmcnt(0) that retires it (hipcc drains LDS-DMA at
-//     a barrier) - exactly where this scheme needs the wait.
-constexpr int DMA_RB = 64;                 // bytes of a row slice
-constexpr int DMA_OPB = BM * DMA_RB;       // one operand image (8 KiB)
+//   - ONE buffer of full 128-byte row slices per operand.  (A first version double-buffered 64-byte slices: a
+//     64-byte slice uses half of each 128-byte line it touches and the other half is requested again one step
+//     later - with four workgroups per CU the line has usually left the 32 KiB L1 by then, so the L2 -> L1
+//     path (64 B/clk/CU) carried every operand byte twice and bounded the K loop.  Full-line slices halve
+//     that traffic: -15..-20 % per launch at K = 384, -30 % at K = 1536.)  The double buffer is given up for
+//     them: 32 KiB keeps four workgroups per CU, and it is the OTHER workgroups' MFMAs, not this one's,
+//     that cover a DMA's latency.  Two barriers per K step; __syncthreads() after the DMA is also the
+//     vmcnt(0) that retires it (hipcc drains LDS-DMA at a barrier).
+constexpr int DMA_RB = 128;                // bytes of a row slice = one cache line
+constexpr int DMA_LDS = 2 * BM * DMA_RB;   // A + B image: 32 KiB
 
-__device__ __forceinline__ int dma_swz(int row) { return (0 - (row >> 2)) & 3; }
+__device__ __forceinline__ int dma_swz(int row) { return (row >> 1) & 7; }
 
 template <typename T>
 __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const GemmDev p) {
   typedef Mma<T> MM;
   typedef typename MM::frag frag;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [buf][A|B][128 rows * 64 B] = 32 KiB
+  constexpr int RB = DMA_RB;
+  constexpr int OPB = BM * RB;               // one operand image (16 KiB)
+  constexpr int CPR = RB / 16;               // 16-byte chunks per row slice
+  constexpr int RPI = 64 / CPR;              // image rows filled by one wave instruction (1 KiB)
+  constexpr int NPC = BM / RPI / 4;          // DMA pieces per wave per operand per step (4)
+  constexpr int KCH = RB / 64;               // fragment groups per slice
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [A|B][128 rows * 128 B] = 32 KiB
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -341,13 +352,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const Gemm
   }
   const int n0 = nt * BN;
 
-  // DMA assignment: wave w, piece j (0,1) fills image rows (2w + j)*16 .. +15; lane l -> row + (l >> 2),
-  // LDS slot l & 3, which holds source chunk (l & 3) ^ swz(row).  Rows past the end are clamped (never stored).
-  const char *a_src[2], *b_src[2];
+  // DMA assignment: wave w, piece j fills image rows (NPC*w + j)*RPI .. +RPI-1; lane l -> row + l / CPR,
+  // LDS slot l % CPR, which holds source chunk (l % CPR) ^ swz(row).  Rows past the end are clamped (never stored).
+  const char *a_src[NPC], *b_src[NPC];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = (2 * wave + j) * 16 + (lane >> 2);
-    const int c = (lane & 3) ^ dma_swz(row);
+  for (int j = 0; j < NPC; ++j) {
+    const int row = (NPC * wave + j) * RPI + lane / CPR;
+    const int c = (lane % CPR) ^ dma_swz(row);
     int64_t m = m_begin + row;
     if (m >= m_end) m = m_end - 1;
     int64_t src = m;
@@ -357,21 +368,25 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const Gemm
     if (n >= p.N) n = p.N - 1;
     b_src[j] = p.B + (int64_t)g * p.b_group_b + (int64_t)n * p.ldb_b + c * 16;
   }
-  const int nk = (p.K * (int)sizeof(T)) / DMA_RB;
+  const int nk = (p.K * (int)sizeof(T)) / RB;
 
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
-  auto dma = [&](int ks, int buf) {
-    char *dst = smem + buf * (2 * DMA_OPB) + (2 * wave) * 1024;
+  auto dma = [&](int ks) {
+    char *dst = smem + (NPC * wave) * 1024;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      __builtin_amdgcn_global_load_lds((glb_void *)(a_src[j] + ks * DMA_RB), (lds_void *)(dst + j * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void *)(b_src[j] + ks * DMA_RB), (lds_void *)(dst + j * 1024 + DMA_OPB), 16, 0, 0);
+    for (int j = 0; j < NPC; ++j) {
+      __builtin_amdgcn_global_load_lds((glb_void *)(a_src[j] + ks * RB), (lds_void *)(dst + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void *)(b_src[j] + ks * RB), (lds_void *)(dst + j * 1024 + OPB), 16, 0, 0);
     }
   };
 
-  const int rdA = (wr * 64 + li) * DMA_RB + ((lg ^ dma_swz(li)) << 4);               // + i*16*64
-  const int rdB = (wc * 64 + li) * DMA_RB + ((lg ^ dma_swz(li)) << 4) + DMA_OPB;
+  int rdA[KCH], rdB[KCH];
+#pragma unroll
+  for (int kc = 0; kc < KCH; ++kc) {
+    rdA[kc] = (wr * 64 + li) * RB + (((kc * 4 + lg) ^ dma_swz(li)) << 4);               // + i*16*RB
+    rdB[kc] = (wc * 64 + li) * RB + (((kc * 4 + lg) ^ dma_swz(li)) << 4) + OPB;
+  }
 
   f32x4 acc[4][4];   // [ni][mi]
 #pragma unroll
@@ -379,23 +394,28 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const Gemm
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  dma(0, 0);
-  __syncthreads();
-  for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < nk) dma(ks + 1, buf ^ 1);
-    const char *sb = smem + buf * (2 * DMA_OPB);
-    frag fa[4], fb[4];
+  auto compute = [&]() {
+    const char *sb = smem;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fa[i] = *(const frag *)(sb + rdA + i * 16 * DMA_RB);
-      fb[i] = *(const frag *)(sb + rdB + i * 16 * DMA_RB);
+    for (int kc = 0; kc < KCH; ++kc) {
+      frag fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = *(const frag *)(sb + rdA[kc] + i * 16 * RB);
+        fb[i] = *(const frag *)(sb + rdB[kc] + i * 16 * RB);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = MM::mma(fb[ni], fa[mi], acc[ni][mi]);
     }
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = MM::mma(fb[ni], fa[mi], acc[ni][mi]);
-    __syncthreads();
+  };
+
+  for (int ks = 0; ks < nk; ++ks) {
+    dma(ks);
+    __syncthreads();          // vmcnt(0) + barrier: the slice has landed
+    compute();
+    __syncthreads();          // everyone has read it
   }
 
   // ---- epilogue: the fp32 tile goes through the (now free) 32 KiB in two 64-row halves (half h = waves wr == h),
@@ -506,19 +526,14 @@ extern "C" int m3_gemm_nt(const m3_gemm_args *a, void *stream) {
   // 32-bit per-lane byte offsets: A rows (gathered source rows must be < M) and one B group must fit 4 GiB
   M3_REQUIRE((a->M + 1) * a->lda * es < ((int64_t)1 << 32) && (int64_t)a->N * a->ldb * es < ((int64_t)1 << 32),
              "m3_gemm_nt: operand panel exceeds the 4 GiB reach of the 32-bit lane offsets");
-  // variant: M3_GEMM_DMA=1/0 forces the LDS-DMA / register-staged kernel (diagnostics); default by shape
+  // variant: fp16 -> LDS-DMA kernel, fp32 (MFMA-bound, measured 2 % slower there) and odd shapes ->
+  // register-staged kernel; M3_GEMM_DMA=1/0 forces one or the other (diagnostics)
   static int dma_mode = -1;
   if (dma_mode < 0) { const char *e = getenv("M3_GEMM_DMA"); dma_mode = e ? (atoi(e) ? 1 : 0) : 2; }
   const bool dma_ok = d.vec8 && (a->K * es) % DMA_RB == 0;
-  // default: fp16 with a short contraction (K*elem <= M3_GEMM_DMA_MAXKB, 1 KiB); long-K shapes amortise the
-  // register-staged kernel's longer K step and are a little faster there (measured: profiles/README.md)
-  static int dma_maxkb = -1;
-  if (dma_maxkb < 0) { const char *e = getenv("M3_GEMM_DMA_MAXKB"); dma_maxkb = e ? atoi(e) : 1024; }
-  const bool use_dma = dma_ok && (dma_mode == 1 || (dma_mode == 2 && a->dtype == M3_F16 && a->K * es <= dma_maxkb));
-  if (use_dma) {
-    const size_t lds_dma = 4 * DMA_OPB;   // 32 KiB
-    if (a->dtype == M3_F16) hipLaunchKernelGGL((gemm_nt_dma_kernel<half_t>), grid, block, lds_dma, s, d);
-    else hipLaunchKernelGGL((gemm_nt_dma_kernel<float>), grid, block, lds_dma, s, d);
+  if (dma_ok && (dma_mode == 1 || (dma_mode == 2 && a->dtype == M3_F16))) {
+    if (a->dtype == M3_F16) hipLaunchKernelGGL((gemm_nt_dma_kernel<half_t>), grid, block, DMA_LDS, s, d);
+    else hipLaunchKernelGGL((gemm_nt_dma_kernel<float>), grid, block, DMA_LDS, s, d);
     return check_launch("m3_gemm_nt");
   }
   const bool ktail = (a->K * es) % ROWB != 0;
