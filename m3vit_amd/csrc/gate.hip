@@ -26,7 +26,7 @@ namespace m3 {
 
 constexpr int GATE_TOK = 64;       // tokens per workgroup
 constexpr int GATE_DW_TOK = 128;   // tokens per workgroup in the dW kernel
-constexpr int GATE_ROWB = 64;      // bytes of a token row staged per step
+constexpr int GATE_ROWB = 128;     // bytes of a token row staged per step (one cache line)
 
 __device__ __forceinline__ float normal_cdf(float z) { return 0.5f * erfcf(-z * 0.70710678118654752f); }
 __device__ __forceinline__ float normal_pdf(float z) { return 0.3989422804014327f * expf(-0.5f * z * z); }
