@@ -96,20 +96,22 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_res_kernel(const 
     if (qt >= nkt) break;
     const int qrow = qt * 16 + li;
     const f16x8 qf = qfs[i];
-    // S^T tiles: st[kt][r] = S[q = li][key = 16*kt + 4*lg + r]
+    // S^T tiles: st[kt][r] = S[q = li][key = 16*kt + 4*lg + r]; only the last key tile can hold keys >= N
     f32x4 st[AR_MAXN / 16];
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < AR_MAXN / 16; ++kt) {
-      st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (kt < nkt) {
-        st[kt] = mma16(row_frag(sK, kt * 16, li, lg), qf, st[kt]);
+        f32x4 sv = mma16(row_frag(sK, kt * 16, li, lg), qf, zero4);
+        if (kt == nkt - 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float s = (kt * 16 + 4 * lg + r < N) ? st[kt][r] : -INFINITY;
-          st[kt][r] = s;
-          mx = fmaxf(mx, s);
+          for (int r = 0; r < 4; ++r) sv[r] = (kt * 16 + 4 * lg + r < N) ? sv[r] : -INFINITY;
         }
+        mx = fmaxf(fmaxf(mx, fmaxf(sv[0], sv[1])), fmaxf(sv[2], sv[3]));
+        st[kt] = sv;
+      } else {
+        st[kt] = zero4;
       }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -230,6 +232,7 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_bwd_res_kernel(const 
     char *dsb = sdS + (st & 1) * NP * 64;
     // ---- S, dP -> P, dS (unscaled) for this wave's key tiles;  D[q = 4*lg + r][key = li]
     f32x4 pt[2][4], dst[2][4];
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       const f16x8 qfr = row_frag(sQ, qs + qt * 16, li, lg), dof = row_frag(sdO, qs + qt * 16, li, lg);
@@ -238,18 +241,20 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_bwd_res_kernel(const 
       for (int r = 0; r < 4; ++r) { l2[r] = sLse[qs + qt * 16 + 4 * lg + r]; dl[r] = sDelta[qs + qt * 16 + 4 * lg + r]; }
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
-        pt[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dst[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (kt * 4 + wave < nkt) {
-          const f32x4 s = mma16(qfr, kf[kt], f32x4{0.f, 0.f, 0.f, 0.f});
-          const f32x4 dp = mma16(dof, vf[kt], f32x4{0.f, 0.f, 0.f, 0.f});
-          const bool kok = (kt * 4 + wave) * 16 + li < N;
+        const int tix = kt * 4 + wave;
+        if (tix < nkt) {
+          const f32x4 s = mma16(qfr, kf[kt], zero4);
+          const f32x4 dp = mma16(dof, vf[kt], zero4);
+          f32x4 pv;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = kok ? __builtin_amdgcn_exp2f(s[r] * c1 - l2[r]) : 0.f;
-            pt[qt][kt][r] = p;
-            dst[qt][kt][r] = p * (dp[r] - dl[r]);
-          }
+          for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r] * c1 - l2[r]);
+          if (tix == nkt - 1 && tix * 16 + li >= N) pv = zero4;          // keys past N live in the last tile only
+          pt[qt][kt] = pv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[qt][kt][r] = pv[r] * (dp[r] - dl[r]);
+        } else {
+          pt[qt][kt] = zero4;
+          dst[qt][kt] = zero4;
         }
       }
     }
