@@ -215,3 +215,50 @@ def test_amp_training_step_fp16():
     amp_train_step(m, crit, opt, big, x, y)
     assert big.get_scale() == 2.0 ** 39                                               # inf found: halved ...
     assert all(torch.equal(a, b.detach()) for a, b in zip(before, m.parameters()))    # ... and the step skipped
+
+
+def test_decoder_head_and_multitask_wrapper():
+    """VisionTransformerUpHead / MultiTaskModel (models/heads/vit_up_head.py:73-224, models/models.py:215-342): key
+    names, the cls-token quirk, output sizes, and the values against the same stack written with plain torch ops on
+    the oracle backbone's tokens; multi-gate = one backbone pass per task, cv losses added."""
+    _need_gpu()
+    import torch.nn.functional as F
+    from m3vit_amd.heads import MultiTaskModel, VisionTransformerUpHead
+    from m3vit_amd.vit import VisionTransformerMoE
+    from oracle import ref_torch as R
+    torch.manual_seed(8)
+    kw = dict(img_size=(32, 48), embed_dim=64, depth=2, num_heads=2, moe_experts=4, moe_top_k=2, gate_dim=66, multi_gate=True)
+    bb = VisionTransformerMoE(mlp_ratio=4.0, moe_mlp_ratio=1, vmoe_noisy_std=0, **kw)
+    tasks = ["semseg", "depth"]
+    heads = torch.nn.ModuleDict({"semseg": VisionTransformerUpHead((32, 48), 16, 64, num_classes=5),
+                                 "depth": VisionTransformerUpHead((32, 48), 16, 64, num_classes=1, num_conv=2, num_upsampe_layer=2)})
+    m = MultiTaskModel(bb, heads, tasks, multi_gate=True).cuda().eval()
+    assert {"norm.weight", "conv_0.weight", "conv_4.bias", "syncbn_fc_3.running_var"} <= set(heads["semseg"].state_dict())
+    x = torch.randn(2, 3, 32, 48)
+    out, cv = m(x.cuda())
+    assert out["semseg"].shape == (2, 5, 32, 48) and out["depth"].shape == (2, 1, 32, 48)
+    # reference computation: oracle backbone tokens (float64) -> the same head stack in float64 torch
+    cfg = R.BackboneCfg(mlp_ratio=4.0, moe_mlp_ratio=1.0, **kw)
+    P = {k: v.detach().double().cpu() for k, v in bb.state_dict().items()}
+    cv_ref = 0.0
+    for t_i, t in enumerate(tasks):
+        tok, c, _ = R.backbone_forward(P, cfg, x.double(), t_i, training=False)
+        h = heads[t].double().cpu()
+        z = F.layer_norm(tok[:, 1:], (64,), h.norm.weight, h.norm.bias, 1e-6).transpose(1, 2).reshape(2, 64, 2, 3)
+        if t == "semseg":
+            for i in range(4):
+                z = F.relu(getattr(h, f"syncbn_fc_{i}")(getattr(h, f"conv_{i}")(z)))
+                if i < 3:
+                    z = F.interpolate(z, scale_factor=2, mode="bilinear", align_corners=False)
+            z = F.interpolate(h.conv_4(z), scale_factor=2, mode="bilinear", align_corners=False)
+        else:
+            z = F.relu(h.syncbn_fc_0(h.conv_0(z)))
+            z = F.interpolate(z, size=z.shape[-1] * 4, mode="bilinear", align_corners=False)
+            z = F.interpolate(h.conv_1(z), size=(32, 48), mode="bilinear", align_corners=False)
+        z = F.interpolate(z, (32, 48), mode="bilinear")
+        assert rel(out[t], z) < 2e-4, t
+        heads[t].float().cuda()
+    # single-task call on a shared (non multi-gate) wrapper returns only that head
+    one = MultiTaskModel(bb, heads, tasks, multi_gate=False).cuda().eval()
+    o1, _ = one(x.cuda(), single_task="depth", task_id=1)
+    assert list(o1) == ["depth"] and torch.allclose(o1["depth"], out["depth"], atol=1e-5)
