@@ -330,20 +330,6 @@ __global__ __launch_bounds__(1024) void balance_kernel(const BalanceDev p) {
   }
 }
 
-__global__ void gate_reduce_kernel(const float *part_imp, const int32_t *part_load, int nblk, int E, float *imp,
-                                   int64_t *load) {
-  const int e = threadIdx.x;
-  if (e >= E) return;
-  float s = 0.f;
-  int64_t c = 0;
-  for (int b = 0; b < nblk; ++b) {
-    s += part_imp[(int64_t)b * E + e];
-    c += part_load[(int64_t)b * E + e];
-  }
-  imp[e] = s;
-  load[e] = c;
-}
-
 // d_logits through scatter + softmax (+ the Normal-CDF load term): thread per token
 struct GateBwdDev {
   const float *noisy; const float *clean; const float *top_logits;

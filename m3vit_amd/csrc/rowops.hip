@@ -169,15 +169,6 @@ __global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(const T *__r
   }
 }
 
-__global__ void ln_param_reduce_kernel(const float *part, int nblk, int D, float *dgamma, float *dbeta, int beta) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= D) return;
-  float a = beta ? dgamma[d] : 0.f, b = beta ? dbeta[d] : 0.f;
-  for (int i = 0; i < nblk; ++i) { a += part[(int64_t)i * D + d]; b += part[((int64_t)nblk + i) * D + d]; }
-  dgamma[d] = a;
-  dbeta[d] = b;
-}
-
 // ------------------------------------------------------------------ cast helpers
 template <typename T>
 __global__ void cast_matrix_kernel(const float *__restrict__ src, int rows, int cols, int transpose, T *__restrict__ dst) {
