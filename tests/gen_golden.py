@@ -15,6 +15,8 @@ Fixtures written to tests/golden/*.npz (small, a few hundred KB total):
   g3_route                   idx -> expert_size, batch_index, index_sorted_experts
   g4_grouped_linear          ragged counts incl. an empty expert: fwd + dX/dW/db
   g5_moe_layer               whole layer out + dX/dW1/db1/dW2/db2/dw_gate
+  g6_balance_noisy           x, w_gate, noise, std -> the gate's own balance loss in training mode
+                             (cv^2(importance) + cv^2(_prob_in_top_k load)) and d loss / d(x, w_gate)
 Inputs are resampled until the top-(k+2) probabilities of every token are
 separated by > 1e-4 relative, so torch.topk's unspecified tie order cannot matter.
 """
@@ -103,6 +105,28 @@ def g2b(T=48, D=384, E=16, k=4, std=1.0):
     raise RuntimeError("no tie-free seed")
 
 
+def g6(T=96, D=64, E=8, k=2, std=1.0):
+    """the reference gate's set_loss() value with noise (Normal-CDF load) and its gradients"""
+    import contextlib, io
+    for seed in range(500, 600):
+        gate = make_gate(D, E, k, seed, noise_std=std).train()
+        x = torch.randn(T, D, requires_grad=True)
+        torch.manual_seed(seed + 1000)
+        noise = torch.randn(T, E)
+        torch.manual_seed(seed + 1000)
+        with contextlib.redirect_stdout(io.StringIO()):
+            idx, score = gate(x)
+        probs = gate.get_activation()
+        if not tie_free(probs.detach(), k):
+            continue
+        loss = gate.get_loss()
+        dx, dw = torch.autograd.grad(loss, [x, gate.w_gate])
+        save("g6_balance_noisy", x=x, w_gate=gate.w_gate, noise=noise, std=np.float32(std), k=k, idx=idx, score=score,
+             loss=loss, dx=dx, dw_gate=dw)
+        return
+    raise RuntimeError("no tie-free seed")
+
+
 def g3():
     d = np.load(os.path.join(OUT, "g1_gate_e16.npz"))
     idx = torch.tensor(d["idx"])
@@ -162,6 +186,7 @@ if __name__ == "__main__":
     g1(64, "g1_gate_e64")
     g2()
     g2b()
+    g6()
     g3()
     g4()
     g5()

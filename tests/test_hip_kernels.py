@@ -333,6 +333,25 @@ def test_noisy_gate_normal_cdf_load_fwd_bwd(ops, E, k, T, std):
     assert rel(dl, clean.grad) < 2e-4
 
 
+def test_noisy_balance_loss_against_reference_golden(ops):
+    """g6 through the C ABI: m3_gate_fwd (+ Normal-CDF load partials) -> m3_balance_loss -> m3_gate_bwd_logits ->
+    m3_gate_bwd_params reproduce the reference gate's own loss and its gradients w.r.t. x and w_gate."""
+    g = _golden("g6_balance_noisy")
+    k = int(g["k"])
+    x = torch.tensor(g["x"]).to(dev()); w = torch.tensor(g["w_gate"]).to(dev()); noise = torch.tensor(g["noise"]).to(dev())
+    E = w.shape[1]
+    out = ops.gate_fwd(x, w, k, noise=noise, noise_std=float(g["std"]) / E)
+    assert np.array_equal(out["idx"].cpu().numpy(), g["idx"])
+    assert abs(float(out["cv_loss"]) - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
+    dl = ops.gate_bwd_logits(out["noisy"], out["idx"], None, out["d_importance"], k, balance_scale=1.0,
+                             idx_next=out["idx_next"], d_load_prob=out["d_load_prob"], clean=out["clean"],
+                             top_logits=out["top_logits"], noise_std=out["noise_std"])
+    dw = torch.empty_like(w)
+    dx = torch.empty_like(x)
+    ops.gate_bwd_params(x, w, dl, d_w_gate=dw, dx=dx)
+    assert rel(dx, torch.tensor(g["dx"])) < 5e-4 and rel(dw, torch.tensor(g["dw_gate"])) < 5e-4
+
+
 # ----------------------------------------------------------------- combine / layernorm
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_combine_fwd_bwd(ops, dtype):

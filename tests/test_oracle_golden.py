@@ -60,6 +60,25 @@ def test_gate_with_caller_noise(golden_dir):
     np.testing.assert_allclose(c["score"], g["score"], rtol=2e-5, atol=1e-7)
 
 
+def test_noisy_balance_loss_matches_reference_gate(golden_dir):
+    """g6: the reference gate's OWN training-mode loss (models/moe/gates.py:405-452: importance, Normal-CDF load via
+    _prob_in_top_k :333-376, cv_squared :378-392) and its gradients - pins the oracle's prob_in_top_k / cv_squared /
+    gates_to_load chain that the HIP balance and gate-backward kernels are tested against."""
+    g = load(golden_dir, "g6_balance_noisy")
+    k = int(g["k"])
+    x = torch.tensor(g["x"]).double().requires_grad_()
+    w = torch.tensor(g["w_gate"]).double().requires_grad_()
+    noise = torch.tensor(g["noise"]).double()
+    (idx, score), clean, noisy, std, top_logits, gates = R.gate_vmoe(x, w, k, noise=noise, noise_std=float(g["std"]), training=True)
+    assert np.array_equal(idx.numpy(), g["idx"])
+    load_ = R.prob_in_top_k(clean, noisy, std, top_logits, k).sum(0)
+    loss = R.cv_squared(gates.sum(0)) + R.cv_squared(load_)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * max(1.0, abs(float(g["loss"])))
+    loss.backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(w.grad.numpy(), g["dw_gate"], rtol=2e-4, atol=1e-7)
+
+
 def test_route_matches_compute_gating(golden_dir):
     g = load(golden_dir, "g3_route")
     k, E = int(g["k"]), int(g["E"])
