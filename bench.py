@@ -27,6 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK = {"f16": 2500.0, "f32": 157.3}      # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+PEAK_HBM = 8000.0                          # GB/s, MI355X_MICROARCH.md
 CV_WEIGHT = 0.01                           # moe_noisy_gate_loss_weight (CLAUDE.md:66-70)
 
 
@@ -66,7 +67,13 @@ class GemmTimer:
             M = kw.get("M")
             if M is None:
                 M = kw["a_row_idx"].numel() if kw.get("a_row_idx") is not None else A.shape[0]
-            self.records.append((s, e, 2.0 * M * B.shape[-2] * B.shape[-1], kw.get("group_offsets") is not None))
+            N, K = B.shape[-2], B.shape[-1]
+            # algorithmic bytes: every operand / output element once (a routed row counts once per use)
+            byts = M * K * A.element_size() + B.numel() * B.element_size() + M * N * C.element_size()
+            for name, esz in (("pre_out", A.element_size()), ("gelu_grad_pre", A.element_size()), ("residual", 4)):
+                if kw.get(name) is not None:
+                    byts += M * N * esz
+            self.records.append((s, e, 2.0 * M * N * K, kw.get("group_offsets") is not None, float(byts)))
             return r
         self.ops.gemm_nt = timed
         return self
@@ -75,15 +82,17 @@ class GemmTimer:
         self.ops.gemm_nt = self.orig
 
     def summary(self):
-        tot_ms = tot_fl = g_ms = g_fl = 0.0
-        for s, e, fl, grouped in self.records:
+        tot_ms = tot_fl = g_ms = g_fl = tot_by = g_by = 0.0
+        for s, e, fl, grouped, byts in self.records:
             ms = s.elapsed_time(e)
-            tot_ms += ms; tot_fl += fl
+            tot_ms += ms; tot_fl += fl; tot_by += byts
             if grouped:
-                g_ms += ms; g_fl += fl
+                g_ms += ms; g_fl += fl; g_by += byts
         n = len(self.records)
         return dict(launches=n, avg_us=1e3 * tot_ms / max(n, 1), tflops=tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0,
-                    flops_per_launch=tot_fl / max(n, 1),
+                    flops_per_launch=tot_fl / max(n, 1), bytes_per_launch=tot_by / max(n, 1),
+                    gbps=tot_by / (tot_ms * 1e-3) / 1e9 if tot_ms else 0.0,
+                    grouped_gbps=g_by / (g_ms * 1e-3) / 1e9 if g_ms else 0.0,
                     grouped_launches=sum(1 for r in self.records if r[3]),
                     grouped_tflops=g_fl / (g_ms * 1e-3) / 1e12 if g_ms else 0.0)
 
@@ -345,17 +354,30 @@ def main():
             traffic = round(pm["kernels"]["gemm_nt_all"]["hbm_bytes_per_launch"])
     except Exception:
         traffic = None
-    roofline = {"kernel": "m3_gemm_nt (gemm_nt_dma_kernel + gemm_nt_kernel)", "bound": "mfma",
-                "achieved": round(g1["tflops"], 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(g1["tflops"] / peak, 4), "traffic": traffic,
+    # Which roof binds: the launches' arithmetic intensity (algorithmic FLOPs / algorithmic bytes) against the machine
+    # balance peak_flops / peak_bandwidth.  fp16: ~170 FLOP/B < 312 -> the HBM roof (the K = 384 GEMMs of
+    # this model are on the HBM side of the ridge); fp32: ~85 FLOP/B > 19.7 -> the MFMA roof.
+    intensity = g1["flops_per_launch"] / g1["bytes_per_launch"]
+    hbm_bound = intensity < peak * 1e12 / (PEAK_HBM * 1e9)
+    roofline = {"kernel": "m3_gemm_nt (gemm_nt_dma_kernel + gemm_nt_kernel)",
+                "bound": "hbm" if hbm_bound else "mfma",
+                "achieved": round(g1["gbps"], 1) if hbm_bound else round(g1["tflops"], 2),
+                "peak": PEAK_HBM if hbm_bound else peak,
+                "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": round(g1["gbps"] / PEAK_HBM, 4) if hbm_bound else round(g1["tflops"] / peak, 4),
+                "traffic": traffic,
                 "avg_launch_us": round(g1["avg_us"], 2), "launches_per_step": g1["launches"] // n_inst,
-                "flops_per_launch": g1["flops_per_launch"],
+                "flops_per_launch": g1["flops_per_launch"], "bytes_per_launch": round(g1["bytes_per_launch"]),
+                "flop_per_byte": round(intensity, 1),
+                "mfma_tflops": round(g1["tflops"], 2), "mfma_frac": round(g1["tflops"] / peak, 4),
+                "hbm_gbps": round(g1["gbps"], 1), "hbm_frac": round(g1["gbps"] / PEAK_HBM, 4),
                 "expert_grouped_gemm_tflops": round(g1["grouped_tflops"], 2),
                 "expert_grouped_gemm_frac": round(g1["grouped_tflops"] / peak, 4),
+                "expert_grouped_gemm_gbps": round(g1["grouped_gbps"], 1),
                 "launch_mode": "the step's launches on one stream (kernel by itself)"}
     if gs is not None:
         roofline["as_timed"] = {"launch_mode": f"{ntasks} concurrent task streams; event pairs include waiting for CU slots",
-                                "achieved": round(gs["tflops"], 2), "frac": round(gs["tflops"] / peak, 4),
+                                "mfma_tflops": round(gs["tflops"], 2), "hbm_gbps": round(gs["gbps"], 1),
                                 "avg_launch_us": round(gs["avg_us"], 2)}
 
     step_flops = 3.0 * cfg.fwd_flops_per_image() * args.batch * ntasks
