@@ -48,8 +48,13 @@ class FMoETransformerMLP(FMoE):
                  regu_experts_fromtask=False, num_experts_pertask=-1, num_tasks=-1, regu_sem=False, sem_force=False,
                  regu_subimage=False, expert_prune=False, prune_threshold=0.1, **kwargs):
         super().__init__(num_expert=num_expert, d_model=d_model, gate=gate, world_size=world_size, top_k=top_k, **kwargs)
-        if regu_sem or sem_force or regu_subimage:
-            raise NotImplementedError("regu_sem / sem_force / regu_subimage are outside the hot path (SURVEY 8a a4)")
+        if regu_sem or regu_subimage:
+            raise NotImplementedError("regu_sem / regu_subimage are outside the hot path (SURVEY 8a a4)")
+        self.sem_force = sem_force
+        if sem_force:
+            # NYUD-40 classes -> 8 expert pairs (custom_moe_layer.py:112-113; configuration data of the reference)
+            self.force_id = [[0], [1, 17, 18, 19, 20], [2, 12, 13, 14, 15, 16], [3, 9, 10, 11], [4, 5], [6, 7, 8, 38],
+                             [21, 22, 23, 24, 25, 26, 39], [27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37]]
         self.our_d_gate = d_gate
         self.our_d_model = d_model
         self.num_expert = num_expert
@@ -99,6 +104,21 @@ class FMoETransformerMLP(FMoE):
         out, clean, noisy, std, top_logits, gates = self.forward_moe(gate_inp, inp, task_id=task_id, sem=sem, tsf=tsf)
         return out.reshape(original_shape), clean, noisy, std, top_logits, gates
 
+    def _force_by_semantics(self, idx, score, sem):
+        """sem_force (custom_moe_layer.py:225-243), vectorised: a patch whose semantic class is in force_id[j] is sent
+        to the expert pair (2j, 2j+1) (pattern repeated to fill top_k); token 0 of every image (cls) keeps its
+        routing; EVERY score becomes 0.5 (constant: no gradient reaches the gate through the combine)."""
+        k = self.top_k
+        B = sem.shape[0]
+        idx3 = idx.reshape(B, -1, k).clone()
+        semf = sem.reshape(B, -1).to(idx.device)
+        patches = idx3[:, 1:1 + semf.shape[1]]
+        for j, classes in enumerate(self.force_id):                # later groups override earlier ones, as the loop does
+            hit = torch.isin(semf, torch.tensor(classes, device=semf.device, dtype=semf.dtype))
+            pattern = torch.tensor(([2 * j, 2 * j + 1] * ((k + 1) // 2))[:k], device=idx.device, dtype=idx.dtype)
+            patches[hit] = pattern
+        return idx3.reshape(-1, k), torch.full_like(score, 0.5)
+
     def forward_moe(self, gate_inp, moe_inp, task_id=None, sem=None, tsf=None):
         if (task_id is not None) and self.multi_gate:
             g = self.gate[task_id]
@@ -112,6 +132,9 @@ class FMoETransformerMLP(FMoE):
         if self.expert_prune:
             score = torch.where(score > self.prune_threshold, score, torch.zeros_like(score))
         idx32 = g._last["idx32"]
+        if self.sem_force and (sem is not None):
+            idx, score = self._force_by_semantics(idx, score, sem)          # :225-243
+            idx32 = idx.to(torch.int32)
         if self.regu_experts_fromtask and (task_id is not None):
             idx = idx + self.start_experts_id[task_id]
             idx32 = idx.to(torch.int32)

@@ -137,7 +137,7 @@ class Block(nn.Module):
                                           gate_task_specific_dim=gate_task_specific_dim, multi_gate=multi_gate,
                                           regu_experts_fromtask=regu_experts_fromtask,
                                           num_experts_pertask=num_experts_pertask, num_tasks=num_tasks,
-                                          expert_prune=expert_prune)
+                                          expert_prune=expert_prune, sem_force=sem_force)
             self.mlp_drop = nn.Dropout(drop)
         else:
             self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
@@ -181,7 +181,7 @@ class VisionTransformerMoE(nn.Module):
                  gate_dim=-1, moe_gate_type="noisy_vmoe", vmoe_noisy_std=1, gate_task_specific_dim=-1,
                  multi_gate=False, regu_experts_fromtask=False, num_experts_pertask=-1, num_tasks=-1,
                  gate_input_ahead=False, expert_prune=False, use_checkpointing=False, act_dtype=torch.float32,
-                 random_init=True, **kwargs):
+                 random_init=True, sem_force=False, **kwargs):
         super().__init__()
         assert drop_rate == 0.0 and attn_drop_rate == 0.0 and drop_path_rate == 0.0
         self.img_size = tuple(img_size) if isinstance(img_size, (tuple, list)) else (img_size, img_size)
@@ -214,7 +214,8 @@ class VisionTransformerMoE(nn.Module):
                                     vmoe_noisy_std=vmoe_noisy_std, gate_task_specific_dim=gate_task_specific_dim,
                                     multi_gate=multi_gate, regu_experts_fromtask=regu_experts_fromtask,
                                     num_experts_pertask=num_experts_pertask, num_tasks=num_tasks,
-                                    gate_input_ahead=gate_input_ahead, expert_prune=expert_prune))
+                                    gate_input_ahead=gate_input_ahead, expert_prune=expert_prune,
+                                    sem_force=sem_force))
         self.blocks = nn.Sequential(*blocks)
         self.pre_logits = nn.Identity()
         self.init_weights()

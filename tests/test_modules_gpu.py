@@ -262,3 +262,39 @@ def test_decoder_head_and_multitask_wrapper():
     one = MultiTaskModel(bb, heads, tasks, multi_gate=False).cuda().eval()
     o1, _ = one(x.cuda(), single_task="depth", task_id=1)
     assert list(o1) == ["depth"] and torch.allclose(o1["depth"], out["depth"], atol=1e-5)
+
+
+def test_sem_force_routing_override():
+    """sem_force (custom_moe_layer.py:225-243): patches are routed by their semantic class to fixed expert pairs, the
+    cls token keeps the gate's choice, all scores become 0.5.  Indices against a literal transcription of the
+    reference's triple loop; output against the oracle's dispatch + bmm on those indices / scores."""
+    _need_gpu()
+    from m3vit_amd.gate import NoisyGate_VMoE
+    from m3vit_amd.moe_layer import FMoETransformerMLP
+    from oracle import ref_torch as R
+    torch.manual_seed(12)
+    E, D, k, B, N = 16, 64, 4, 2, 7                                  # 6 patches + cls per image
+    layer = FMoETransformerMLP(num_expert=E, d_model=D, d_gate=D, d_hidden=D, gate=NoisyGate_VMoE, top_k=k,
+                               vmoe_noisy_std=0, sem_force=True,
+                               activation=torch.nn.Sequential(torch.nn.GELU(), torch.nn.Dropout(0.))).cuda()
+    x = torch.randn(B, N, D, device="cuda")
+    sem = torch.tensor([[0, 17, 255, 38, 5, 30], [12, 12, 3, 255, 21, 1]])     # 255: not in any group -> gate's routing
+    seen = {}
+    layer.gate_hook = lambda idx, score, _: seen.update(idx=idx.clone(), score=score.clone())
+    out, clean, *_ = layer(x, None, None, None, sem)
+    # the gate's own routing, then the reference's loop
+    (gidx, _), *_ = R.gate_vmoe(x.reshape(-1, D).double().cpu(), layer.gate.w_gate.detach().double().cpu(), k)
+    want = gidx.reshape(B, N, k).clone()
+    for b in range(B):
+        for i in range(sem.shape[1]):
+            for j, grp in enumerate(layer.force_id):
+                if int(sem[b, i]) in grp:
+                    want[b, i + 1, :] = torch.tensor(([2 * j, 2 * j + 1] * ((k + 1) // 2))[:k])
+    assert torch.equal(seen["idx"].cpu(), want.reshape(-1, k))
+    assert torch.equal(seen["score"].cpu(), torch.full((B * N, k), 0.5))
+    e = layer.experts
+    y = R.moe_dispatch_ffn(x.reshape(-1, D).double().cpu(), want.reshape(-1, k), e.htoh4.weight.detach().double().cpu(),
+                           e.htoh4.bias.detach().double().cpu(), e.h4toh.weight.detach().double().cpu(),
+                           e.h4toh.bias.detach().double().cpu())
+    ref = 0.5 * y.view(-1, k, D).sum(1)
+    assert rel(out.reshape(-1, D), ref) < 2e-5
