@@ -412,10 +412,11 @@ static size_t attn_bwd_lds() {
          2 * (size_t)DH * (AB_QB * ES + 16) + 2 * AB_QB * sizeof(float);
 }
 
-// short-sequence fp16 / dh = 32 variants (attention_res.hip)
-int launch_attention_fwd_res(const void *qkv, int B, int N, int heads, void *o, float *lse, float scale, hipStream_t s);
+// short-sequence fp16 variants (attention_res.hip)
+int launch_attention_fwd_res(const void *qkv, int B, int N, int heads, int dh, void *o, float *lse, float scale,
+                             hipStream_t s);
 int launch_attention_bwd_res(const void *qkv, const void *o, const void *d_o, const float *lse, int B, int N, int heads,
-                             void *dqkv, float scale, hipStream_t s);
+                             int dh, void *dqkv, float scale, hipStream_t s);
 constexpr int ATTN_RES_MAXN = 256;
 
 }  // namespace m3
@@ -432,7 +433,7 @@ extern "C" int m3_attention_fwd(const void *qkv, int dtype, int B, int N, int he
   const dim3 grid((N + AT_QB - 1) / AT_QB, B * heads), block(AT_THREADS);
   const float scale = 1.0f / sqrtf((float)dh);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == M3_F16 && dh == 32 && N <= ATTN_RES_MAXN) return launch_attention_fwd_res(qkv, B, N, heads, o, lse, scale, s);
+  if (dtype == M3_F16 && N <= ATTN_RES_MAXN) return launch_attention_fwd_res(qkv, B, N, heads, dh, o, lse, scale, s);
 #define M3_AF(TT, DD) \
   hipLaunchKernelGGL((attention_fwd_kernel<TT, DD>), grid, block, 0, s, (const TT *)qkv, B, N, heads, (TT *)o, lse, scale)
   if (dtype == M3_F16) { if (dh == 32) M3_AF(half_t, 32); else M3_AF(half_t, 64); }
@@ -476,8 +477,8 @@ extern "C" int m3_attention_bwd(const void *qkv, const void *o, const void *d_o,
   if (N <= AB_KEYS) dq_ws = nullptr;
   const float scale = 1.0f / sqrtf((float)dh);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == M3_F16 && dh == 32 && N <= ATTN_RES_MAXN)
-    return launch_attention_bwd_res(qkv, o, d_o, lse, B, N, heads, dqkv, scale, s);
+  if (dtype == M3_F16 && N <= ATTN_RES_MAXN)
+    return launch_attention_bwd_res(qkv, o, d_o, lse, B, N, heads, dh, dqkv, scale, s);
   if (dtype == M3_F16) {
     if (dh == 32) return launch_attn_bwd<half_t, 32>(qkv, o, d_o, lse, B, N, heads, dqkv, dq_ws, scale, s);
     return launch_attn_bwd<half_t, 64>(qkv, o, d_o, lse, B, N, heads, dqkv, dq_ws, scale, s);

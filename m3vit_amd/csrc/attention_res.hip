@@ -1,17 +1,18 @@
-// Attention forward / backward for SHORT sequences (N <= 256 tokens, fp16, head dim 32): the case of
-// the 224x224 configurations (N = 197), where one (image, head) pair is only 197 x 64 bytes per
-// operand.  Same maths and operand plan as attention.hip (Attention.forward,
+// Attention forward / backward for SHORT sequences (N <= 256 tokens, fp16, head dim 32 or 64): the case of
+// the 224x224 configurations (N = 197; ViT-S heads of 32, ViT-B heads of 64), where one (image, head) pair is
+// only 197 x 64 / 128 bytes per operand.  Same maths and operand plan as attention.hip (Attention.forward,
 // models/moe/ckpt/vision_transformer_moe.py:299-313), but everything a workgroup needs is staged
 // ONCE: K / V (forward) or Q / dO / K (backward) live in LDS for the whole kernel, so the loops over
 // the query tiles run without global-memory latency and with at most one barrier per step.
 //
-// LDS images are row-major 64-byte rows (32 halves), XOR-swizzled at 16-byte granularity
-// (chunk ^= (row >> 1) & 3): conflict-free both for ds_read_b128 row fragments (contraction along the
-// row) and for ds_read_b64_tr_b16 transposed fragments (contraction along the rows), so no transposed
-// copies are kept.
+// LDS images are row-major rows of dh halves (64 or 128 bytes), XOR-swizzled at 16-byte granularity
+// (64-byte rows: chunk ^= (row >> 1) & 3; 128-byte rows: chunk ^= row & 7): conflict-free both for
+// ds_read_b128 row fragments (contraction along the row) and for ds_read_b64_tr_b16 transposed fragments
+// (contraction along the rows), so no transposed copies are kept.
 //   fwd : wave owns query tiles {w, w+4, ..}: S^T[key][q] = K Q^T for ALL keys (<= 16 tiles in
 //         registers), plain softmax (no online rescaling), O^T[d][q] = V^T P^T.
-//   bwd : wave owns key tiles {w, w+4, ..} (dK^T, dV^T in registers), sweeps 32-row query steps:
+//   bwd : wave owns key tiles {w, w+NW, ..} (NW = 4 waves for dh 32, 8 for dh 64; dK^T, dV^T in registers),
+//         sweeps 32-row query steps:
 //         S = Q K^T, dP = dO V^T, P = exp(S - lse), dS = P (dP - delta);  dV^T += dO^T P,
 //         dK^T += Q^T dS;  dS^T goes to a double-buffered LDS image for dQ^T = K^T dS^T.
 #include "common.h"
@@ -19,28 +20,28 @@
 namespace m3 {
 
 constexpr int AR_THREADS = 256;
-constexpr int AR_DH = 32;
 constexpr int AR_MAXN = 256;
 constexpr float AR_LOG2E = 1.4426950408889634f;
 
 typedef __fp16 ar_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
-// byte offset of (row, byte-in-row) in a swizzled image of 64-byte rows
-__device__ __forceinline__ int sw64(int row, int byte) {
-  return row * 64 + ((((byte >> 4) ^ (row >> 1)) & 3) << 4) + (byte & 15);
+// byte offset of (row, byte-in-row) in a swizzled image whose rows hold W halves (W = 32: 64-byte rows, W = 64: 128)
+template <int W> __device__ __forceinline__ int swo(int row, int byte) {
+  if (W == 32) return row * 64 + ((((byte >> 4) ^ (row >> 1)) & 3) << 4) + (byte & 15);
+  return row * 128 + ((((byte >> 4) ^ row) & 7) << 4) + (byte & 15);
 }
 
-// row fragment: lane (li, lg) <- 8 halves of row (r0 + li), elements 8*lg .. 8*lg+7
-__device__ __forceinline__ f16x8 row_frag(const char *img, int r0, int li, int lg) {
-  return *(const f16x8 *)(img + sw64(r0 + li, lg * 16));
+// row fragment: lane (li, lg) <- 8 halves of row (r0 + li), elements 32*ch + 8*lg .. +7
+template <int W> __device__ __forceinline__ f16x8 row_frag(const char *img, int r0, int ch, int li, int lg) {
+  return *(const f16x8 *)(img + swo<W>(r0 + li, ch * 64 + lg * 16));
 }
 
 // transposed fragment: lane (li, lg) <- column (col + li), contraction rows rb + {4*lg + r, 16 + 4*lg + r}
 // (the k order of Mma<half_t>::from_tiles, i.e. of an accumulator pair used as the other operand)
-__device__ __forceinline__ f16x8 tr_frag(const char *img, int rb, int col, int li, int lg) {
+template <int W> __device__ __forceinline__ f16x8 tr_frag(const char *img, int rb, int col, int li, int lg) {
   const int r = rb + 4 * lg + (li >> 2), byte = (col + 4 * (li & 3)) * 2;
-  const ar_fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) ar_fp16x4 *)(img + sw64(r, byte)));
-  const ar_fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) ar_fp16x4 *)(img + sw64(r + 16, byte)));
+  const ar_fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) ar_fp16x4 *)(img + swo<W>(r, byte)));
+  const ar_fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) ar_fp16x4 *)(img + swo<W>(r + 16, byte)));
   f16x8 f;
   f[0] = (half_t)lo[0]; f[1] = (half_t)lo[1]; f[2] = (half_t)lo[2]; f[3] = (half_t)lo[3];
   f[4] = (half_t)hi[0]; f[5] = (half_t)hi[1]; f[6] = (half_t)hi[2]; f[7] = (half_t)hi[3];
@@ -52,13 +53,14 @@ __device__ __forceinline__ f32x4 mma16(const f16x8 &a, const f16x8 &b, f32x4 c) 
 }
 
 // ------------------------------------------------------------------------------ forward
+template <int DH>
 __global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_res_kernel(const half_t *__restrict__ qkv, int N, int heads,
                                                                            half_t *__restrict__ o,
                                                                            float *__restrict__ lse, float scale) {
-  constexpr int DH = AR_DH;
+  constexpr int RBY = DH * 2, CPR = RBY / 16, NCH = DH / 32, NDT = DH / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NP = (N + 31) & ~31;
-  char *sK = smem, *sV = smem + NP * 64;
+  char *sK = smem, *sV = smem + NP * RBY;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -70,22 +72,25 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_res_kernel(const 
 
   // this wave's query tiles {wave, wave + 4, ...}: Q fragments straight from global, all issued up front
   const int nkt = (N + 15) >> 4;                 // key tiles == query tiles
-  f16x8 qfs[AR_MAXN / 64];
+  f16x8 qfs[AR_MAXN / 64][NCH];
 #pragma unroll
   for (int i = 0; i < AR_MAXN / 64; ++i) {
     const int qrow = (i * 4 + wave) * 16 + li;
-    qfs[i] = Mma<half_t>::zero();
-    if (qrow < N) qfs[i] = *(const f16x8 *)(qbase + (int64_t)qrow * ld + 8 * lg);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      qfs[i][ch] = Mma<half_t>::zero();
+      if (qrow < N) qfs[i][ch] = *(const f16x8 *)(qbase + (int64_t)qrow * ld + ch * 32 + 8 * lg);
+    }
   }
-  for (int q = tid; q < NP * 4; q += AR_THREADS) {
-    const int row = q >> 2, c = q & 3;
+  for (int q = tid; q < NP * CPR; q += AR_THREADS) {
+    const int row = q / CPR, c = q % CPR;
     u32x4 kv = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
     if (row < N) {
       kv = *(const u32x4 *)((const char *)(kbase + (int64_t)row * ld) + c * 16);
       vv = *(const u32x4 *)((const char *)(vbase + (int64_t)row * ld) + c * 16);
     }
-    *(u32x4 *)(sK + sw64(row, c * 16)) = kv;
-    *(u32x4 *)(sV + sw64(row, c * 16)) = vv;
+    *(u32x4 *)(sK + swo<DH>(row, c * 16)) = kv;
+    *(u32x4 *)(sV + swo<DH>(row, c * 16)) = vv;
   }
   __syncthreads();
 
@@ -95,7 +100,6 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_res_kernel(const 
     const int qt = i * 4 + wave;
     if (qt >= nkt) break;
     const int qrow = qt * 16 + li;
-    const f16x8 qf = qfs[i];
     // S^T tiles: st[kt][r] = S[q = li][key = 16*kt + 4*lg + r]; only the last key tile can hold keys >= N
     f32x4 st[AR_MAXN / 16];
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -103,7 +107,9 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_res_kernel(const 
 #pragma unroll
     for (int kt = 0; kt < AR_MAXN / 16; ++kt) {
       if (kt < nkt) {
-        f32x4 sv = mma16(row_frag(sK, kt * 16, li, lg), qf, zero4);
+        f32x4 sv = zero4;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) sv = mma16(row_frag<DH>(sK, kt * 16, ch, li, lg), qfs[i][ch], sv);
         if (kt == nkt - 1) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) sv[r] = (kt * 16 + 4 * lg + r < N) ? sv[r] : -INFINITY;
@@ -132,41 +138,44 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_res_kernel(const 
     psum += __shfl_xor(psum, 16, 64);
     psum += __shfl_xor(psum, 32, 64);
     // O^T[d = 16*dt + 4*lg + r][q = li] = sum_key V^T[d][key] P^T[key][q]
-    f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 oacc[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) oacc[dt] = zero4;
 #pragma unroll
     for (int cc = 0; cc < AR_MAXN / 32; ++cc) {
       if (cc * 2 < nkt) {
         const f16x8 pf = Mma<half_t>::from_tiles(&st[cc * 2]);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) oacc[dt] = mma16(tr_frag(sV, cc * 32, dt * 16, li, lg), pf, oacc[dt]);
+        for (int dt = 0; dt < NDT; ++dt) oacc[dt] = mma16(tr_frag<DH>(sV, cc * 32, dt * 16, li, lg), pf, oacc[dt]);
       }
     }
     if (qrow < N) {
       const float inv = 1.0f / psum;
       half_t *orow = o + ((int64_t)b * N + qrow) * C + h * DH;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) Vec4<half_t>::store(orow + dt * 16 + 4 * lg, oacc[dt] * inv);
+      for (int dt = 0; dt < NDT; ++dt) Vec4<half_t>::store(orow + dt * 16 + 4 * lg, oacc[dt] * inv);
       if (lg == 0) lse[((int64_t)b * heads + h) * N + qrow] = mx * scale + __logf(psum);
     }
   }
 }
 
 // ----------------------------------------------------------------------------- backward
-__global__ __launch_bounds__(AR_THREADS, 2) void attention_bwd_res_kernel(const half_t *__restrict__ qkv,
-                                                                           const half_t *__restrict__ o,
-                                                                           const half_t *__restrict__ d_o,
-                                                                           const float *__restrict__ lse, int N,
-                                                                           int heads, half_t *__restrict__ dqkv,
-                                                                           float scale) {
-  constexpr int DH = AR_DH;
+// NW waves; wave owns key tiles {w, w + NW, ...} (KTW = 16 / NW of them); dQ pieces (2 query tiles x NDT d tiles) = NW
+template <int DH>
+__global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attention_bwd_res_kernel(
+    const half_t *__restrict__ qkv, const half_t *__restrict__ o, const half_t *__restrict__ d_o,
+    const float *__restrict__ lse, int N, int heads, half_t *__restrict__ dqkv, float scale) {
+  constexpr int RBY = DH * 2, CPR = RBY / 16, NCH = DH / 32, NDT = DH / 16;
+  constexpr int NW = DH == 32 ? 4 : 8, NT = NW * 64, KTW = (AR_MAXN / 16) / NW;
+  static_assert(2 * NDT == NW, "one dQ piece per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NP = (N + 31) & ~31;
-  char *sQ = smem, *sdO = sQ + NP * 64, *sK = sdO + NP * 64;
-  char *sdS = sK + NP * 64;                            // two [NP keys][32 q] images
+  char *sQ = smem, *sdO = sQ + NP * RBY, *sK = sdO + NP * RBY;
+  char *sdS = sK + NP * RBY;                           // two [NP keys][32 q] images (64-byte rows)
   float *sLse = (float *)(sdS + 2 * NP * 64);          // lse * log2(e); +inf-like for the padded rows
   float *sDelta = sLse + NP;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
   const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / heads, h = bh - b * heads;
   const int C = heads * DH;
@@ -178,9 +187,9 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_bwd_res_kernel(const 
   half_t *dqbase = dqkv + (int64_t)b * N * ld + h * DH;
   const float *lbase = lse + ((int64_t)b * heads + h) * N;
 
-  // ---- stage Q, dO, K; delta[q] = sum_d dO O (4 chunk-threads per row)
-  for (int q = tid; q < NP * 4; q += AR_THREADS) {
-    const int row = q >> 2, c = q & 3;
+  // ---- stage Q, dO, K; delta[q] = sum_d dO O (CPR chunk-threads per row)
+  for (int q = tid; q < NP * CPR; q += NT) {
+    const int row = q / CPR, c = q % CPR;
     u32x4 qv = u32x4{0u, 0u, 0u, 0u}, dv = qv, kv = qv, ov = qv;
     if (row < N) {
       qv = *(const u32x4 *)((const char *)(qbase + (int64_t)row * ld) + c * 16);
@@ -188,40 +197,44 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_bwd_res_kernel(const 
       dv = *(const u32x4 *)((const char *)(dobase + (int64_t)row * C) + c * 16);
       ov = *(const u32x4 *)((const char *)(obase + (int64_t)row * C) + c * 16);
     }
-    *(u32x4 *)(sQ + sw64(row, c * 16)) = qv;
-    *(u32x4 *)(sdO + sw64(row, c * 16)) = dv;
-    *(u32x4 *)(sK + sw64(row, c * 16)) = kv;
+    *(u32x4 *)(sQ + swo<DH>(row, c * 16)) = qv;
+    *(u32x4 *)(sdO + swo<DH>(row, c * 16)) = dv;
+    *(u32x4 *)(sK + swo<DH>(row, c * 16)) = kv;
     const f16x8 dh8 = __builtin_bit_cast(f16x8, dv), oh8 = __builtin_bit_cast(f16x8, ov);
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) s += (float)dh8[j] * (float)oh8[j];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
+#pragma unroll
+    for (int m = 1; m < CPR; m <<= 1) s += __shfl_xor(s, m, 64);
     if (c == 0) {
       sDelta[row] = s;
       sLse[row] = (row < N) ? lbase[row] * AR_LOG2E : 1e30f;     // padded query rows: P = exp2(-huge) = 0
     }
   }
   // rows of the dS^T images that no wave writes (key tiles past the last valid one) must read as zero
-  for (int q = tid; q < 2 * NP * 4; q += AR_THREADS) *(u32x4 *)(sdS + q * 16) = u32x4{0u, 0u, 0u, 0u};
-  // this wave's key tiles {wave, wave + 4, ...}: K / V fragments (B operands) straight from global
+  for (int q = tid; q < 2 * NP * 4; q += NT) *(u32x4 *)(sdS + q * 16) = u32x4{0u, 0u, 0u, 0u};
+  // this wave's key tiles: K / V fragments (B operands) straight from global
   const int nkt = (N + 15) >> 4;
-  f16x8 kf[4], vf[4];
+  f16x8 kf[KTW][NCH], vf[KTW][NCH];
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt) {
-    const int key = (kt * 4 + wave) * 16 + li;
-    kf[kt] = Mma<half_t>::zero();
-    vf[kt] = Mma<half_t>::zero();
-    if (key < N) {
-      kf[kt] = *(const f16x8 *)(kbase + (int64_t)key * ld + 8 * lg);
-      vf[kt] = *(const f16x8 *)(vbase + (int64_t)key * ld + 8 * lg);
+  for (int kt = 0; kt < KTW; ++kt) {
+    const int key = (kt * NW + wave) * 16 + li;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      kf[kt][ch] = Mma<half_t>::zero();
+      vf[kt][ch] = Mma<half_t>::zero();
+      if (key < N) {
+        kf[kt][ch] = *(const f16x8 *)(kbase + (int64_t)key * ld + ch * 32 + 8 * lg);
+        vf[kt][ch] = *(const f16x8 *)(vbase + (int64_t)key * ld + ch * 32 + 8 * lg);
+      }
     }
   }
-  f32x4 dkt[2][4], dvt[2][4];
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 dkt[NDT][KTW], dvt[NDT][KTW];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NDT; ++a)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { dkt[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int c = 0; c < KTW; ++c) { dkt[a][c] = zero4; dvt[a][c] = zero4; }
   __syncthreads();
 
   const float c1 = scale * AR_LOG2E;
@@ -231,20 +244,28 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_bwd_res_kernel(const 
     const int qs = st * 32;
     char *dsb = sdS + (st & 1) * NP * 64;
     // ---- S, dP -> P, dS (unscaled) for this wave's key tiles;  D[q = 4*lg + r][key = li]
-    f32x4 pt[2][4], dst[2][4];
-    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 pt[2][KTW], dst[2][KTW];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      const f16x8 qfr = row_frag(sQ, qs + qt * 16, li, lg), dof = row_frag(sdO, qs + qt * 16, li, lg);
+      f16x8 qfr[NCH], dof[NCH];
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        qfr[ch] = row_frag<DH>(sQ, qs + qt * 16, ch, li, lg);
+        dof[ch] = row_frag<DH>(sdO, qs + qt * 16, ch, li, lg);
+      }
       float l2[4], dl[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) { l2[r] = sLse[qs + qt * 16 + 4 * lg + r]; dl[r] = sDelta[qs + qt * 16 + 4 * lg + r]; }
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        const int tix = kt * 4 + wave;
+      for (int kt = 0; kt < KTW; ++kt) {
+        const int tix = kt * NW + wave;
         if (tix < nkt) {
-          const f32x4 s = mma16(qfr, kf[kt], zero4);
-          const f32x4 dp = mma16(dof, vf[kt], zero4);
+          f32x4 s = zero4, dp = zero4;
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch) {
+            s = mma16(qfr[ch], kf[kt][ch], s);
+            dp = mma16(dof[ch], vf[kt][ch], dp);
+          }
           f32x4 pv;
 #pragma unroll
           for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r] * c1 - l2[r]);
@@ -260,28 +281,28 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_bwd_res_kernel(const 
     }
     // ---- dV^T += dO^T P ; dK^T += Q^T dS   (contraction over the 32 queries of the step)
     {
-      f16x8 aq[2], ado[2];
+      f16x8 aq[NDT], ado[NDT];
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        aq[dt] = tr_frag(sQ, qs, dt * 16, li, lg);
-        ado[dt] = tr_frag(sdO, qs, dt * 16, li, lg);
+      for (int dt = 0; dt < NDT; ++dt) {
+        aq[dt] = tr_frag<DH>(sQ, qs, dt * 16, li, lg);
+        ado[dt] = tr_frag<DH>(sdO, qs, dt * 16, li, lg);
       }
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        if (kt * 4 + wave < nkt) {
+      for (int kt = 0; kt < KTW; ++kt) {
+        if (kt * NW + wave < nkt) {
           f32x4 tp[2] = {pt[0][kt], pt[1][kt]}, td[2] = {dst[0][kt], dst[1][kt]};
           const f16x8 pf = Mma<half_t>::from_tiles(tp), dsf = Mma<half_t>::from_tiles(td);
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
+          for (int dt = 0; dt < NDT; ++dt) {
             dvt[dt][kt] = mma16(ado[dt], pf, dvt[dt][kt]);
             dkt[dt][kt] = mma16(aq[dt], dsf, dkt[dt][kt]);
           }
           // dS^T[key][q]: this lane holds 4 consecutive q of one key per (qt, kt) -> one 8-byte store
-          const int krow = (kt * 4 + wave) * 16 + li;
+          const int krow = (kt * NW + wave) * 16 + li;
 #pragma unroll
           for (int qt = 0; qt < 2; ++qt) {
             f16x4 v = f16x4{(half_t)dst[qt][kt][0], (half_t)dst[qt][kt][1], (half_t)dst[qt][kt][2], (half_t)dst[qt][kt][3]};
-            *(f16x4 *)(dsb + sw64(krow, (qt * 16 + 4 * lg) * 2)) = v;
+            *(f16x4 *)(dsb + swo<32>(krow, (qt * 16 + 4 * lg) * 2)) = v;
           }
         }
       }
@@ -289,10 +310,10 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_bwd_res_kernel(const 
     __syncthreads();      // the other dS^T buffer is rewritten only after the NEXT barrier
     // ---- dQ^T[d = 16*dt + 4*lg + r][q = 16*qt + li] = K^T dS^T, one (qt, dt) piece per wave
     {
-      const int qt = wave >> 1, dt = wave & 1;
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int qt = wave / NDT, dt = wave - qt * NDT;
+      f32x4 acc = zero4;
       for (int c = 0; c < nkc; ++c)
-        acc = mma16(tr_frag(sK, c * 32, dt * 16, li, lg), tr_frag(dsb, c * 32, qt * 16, li, lg), acc);
+        acc = mma16(tr_frag<DH>(sK, c * 32, dt * 16, li, lg), tr_frag<32>(dsb, c * 32, qt * 16, li, lg), acc);
       const int qr = qs + qt * 16 + li;
       if (qr < N) Vec4<half_t>::store(dqbase + (int64_t)qr * ld + dt * 16 + 4 * lg, acc * scale);
     }
@@ -300,11 +321,11 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_bwd_res_kernel(const 
 
   // ---- dK, dV rows of this wave's keys
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt) {
-    const int key = (kt * 4 + wave) * 16 + li;
+  for (int kt = 0; kt < KTW; ++kt) {
+    const int key = (kt * NW + wave) * 16 + li;
     if (key < N) {
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
+      for (int dt = 0; dt < NDT; ++dt) {
         Vec4<half_t>::store(dqbase + C + (int64_t)key * ld + dt * 16 + 4 * lg, dkt[dt][kt] * scale);
         Vec4<half_t>::store(dqbase + 2 * C + (int64_t)key * ld + dt * 16 + 4 * lg, dvt[dt][kt]);
       }
@@ -312,26 +333,41 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_bwd_res_kernel(const 
   }
 }
 
-size_t attn_res_fwd_lds(int N) { return (size_t)2 * ((N + 31) & ~31) * 64; }
-size_t attn_res_bwd_lds(int N) { const size_t np = (N + 31) & ~31; return 5 * np * 64 + 2 * np * sizeof(float); }
+size_t attn_res_fwd_lds(int N, int dh) { return (size_t)2 * ((N + 31) & ~31) * dh * 2; }
+size_t attn_res_bwd_lds(int N, int dh) {
+  const size_t np = (N + 31) & ~31;
+  return 3 * np * dh * 2 + 2 * np * 64 + 2 * np * sizeof(float);
+}
 
-int launch_attention_fwd_res(const void *qkv, int B, int N, int heads, void *o, float *lse, float scale, hipStream_t s) {
-  hipLaunchKernelGGL(attention_fwd_res_kernel, dim3(B * heads), dim3(AR_THREADS), attn_res_fwd_lds(N), s,
-                     (const half_t *)qkv, N, heads, (half_t *)o, lse, scale);
+int launch_attention_fwd_res(const void *qkv, int B, int N, int heads, int dh, void *o, float *lse, float scale,
+                             hipStream_t s) {
+  const size_t lds = attn_res_fwd_lds(N, dh);
+  if (dh == 32)
+    hipLaunchKernelGGL(attention_fwd_res_kernel<32>, dim3(B * heads), dim3(AR_THREADS), lds, s, (const half_t *)qkv, N, heads,
+                       (half_t *)o, lse, scale);
+  else
+    hipLaunchKernelGGL(attention_fwd_res_kernel<64>, dim3(B * heads), dim3(AR_THREADS), lds, s, (const half_t *)qkv, N, heads,
+                       (half_t *)o, lse, scale);
   return check_launch("m3_attention_fwd");
 }
 
 int launch_attention_bwd_res(const void *qkv, const void *o, const void *d_o, const float *lse, int B, int N, int heads,
-                             void *dqkv, float scale, hipStream_t s) {
-  const size_t lds = attn_res_bwd_lds(N);
+                             int dh, void *dqkv, float scale, hipStream_t s) {
+  const size_t lds = attn_res_bwd_lds(N, dh);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)attention_bwd_res_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)attn_res_bwd_lds(AR_MAXN));
+    (void)hipFuncSetAttribute((const void *)attention_bwd_res_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)attn_res_bwd_lds(AR_MAXN, 32));
+    (void)hipFuncSetAttribute((const void *)attention_bwd_res_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)attn_res_bwd_lds(AR_MAXN, 64));
     attr_set = true;
   }
-  hipLaunchKernelGGL(attention_bwd_res_kernel, dim3(B * heads), dim3(AR_THREADS), lds, s, (const half_t *)qkv,
-                     (const half_t *)o, (const half_t *)d_o, lse, N, heads, (half_t *)dqkv, scale);
+  if (dh == 32)
+    hipLaunchKernelGGL(attention_bwd_res_kernel<32>, dim3(B * heads), dim3(256), lds, s, (const half_t *)qkv,
+                       (const half_t *)o, (const half_t *)d_o, lse, N, heads, (half_t *)dqkv, scale);
+  else
+    hipLaunchKernelGGL(attention_bwd_res_kernel<64>, dim3(B * heads), dim3(512), lds, s, (const half_t *)qkv,
+                       (const half_t *)o, (const half_t *)d_o, lse, N, heads, (half_t *)dqkv, scale);
   return check_launch("m3_attention_bwd");
 }
 

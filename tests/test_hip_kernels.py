@@ -403,7 +403,8 @@ def _attn_ref(qkv, B, N, h, dh):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,N,h,dh", [(2, 197, 12, 32), (1, 50, 3, 32), (1, 256, 2, 64), (2, 65, 4, 64),
                                       (1, 1025, 2, 32), (1, 1201, 2, 64), (2, 257, 3, 32),
-                                      (3, 256, 2, 32), (2, 1, 2, 32), (2, 17, 3, 32), (1, 224, 5, 32), (2, 225, 1, 32)])
+                                      (3, 256, 2, 32), (2, 1, 2, 32), (2, 17, 3, 32), (1, 224, 5, 32), (2, 225, 1, 32),
+                                      (2, 197, 12, 64), (1, 33, 2, 64), (2, 240, 1, 64)])
 def test_attention_fwd_bwd(ops, dtype, B, N, h, dh):
     C = h * dh
     qkv = rnd(B * N, 3 * C, dtype=dtype, seed=71)
