@@ -246,12 +246,13 @@ int m3_attention_bwd(const void *qkv, const void *o, const void *d_o, const floa
 int m3_cast_matrix(const float *src, int G, int rows, int cols, int transpose,
                    void *dst, int dst_dtype, void *stream);
 /* The same for many matrices in ONE launch (all operand copies of a model per optimizer step):
- * descs_dev is a DEVICE array of n_desc descriptors, tile_start = running sum of
+ * descs_dev is a DEVICE array of n_desc descriptors; a job writes dst (same layout as src) and/or dst_t
+ * (transposed, [g][cols][rows]) - either may be NULL - from one read of src; tile_start = running sum of
  * G * ceil(rows/32) * ceil(cols/32) over the preceding descriptors, total_tiles = the full sum. */
 typedef struct m3_cast_desc {
-  const float *src; void *dst;
-  int32_t G, rows, cols, transpose;
-  int32_t tile_start, pad;
+  const float *src; void *dst; void *dst_t;
+  int32_t G, rows, cols;
+  int32_t tile_start, pad0, pad1;
 } m3_cast_desc;
 int m3_cast_batch(const m3_cast_desc *descs_dev, int n_desc, int total_tiles, int dst_dtype, void *stream);
 /* dst[i] += src[i] (fp32, n elements): sums the flat gradient buffers of task passes that ran

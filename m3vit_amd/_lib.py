@@ -54,8 +54,8 @@ class WgradArgs(Structure):
 
 
 class CastDesc(Structure):
-    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("G", c_int32), ("rows", c_int32), ("cols", c_int32),
-                ("transpose", c_int32), ("tile_start", c_int32), ("pad", c_int32)]
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("dst_t", c_void_p), ("G", c_int32), ("rows", c_int32),
+                ("cols", c_int32), ("tile_start", c_int32), ("pad0", c_int32), ("pad1", c_int32)]
 
 
 class GateFwdArgs(Structure):

@@ -195,11 +195,12 @@ __global__ void cast_matrix_kernel(const float *__restrict__ src, int rows, int 
   }
 }
 
-// many matrices in one launch: block -> descriptor by binary search over the tile prefix
+// many matrices in one launch: block -> descriptor by binary search over the tile prefix; a job may ask for the
+// plain copy, the transposed copy, or both from ONE read of the fp32 tile
 struct CastDesc {            // = m3_cast_desc
-  const float *src; void *dst;
-  int32_t G, rows, cols, transpose;
-  int32_t tile_start, pad;
+  const float *src; void *dst; void *dst_t;
+  int32_t G, rows, cols;
+  int32_t tile_start, pad0, pad1;
 };
 
 template <typename T>
@@ -219,23 +220,19 @@ __global__ __launch_bounds__(256) void cast_batch_kernel(const CastDesc *__restr
   const int r0 = (rest / tcols) * 32, c0 = (rest % tcols) * 32;
   const int64_t goff = (int64_t)g * d.rows * d.cols;
   const float *src = d.src + goff;
-  T *dst = (T *)d.dst + goff;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-  if (!d.transpose) {
-    for (int i = ty; i < 32; i += 8) {
-      const int r = r0 + i, c = c0 + tx;
-      if (r < d.rows && c < d.cols) dst[(int64_t)r * d.cols + c] = (T)src[(int64_t)r * d.cols + c];
-    }
-    return;
-  }
   for (int i = ty; i < 32; i += 8) {
     const int r = r0 + i, c = c0 + tx;
-    tile[i][tx] = (r < d.rows && c < d.cols) ? src[(int64_t)r * d.cols + c] : 0.f;
+    const float v = (r < d.rows && c < d.cols) ? src[(int64_t)r * d.cols + c] : 0.f;
+    if (d.dst && r < d.rows && c < d.cols) ((T *)d.dst + goff)[(int64_t)r * d.cols + c] = (T)v;
+    tile[i][tx] = v;
   }
+  if (!d.dst_t) return;
   __syncthreads();
+  T *dst_t = (T *)d.dst_t + goff;
   for (int i = ty; i < 32; i += 8) {
-    const int c = c0 + i, r = r0 + tx;   // dst[c][r]
-    if (r < d.rows && c < d.cols) dst[(int64_t)c * d.rows + r] = (T)tile[tx][i];
+    const int c = c0 + i, r = r0 + tx;   // dst_t[c][r]
+    if (r < d.rows && c < d.cols) dst_t[(int64_t)c * d.rows + r] = (T)tile[tx][i];
   }
 }
 

@@ -209,19 +209,17 @@ class BackboneEngine:
             for n in self._linear_names():
                 w = self.params[n + ".weight"]
                 w2 = w.reshape(w.shape[0], -1) if n == "patch_embed.proj" else w
-                if self.dt == torch.float32:
-                    self.wc[n] = w2
-                else:
-                    self.wc[n] = torch.empty_like(w2, dtype=self.dt)
-                    jobs.append((w2, self.wc[n], False))
+                self.wc[n] = w2 if self.dt == torch.float32 else torch.empty_like(w2, dtype=self.dt)
                 if n != "patch_embed.proj":
                     self.wt[n] = torch.empty(*w2.shape[:-2], w2.shape[-1], w2.shape[-2], dtype=self.dt, device=self.dev)
-                    jobs.append((w2, self.wt[n], True))
+                plain = None if self.dt == torch.float32 else self.wc[n]
+                if plain is not None or n in self.wt:
+                    jobs.append((w2, plain, self.wt.get(n)))          # both copies from one read of the master
             if self.dt != torch.float32:
                 for n, p in self.params.items():
                     if n.endswith("w_gate"):
                         self.wgate_c[n] = torch.empty_like(p, dtype=self.dt)
-                        jobs.append((p, self.wgate_c[n], False))
+                        jobs.append((p, self.wgate_c[n], None))
             self.cast_plan = ops.CastPlan(jobs, self.dt) if jobs else None
         if self.cast_plan is not None:
             self.cast_plan.run()

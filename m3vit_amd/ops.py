@@ -311,27 +311,31 @@ def cast_matrix(src, dst, transpose=False):
 
 
 class CastPlan:
-    """Device-resident descriptor table for m3_cast_batch: every (fp32 master -> operand copy) pair of a
+    """Device-resident descriptor table for m3_cast_batch: every (fp32 master -> operand copies) job of a
     model, converted by ONE launch per optimizer step."""
 
     def __init__(self, jobs, dst_dtype):
-        # jobs: list of (src fp32 [.., rows, cols], dst [.., rows, cols] or [.., cols, rows], transpose)
-        import ctypes
+        # jobs: list of (src fp32 [.., rows, cols], dst [.., rows, cols] or None, dst_t [.., cols, rows] or None):
+        # the plain and / or the transposed copy, both written from one read of src
         arr = (_lib.CastDesc * len(jobs))()
         t0 = 0
         self.keep = []
-        for d, (src, dst, tr) in zip(arr, jobs):
-            _req(src, torch.float32, "src"); _req(dst, dst_dtype, "dst")
+        for d, (src, dst, dst_t) in zip(arr, jobs):
+            _req(src, torch.float32, "src")
             rows, cols = src.shape[-2], src.shape[-1]
             G = src.numel() // (rows * cols)
-            assert dst.numel() == src.numel()
-            d.src, d.dst, d.G, d.rows, d.cols, d.transpose, d.tile_start = (src.data_ptr(), dst.data_ptr(), G, rows,
-                                                                              cols, int(bool(tr)), t0)
+            for o in (dst, dst_t):
+                if o is not None:
+                    _req(o, dst_dtype, "dst")
+                    assert o.numel() == src.numel()
+            assert dst is not None or dst_t is not None
+            d.src, d.G, d.rows, d.cols, d.tile_start = src.data_ptr(), G, rows, cols, t0
+            d.dst = dst.data_ptr() if dst is not None else None
+            d.dst_t = dst_t.data_ptr() if dst_t is not None else None
             t0 += G * ((rows + 31) // 32) * ((cols + 31) // 32)
-            self.keep += [src, dst]
+            self.keep += [src, dst, dst_t]
         self.n, self.total, self.dtype = len(jobs), t0, dst_dtype
-        raw = bytes(arr)
-        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(jobs[0][0].device)
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(jobs[0][0].device)
 
     def run(self):
         check(lib().m3_cast_batch(_p(self.table), self.n, self.total, dt_code(self.dtype), _stream()), "m3_cast_batch")

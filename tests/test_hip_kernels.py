@@ -444,18 +444,20 @@ def test_cast_and_patchify(ops):
     dst2 = torch.empty(3, 70, 45, dtype=torch.float32, device=dev())
     ops.cast_matrix(src, dst2)
     assert torch.equal(dst2, src)
-    # the same through one batched launch (ragged shapes, grouped matrices, both orientations)
+    # the same through one batched launch (ragged shapes, grouped matrices; plain / transposed / both per job)
     srcs = [rnd(3, 70, 45, seed=87), rnd(33, 100, seed=88), rnd(1, 5, 7, seed=89), rnd(64, 16, seed=90)]
-    jobs, want = [], []
+    jobs = []
     for i, sm in enumerate(srcs):
-        tr = i % 2 == 0
-        shape = (*sm.shape[:-2], sm.shape[-1], sm.shape[-2]) if tr else sm.shape
-        d = torch.zeros(shape, dtype=torch.float16, device=dev())
-        jobs.append((sm, d, tr))
-        want.append((sm.transpose(-1, -2) if tr else sm).to(torch.float16))
+        tshape = (*sm.shape[:-2], sm.shape[-1], sm.shape[-2])
+        plain = torch.zeros(sm.shape, dtype=torch.float16, device=dev()) if i != 1 else None
+        tr = torch.zeros(tshape, dtype=torch.float16, device=dev()) if i != 2 else None
+        jobs.append((sm, plain, tr))
     ops.CastPlan(jobs, torch.float16).run()
-    for (_, d, _), w_ in zip(jobs, want):
-        assert torch.equal(d, w_)
+    for sm, plain, tr in jobs:
+        if plain is not None:
+            assert torch.equal(plain, sm.to(torch.float16))
+        if tr is not None:
+            assert torch.equal(tr, sm.transpose(-1, -2).to(torch.float16))
     img = rnd(2, 3, 32, 48, seed=82)
     P = 16
     rows = torch.empty(2 * 2 * 3, 3 * P * P, dtype=torch.float32, device=dev())
