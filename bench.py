@@ -146,114 +146,22 @@ def main():
 
     from m3vit_amd import ops
     from m3vit_amd.config import VIT_SMALL_MOE, BackboneConfig, init_params
-    from m3vit_amd.engine import BackboneEngine
+    from m3vit_amd.step import MultiTaskStep
 
     cfg = BackboneConfig(**VIT_SMALL_MOE)
     dtype = torch.float16 if args.dtype == "f16" else torch.float32
     params = init_params(cfg, seed=1)                       # same weights on every rank
-    use_ep = args.ep and world > 1
-    wg_stream = args.wgrad_streams and not use_ep
-    eng = BackboneEngine(cfg, params, batch=args.batch, dtype=dtype, device=str(dev),
-                         ep_world=world if use_ep else 1, ep_rank=rank if use_ep else 0, wgrad_stream=wg_stream)
+    # m3vit_amd/step.py: one engine context + HIP stream per task pass, hipGraph capture, and for N > 1 the
+    # all-reduce of the upper blocks' gradients overlapped with the lower blocks' backward
+    runner = MultiTaskStep(cfg, params, batch=args.batch, dtype=dtype, device=str(dev), cv_weight=CV_WEIGHT,
+                           parallel_tasks=not args.serial_tasks, graph=not args.no_graph, world=world, rank=rank,
+                           expert_parallel=args.ep, wgrad_streams=args.wgrad_streams)
+    use_ep, par_tasks, ntasks = runner.use_ep, runner.par, len(runner.tasks)
     g = torch.Generator().manual_seed(1000 + rank)          # each rank its own images
     images = torch.randn(args.batch, 3, *cfg.img_size, generator=g).to(dev)
     dtok = (torch.randn(args.batch, cfg.num_tokens, cfg.embed_dim, generator=g) * 0.05).to(dev)
-    ntasks = cfg.num_tasks
-
-    flat = eng.flat_grads                                   # one flat fp32 gradient buffer
-    # The task passes of one step are independent until their gradients are added (models/models.py:299-301
-    # runs them one after the other): give each its own engine context (activations, scratch, gradient
-    # buffer; parameters and operand copies shared) and its own HIP stream, so that kernels of different
-    # passes overlap (one pass's store-bound phases under the other's MFMA phases, and the ragged last
-    # round of workgroups of one kernel filled by the other's).
-    par_tasks = (not args.serial_tasks) and not use_ep and ntasks > 1
-    engs = [eng] + [BackboneEngine(cfg, None, batch=args.batch, dtype=dtype, device=str(dev), share=eng,
-                                   wgrad_stream=wg_stream) for _ in range(ntasks - 1)] if par_tasks else [eng]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(ntasks - 1)] if par_tasks else []
-
-    def serial_step():
-        eng.prepare_weights()
-        eng.zero_grad()
-        for task in range(ntasks):
-            eng.forward(images, task)
-            eng.backward(dtok, cv_weight=CV_WEIGHT)
-
-    def run_tasks(fn_per_engine):
-        """fn(engine, task) for every task pass, each on its own stream (or serially), joined on the current stream"""
-        if not par_tasks:
-            for task in range(ntasks):
-                fn_per_engine(eng, task)
-            return
-        main = torch.cuda.current_stream()
-        for st in streams:
-            st.wait_stream(main)
-        for task in range(ntasks):
-            with torch.cuda.stream(main if task == 0 else streams[task - 1]):
-                fn_per_engine(engs[task], task)
-        for st in streams:
-            main.wait_stream(st)
-
-    def fwd_bwd_upper(e, task):
-        e.zero_grad()
-        e.forward(images, task)
-        e.backward_begin(dtok, cv_weight=CV_WEIGHT)
-        e.backward_blocks(e.depth - 1, e.split_block)
-        e.backward_sync_wgrad()
-
-    def bwd_lower(e, task):
-        e.backward_blocks(e.split_block - 1, 0)
-        e.backward_end()
-
-    def add_slices(lo, hi):
-        for e in engs[1:]:
-            ops.add_f32(flat[lo:hi], e.flat_grads[lo:hi])      # flat += gradients of the other passes
-
-    # A step in two halves, so that under data parallelism the all-reduce of the upper blocks' gradients
-    # (flat[:n_upper], final after part A) runs on RCCL's stream while part B computes.  With serial task
-    # passes the halves cannot be separated (pass 1's forward needs pass 0's backward to be over): one part.
-    two_parts = par_tasks and world > 1
-    n_up = eng.n_upper if two_parts else 0
-
-    def part_a():
-        eng.prepare_weights()
-        if two_parts:
-            run_tasks(fwd_bwd_upper)
-            add_slices(0, n_up)
-        elif par_tasks:
-            run_tasks(lambda e, t: (e.zero_grad(), e.forward(images, t), e.backward(dtok, cv_weight=CV_WEIGHT)))
-            add_slices(0, flat.numel())
-        else:
-            serial_body()
-
-    def part_b():
-        run_tasks(bwd_lower)
-        add_slices(n_up, flat.numel())
-
-    def serial_body():
-        eng.zero_grad()
-        for task in range(ntasks):
-            eng.forward(images, task)
-            eng.backward(dtok, cv_weight=CV_WEIGHT)
-
-    def compute_step():
-        part_a()
-        if two_parts:
-            part_b()
-
-    def sync_grads():
-        eng.sync_grads(world=world)                         # RCCL over xGMI; mean over ranks (experts stay local under EP)
-
-    def step():
-        if not two_parts:
-            compute_step()
-            sync_grads()
-            return
-        part_a()
-        w1 = dist.all_reduce(flat[:n_up], async_op=True)     # overlaps part B
-        part_b()
-        w2 = dist.all_reduce(flat[n_up:], async_op=True)
-        w1.wait(); w2.wait()
-        flat.div_(world)
+    runner.bind(images, dtok)                                # inputs resident in HBM before anything is timed
+    step, serial_step = runner.step_eager, runner.serial_step
 
     def barrier():
         if world > 1:
@@ -268,43 +176,14 @@ def main():
     step()
     torch.cuda.synchronize()
     log("first step done")
-    # The step is ~1100 dependent kernel launches with no host decisions in between: capture it once
-    # into a hipGraph and replay it (the launch-bound inner loop is the graph, not the Python loop).
-    run = step
-    graph = None
-    if not args.no_graph and not use_ep and not wg_stream:       # EP reads the per-layer counts on the host: not capturable
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                compute_step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                part_a()
-            graph_b = None
-            if two_parts:
-                graph_b = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_b):
-                    part_b()
-
-            def run():                                      # collectives stay outside the graphs
-                graph.replay()
-                if graph_b is None:
-                    sync_grads()
-                    return
-                w1 = dist.all_reduce(flat[:n_up], async_op=True)
-                graph_b.replay()
-                w2 = dist.all_reduce(flat[n_up:], async_op=True)
-                w1.wait(); w2.wait()
-                flat.div_(world)
-            log("step captured into a hipGraph" + (" (two halves around the first all-reduce)" if two_parts else ""))
-        except Exception as e:          # capture is an optimisation, never a requirement
-            graph = None
-            run = step
-            torch.cuda.synchronize()
-            log(f"graph capture unavailable ({type(e).__name__}: {e}); running eagerly")
+    # The step is ~760 dependent kernel launches with no host decisions in between: capture it once
+    # into hipGraph(s) and replay (the launch-bound inner loop is the graph, not the Python loop).
+    if runner.capture():
+        log("step captured into a hipGraph" + (" (two halves around the first all-reduce)" if runner.two_parts else ""))
+    elif runner.want_graph:
+        log("graph capture unavailable; running eagerly")
+    run = runner.step
+    graph = runner.graph_a
     for i in range(args.warmup):
         run()
     barrier()
@@ -389,8 +268,8 @@ def main():
         "config": {"workload": "configs[1]: ViT-Small/16 + MoE E=16 top-k=4 multi_gate, synthetic 224x224",
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "task_passes": ntasks,
                    "tokens_per_image": cfg.num_tokens, "cv_loss_weight": CV_WEIGHT,
-                   "launch": "hipGraph replay" if graph is not None else "eager",
-                   "task_streams": ntasks if par_tasks else 1, "wgrad_streams": len(engs) if wg_stream else 0,
+                   "launch": runner.launch,
+                   "task_streams": ntasks if par_tasks else 1, "wgrad_streams": len(runner.engs) if args.wgrad_streams else 0,
                    "parallelism": "single" if world == 1 else (f"dp{world}+ep{world} (experts sharded, RCCL all-to-all + all-reduce)"
                                                                     if use_ep else f"dp{world} (replicated experts, RCCL all-reduce)")},
         "model_tflops": round(step_flops * args.steps / dt / 1e12 * world, 2),

@@ -270,3 +270,33 @@ def test_split_backward_and_gradient_slices():
         b.backward_end()
         torch.cuda.synchronize()
         assert torch.equal(b.flat_grads, a.flat_grads)
+
+
+def test_multitask_step_runner_graph_and_streams_match_serial():
+    """m3vit_amd.step.MultiTaskStep (what bench.py drives): task passes on their own streams inside a replayed
+    hipGraph give the gradients of the serial reference order, step after step."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from m3vit_amd.step import MultiTaskStep
+    from oracle import ref_torch as R
+    cfg = R.BackboneCfg(img_size=(64, 64), embed_dim=64, depth=4, num_heads=2, mlp_ratio=4.0, moe_mlp_ratio=1.0,
+                        moe_experts=8, moe_top_k=2, gate_dim=67, multi_gate=True)            # 3 task passes
+    P = R.init_backbone_params(cfg, seed=4)
+    torch.manual_seed(9)
+    img = torch.randn(4, 3, 64, 64).cuda()
+    dtok = (torch.randn(4, cfg.num_tokens, 64) * 0.1).cuda()
+    run = MultiTaskStep(cfg, P, batch=4, dtype=torch.float16, cv_weight=0.01)
+    assert len(run.engs) == 3 and run.tasks == [0, 1, 2] and not run.two_parts
+    run.bind(img, dtok)
+    run.serial_step()
+    torch.cuda.synchronize()
+    want = run.flat.clone()
+    run.step()                                   # eager, three streams
+    torch.cuda.synchronize()
+    assert rel(run.flat, want) < 1e-5
+    assert run.capture() and run.launch == "hipGraph replay"
+    for _ in range(2):
+        run.flat.fill_(7.0)                      # the graph must rebuild the gradients from scratch
+        run.step()
+        torch.cuda.synchronize()
+        assert rel(run.flat, want) < 1e-5

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-GPU step times of the OTHER BASELINE configs' shapes (they are parity-test cases, not bench lines; this is
-orientation for the next rounds).  One step = refresh operand copies + forward + backward of every task pass,
-eager launch on one stream, fp16 activations.
+orientation for the next rounds).  One step = refresh operand copies + forward + backward of every task pass
+(m3vit_amd.step.MultiTaskStep: one stream per task pass, hipGraph replay), fp16 activations.
     python tools/config_bench.py
 """
 import os
@@ -12,7 +12,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from m3vit_amd.config import BackboneConfig, init_params  # noqa: E402
-from m3vit_amd.engine import BackboneEngine  # noqa: E402
+from m3vit_amd.step import MultiTaskStep  # noqa: E402
 
 CASES = [
     ("configs[2] ViT-S task-conditioned, 5 tasks, 8 x 512x512", 8, dict(img_size=(512, 512), embed_dim=384, depth=12,
@@ -24,26 +24,23 @@ CASES = [
 ]
 for name, B, kw, ntasks in CASES:
     cfg = BackboneConfig(**kw)
-    eng = BackboneEngine(cfg, init_params(cfg, seed=1), batch=B, dtype=torch.float16)
-    img = torch.randn(B, 3, *cfg.img_size).cuda()
-    dtok = (torch.randn(B, cfg.num_tokens, cfg.embed_dim) * 0.05).cuda()
-
-    def step():
-        eng.prepare_weights()
-        eng.zero_grad()
-        for t in range(ntasks):
-            eng.forward(img, t if (cfg.multi_gate or cfg.gate_task_specific_dim >= 0) else None)
-            eng.backward(dtok, cv_weight=0.01)
+    tasks = list(range(ntasks)) if (cfg.multi_gate or cfg.gate_task_specific_dim >= 0) else [None]
+    run = MultiTaskStep(cfg, init_params(cfg, seed=1), batch=B, dtype=torch.float16, tasks=tasks)
+    run.bind(torch.randn(B, 3, *cfg.img_size).cuda(), (torch.randn(B, cfg.num_tokens, cfg.embed_dim) * 0.05).cuda())
+    run.step()
+    torch.cuda.synchronize()
+    run.capture()
     for _ in range(2):
-        step()
+        run.step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n = 5
     for _ in range(n):
-        step()
+        run.step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     fl = 3.0 * cfg.fwd_flops_per_image() * B * ntasks
-    print(f"{name}: {dt * 1e3:7.1f} ms/step  {B / dt:7.0f} img/s  model {fl / dt / 1e12:5.0f} TFLOP/s", flush=True)
-    del eng
+    print(f"{name}: {dt * 1e3:7.1f} ms/step  {B / dt:7.0f} img/s  model {fl / dt / 1e12:5.0f} TFLOP/s  ({run.launch}, "
+          f"{len(run.engs)} stream(s))", flush=True)
+    del run
     torch.cuda.empty_cache()
