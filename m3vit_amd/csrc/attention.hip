@@ -415,8 +415,12 @@ static size_t attn_bwd_lds() {
 // short-sequence fp16 variants (attention_res.hip)
 int launch_attention_fwd_res(const void *qkv, int B, int N, int heads, int dh, void *o, float *lse, float scale,
                              hipStream_t s);
+int launch_attention_fwd_stream(const void *qkv, int B, int N, int heads, int dh, void *o, float *lse, float scale,
+                                hipStream_t s);
 int launch_attention_bwd_res(const void *qkv, const void *o, const void *d_o, const float *lse, int B, int N, int heads,
                              int dh, void *dqkv, float scale, hipStream_t s);
+int launch_attention_bwd_stream(const void *qkv, const void *o, const void *d_o, const float *lse, int B, int N, int heads,
+                                int dh, void *dqkv, float *dq_ws, float scale, hipStream_t s);
 constexpr int ATTN_RES_MAXN = 256;
 
 }  // namespace m3
@@ -434,6 +438,7 @@ extern "C" int m3_attention_fwd(const void *qkv, int dtype, int B, int N, int he
   const float scale = 1.0f / sqrtf((float)dh);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == M3_F16 && N <= ATTN_RES_MAXN) return launch_attention_fwd_res(qkv, B, N, heads, dh, o, lse, scale, s);
+  if (dtype == M3_F16) return launch_attention_fwd_stream(qkv, B, N, heads, dh, o, lse, scale, s);
 #define M3_AF(TT, DD) \
   hipLaunchKernelGGL((attention_fwd_kernel<TT, DD>), grid, block, 0, s, (const TT *)qkv, B, N, heads, (TT *)o, lse, scale)
   if (dtype == M3_F16) { if (dh == 32) M3_AF(half_t, 32); else M3_AF(half_t, 64); }
@@ -464,7 +469,8 @@ static int launch_attn_bwd(const void *qkv, const void *o, const void *d_o, cons
 }
 
 extern "C" int64_t m3_attention_bwd_ws_elems(int B, int N, int heads, int dh) {
-  return N > AB_KEYS ? (int64_t)((N + AB_KEYS - 1) / AB_KEYS) * B * heads * N * dh : 0;
+  // dQ slabs [key block][B*heads][N][dh] + delta [B*N*heads] (fp16 long-sequence kernel)
+  return N > AB_KEYS ? (int64_t)((N + AB_KEYS - 1) / AB_KEYS) * B * heads * N * dh + (int64_t)B * N * heads : 0;
 }
 
 extern "C" int m3_attention_bwd(const void *qkv, const void *o, const void *d_o, const float *lse, int dtype, int B,
@@ -479,6 +485,15 @@ extern "C" int m3_attention_bwd(const void *qkv, const void *o, const void *d_o,
   hipStream_t s = (hipStream_t)stream;
   if (dtype == M3_F16 && N <= ATTN_RES_MAXN)
     return launch_attention_bwd_res(qkv, o, d_o, lse, B, N, heads, dh, dqkv, scale, s);
+  if (dtype == M3_F16) {
+    int rc = launch_attention_bwd_stream(qkv, o, d_o, lse, B, N, heads, dh, dqkv, dq_ws, scale, s);
+    if (rc) return rc;
+    const int nkb = (N + AB_KEYS - 1) / AB_KEYS;
+    const int64_t n4 = (int64_t)B * heads * N * dh / 4;
+    hipLaunchKernelGGL((attention_dq_reduce_kernel<half_t>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dq_ws, nkb, B,
+                       N, heads, dh, (half_t *)dqkv);
+    return check_launch("m3_attention_bwd(dq reduce)");
+  }
   if (dtype == M3_F16) {
     if (dh == 32) return launch_attn_bwd<half_t, 32>(qkv, o, d_o, lse, B, N, heads, dqkv, dq_ws, scale, s);
     return launch_attn_bwd<half_t, 64>(qkv, o, d_o, lse, B, N, heads, dqkv, dq_ws, scale, s);

@@ -333,6 +333,383 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
   }
 }
 
+// -------------------------------------------------------------------- forward, long sequences
+// N > 256: one workgroup per (image, head, 64-query block); wave w owns the 16 queries q0 + 16w.  K / V are streamed in
+// 64-key tiles through a two-slot ring of swizzled LDS images (rows prefetched into registers one tile ahead, one
+// barrier per tile), online softmax in the S^T accumulator layout, V read transposed with ds_read_b64_tr_b16.
+template <int DH>
+__global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_stream_kernel(const half_t *__restrict__ qkv, int N, int heads,
+                                                                              half_t *__restrict__ o,
+                                                                              float *__restrict__ lse, float scale) {
+  constexpr int RBY = DH * 2, CPR = RBY / 16, NCH = DH / 32, NDT = DH / 16;
+  constexpr int KT = 64;                              // keys per tile
+  constexpr int NLD = KT * CPR / AR_THREADS;          // chunks per thread per operand per tile (1 / 2)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *sK = smem, *sV = smem + 2 * KT * RBY;         // [2][64][RBY] each
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int nqb = gridDim.x;
+  const int log_id = xcd_remap(blockIdx.x + nqb * blockIdx.y, nqb * gridDim.y);
+  const int qb = log_id % nqb;
+  const int bh = log_id / nqb, b = bh / heads, h = bh - b * heads;
+  const int C = heads * DH;
+  const int64_t ld = 3 * (int64_t)C;
+  const half_t *qbase = qkv + (int64_t)b * N * ld + h * DH;
+  const half_t *kbase = qbase + C, *vbase = qbase + 2 * C;
+
+  const int qrow = qb * 64 + wave * 16 + li;
+  f16x8 qf[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    qf[ch] = Mma<half_t>::zero();
+    if (qrow < N) qf[ch] = *(const f16x8 *)(qbase + (int64_t)qrow * ld + ch * 32 + 8 * lg);
+  }
+  u32x4 rk[NLD], rv[NLD];
+  auto fetch = [&](int key0) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int q = tid + AR_THREADS * i, row = q / CPR, c = q % CPR;
+      rk[i] = u32x4{0u, 0u, 0u, 0u};
+      rv[i] = u32x4{0u, 0u, 0u, 0u};
+      if (key0 + row < N) {
+        rk[i] = *(const u32x4 *)((const char *)(kbase + (int64_t)(key0 + row) * ld) + c * 16);
+        rv[i] = *(const u32x4 *)((const char *)(vbase + (int64_t)(key0 + row) * ld) + c * 16);
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int q = tid + AR_THREADS * i, row = q / CPR, c = q % CPR;
+      *(u32x4 *)(sK + buf * KT * RBY + swo<DH>(row, c * 16)) = rk[i];
+      *(u32x4 *)(sV + buf * KT * RBY + swo<DH>(row, c * 16)) = rv[i];
+    }
+  };
+  fetch(0);
+  stash(0);
+  __syncthreads();
+
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 oacc[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) oacc[dt] = zero4;
+  const float c1 = scale * AR_LOG2E;
+  float m_run = -INFINITY, l_run = 0.f;             // running max of the raw scores, running sum of exp2
+  const int ntiles = (N + KT - 1) / KT;
+  for (int t = 0; t < ntiles; ++t) {
+    const int key0 = t * KT, buf = t & 1;
+    const bool more = t + 1 < ntiles;
+    if (more) fetch(key0 + KT);
+    const char *cK = sK + buf * KT * RBY, *cV = sV + buf * KT * RBY;
+    // S^T tiles: st[kt][r] = S[q = li][key = key0 + 16*kt + 4*lg + r]
+    f32x4 st[4];
+    float mt = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4 sv = zero4;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) sv = mma16(row_frag<DH>(cK, kt * 16, ch, li, lg), qf[ch], sv);
+      if (!more) {                                   // only the last tile can hold keys >= N
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[r] = (key0 + kt * 16 + 4 * lg + r < N) ? sv[r] : -INFINITY;
+      }
+      mt = fmaxf(fmaxf(mt, fmaxf(sv[0], sv[1])), fmaxf(sv[2], sv[3]));
+      st[kt] = sv;
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c1);
+    const float mc = m_new * c1;
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(st[kt][r] * c1 - mc);
+        st[kt][r] = p;
+        psum += p;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) oacc[dt] *= alpha;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const f16x8 pf = Mma<half_t>::from_tiles(&st[cc * 2]);
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) oacc[dt] = mma16(tr_frag<DH>(cV, cc * 32, dt * 16, li, lg), pf, oacc[dt]);
+    }
+    if (more) stash(buf ^ 1);                        // that slot was last read before the previous barrier
+    __syncthreads();
+  }
+  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+  if (qrow < N) {
+    const float inv = 1.0f / l_tot;
+    half_t *orow = o + ((int64_t)b * N + qrow) * C + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) Vec4<half_t>::store(orow + dt * 16 + 4 * lg, oacc[dt] * inv);
+    if (lg == 0) lse[((int64_t)b * heads + h) * N + qrow] = m_run * scale + __logf(l_tot);
+  }
+}
+
+int launch_attention_fwd_stream(const void *qkv, int B, int N, int heads, int dh, void *o, float *lse, float scale,
+                                hipStream_t s) {
+  const dim3 grid((N + 63) / 64, B * heads);
+  const size_t lds = (size_t)4 * 64 * dh * 2;
+  if (dh == 32)
+    hipLaunchKernelGGL(attention_fwd_stream_kernel<32>, grid, dim3(AR_THREADS), lds, s, (const half_t *)qkv, N, heads,
+                       (half_t *)o, lse, scale);
+  else
+    hipLaunchKernelGGL(attention_fwd_stream_kernel<64>, grid, dim3(AR_THREADS), lds, s, (const half_t *)qkv, N, heads,
+                       (half_t *)o, lse, scale);
+  return check_launch("m3_attention_fwd");
+}
+
+// ------------------------------------------------------------------- backward, long sequences
+// N > 256: one workgroup per (image, head, 256-key block).  The key block's K image stays in LDS, its K / V
+// fragments and dK^T / dV^T in registers; the queries are swept in 32-row steps whose Q / dO rows are prefetched one
+// step ahead (registers -> the other half of a two-slot LDS ring, visible after the step's single barrier).
+// delta[q] = <dO[q], O[q]> comes from a row kernel run once per call; the key block's dQ contribution goes to an fp32
+// slab summed in key-block order by attention_dq_reduce_kernel (attention.hip).
+template <int DH>
+__global__ __launch_bounds__(64) void attention_delta_kernel(const half_t *__restrict__ o, const half_t *__restrict__ d_o,
+                                                             int64_t rows, int heads, float *__restrict__ delta) {
+  // one wave per 64 (token, head) rows; delta laid out [token][head]
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= rows * heads) return;
+  const half_t *po = o + i * DH, *pd = d_o + i * DH;
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < DH / 8; ++c) {
+    const f16x8 a = *(const f16x8 *)(po + c * 8), b = *(const f16x8 *)(pd + c * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)b[j];
+  }
+  delta[i] = s;
+}
+
+template <int DH>
+__global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attention_bwd_stream_kernel(
+    const half_t *__restrict__ qkv, const half_t *__restrict__ d_o, const float *__restrict__ lse,
+    const float *__restrict__ delta, int N, int heads, half_t *__restrict__ dqkv, float *__restrict__ dq_ws, float scale) {
+  constexpr int RBY = DH * 2, CPR = RBY / 16, NCH = DH / 32, NDT = DH / 16;
+  constexpr int NW = DH == 32 ? 4 : 8, NT = NW * 64, KTW = 16 / NW, KB = 256;
+  static_assert(2 * NDT == NW && 32 * CPR * 2 == NT, "one dQ piece and one staged chunk per thread");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *sK = smem;                                     // [256 keys][RBY]
+  char *sQ = sK + KB * RBY;                            // [2][32 rows][RBY]
+  char *sdO = sQ + 2 * 32 * RBY;
+  char *sdS = sdO + 2 * 32 * RBY;                      // [2][256 keys][64 B]
+  float *sLse = (float *)(sdS + 2 * KB * 64);          // [2][32]: lse * log2(e)
+  float *sDelta = sLse + 64;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int nkb = (N + KB - 1) / KB;
+  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = wid / nkb, kbi = wid - bh * nkb, b = bh / heads, h = bh - b * heads;
+  const int kb0 = kbi * KB;
+  const int C = heads * DH;
+  const int64_t ld = 3 * (int64_t)C;
+  const half_t *qbase = qkv + (int64_t)b * N * ld + h * DH;
+  const half_t *kbase = qbase + C, *vbase = qbase + 2 * C;
+  const half_t *dobase = d_o + (int64_t)b * N * C + h * DH;
+  half_t *dqbase = dqkv + (int64_t)b * N * ld + h * DH;
+  const float *lbase = lse + ((int64_t)b * heads + h) * N;
+  const float *dbase = delta + (int64_t)b * N * heads + h;             // [token][head]
+  float *dqw = dq_ws + ((int64_t)kbi * (gridDim.x / nkb) + bh) * N * DH;
+  const int nkeys = (N - kb0 < KB) ? N - kb0 : KB;
+  const int nkt = (nkeys + 15) >> 4;                  // valid key tiles of this block
+  const int nkc = (nkeys + 31) >> 5;                  // 32-key chunks that matter for dQ
+
+  // ---- K image of the key block, zero the dS^T images
+  for (int q = tid; q < KB * CPR; q += NT) {
+    const int row = q / CPR, c = q % CPR;
+    u32x4 kv = u32x4{0u, 0u, 0u, 0u};
+    if (row < nkeys) kv = *(const u32x4 *)((const char *)(kbase + (int64_t)(kb0 + row) * ld) + c * 16);
+    *(u32x4 *)(sK + swo<DH>(row, c * 16)) = kv;
+  }
+  for (int q = tid; q < 2 * KB * 4; q += NT) *(u32x4 *)(sdS + q * 16) = u32x4{0u, 0u, 0u, 0u};
+  f16x8 kf[KTW][NCH], vf[KTW][NCH];
+#pragma unroll
+  for (int kt = 0; kt < KTW; ++kt) {
+    const int key = kb0 + (kt * NW + wave) * 16 + li;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      kf[kt][ch] = Mma<half_t>::zero();
+      vf[kt][ch] = Mma<half_t>::zero();
+      if (key < N) {
+        kf[kt][ch] = *(const f16x8 *)(kbase + (int64_t)key * ld + ch * 32 + 8 * lg);
+        vf[kt][ch] = *(const f16x8 *)(vbase + (int64_t)key * ld + ch * 32 + 8 * lg);
+      }
+    }
+  }
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 dkt[NDT][KTW], dvt[NDT][KTW];
+#pragma unroll
+  for (int a = 0; a < NDT; ++a)
+#pragma unroll
+    for (int c = 0; c < KTW; ++c) { dkt[a][c] = zero4; dvt[a][c] = zero4; }
+
+  // staging assignment: thread -> one 16-byte chunk of the step: first half of the threads Q, second half dO
+  const int half_t_ = NT / 2;
+  const bool is_do = tid >= half_t_;
+  const int sq = is_do ? tid - half_t_ : tid;          // 0 .. 32*CPR-1
+  const int srow = sq / CPR, sc = sq % CPR;
+  auto fetch = [&](int qs, u32x4 &v, float &l2, float &dl) {
+    const int qr = qs + srow;
+    v = u32x4{0u, 0u, 0u, 0u};
+    if (qr < N) {
+      if (is_do) v = *(const u32x4 *)((const char *)(dobase + (int64_t)qr * C) + sc * 16);
+      else v = *(const u32x4 *)((const char *)(qbase + (int64_t)qr * ld) + sc * 16);
+    }
+    l2 = 1e30f; dl = 0.f;                               // padded query rows: P = exp2(-huge) = 0
+    if (tid < 32 && qs + tid < N) { l2 = lbase[qs + tid] * AR_LOG2E; dl = dbase[(int64_t)(qs + tid) * heads]; }
+  };
+  auto stash = [&](int buf, const u32x4 &v, float l2, float dl) {
+    *(u32x4 *)((is_do ? sdO : sQ) + buf * 32 * RBY + swo<DH>(srow, sc * 16)) = v;
+    if (tid < 32) { sLse[buf * 32 + tid] = l2; sDelta[buf * 32 + tid] = dl; }
+  };
+  {
+    u32x4 v; float l2, dl;
+    fetch(0, v, l2, dl);
+    stash(0, v, l2, dl);
+  }
+  __syncthreads();
+
+  const float c1 = scale * AR_LOG2E;
+  const int nsteps = (N + 31) >> 5;
+  for (int st = 0; st < nsteps; ++st) {
+    const int qs = st * 32, buf = st & 1;
+    const char *cQ = sQ + buf * 32 * RBY, *cdO = sdO + buf * 32 * RBY;
+    char *dsb = sdS + buf * KB * 64;
+    u32x4 nv; float nl2, ndl;
+    const bool more = st + 1 < nsteps;
+    if (more) fetch(qs + 32, nv, nl2, ndl);            // rows of the next step: in flight under this step's MFMAs
+    // ---- S, dP -> P, dS (unscaled) for this wave's key tiles;  D[q = 4*lg + r][key = li]
+    f32x4 pt[2][KTW], dst[2][KTW];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      f16x8 qfr[NCH], dof[NCH];
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        qfr[ch] = row_frag<DH>(cQ, qt * 16, ch, li, lg);
+        dof[ch] = row_frag<DH>(cdO, qt * 16, ch, li, lg);
+      }
+      float l2[4], dl[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { l2[r] = sLse[buf * 32 + qt * 16 + 4 * lg + r]; dl[r] = sDelta[buf * 32 + qt * 16 + 4 * lg + r]; }
+#pragma unroll
+      for (int kt = 0; kt < KTW; ++kt) {
+        const int tix = kt * NW + wave;
+        if (tix < nkt) {
+          f32x4 s = zero4, dp = zero4;
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch) {
+            s = mma16(qfr[ch], kf[kt][ch], s);
+            dp = mma16(dof[ch], vf[kt][ch], dp);
+          }
+          f32x4 pv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r] * c1 - l2[r]);
+          if (tix == nkt - 1 && tix * 16 + li >= nkeys) pv = zero4;      // keys past N live in the last tile only
+          pt[qt][kt] = pv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[qt][kt][r] = pv[r] * (dp[r] - dl[r]);
+        } else {
+          pt[qt][kt] = zero4;
+          dst[qt][kt] = zero4;
+        }
+      }
+    }
+    // ---- dV^T += dO^T P ; dK^T += Q^T dS   (contraction over the 32 queries of the step)
+    {
+      f16x8 aq[NDT], ado[NDT];
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        aq[dt] = tr_frag<DH>(cQ, 0, dt * 16, li, lg);
+        ado[dt] = tr_frag<DH>(cdO, 0, dt * 16, li, lg);
+      }
+#pragma unroll
+      for (int kt = 0; kt < KTW; ++kt) {
+        if (kt * NW + wave < nkt) {
+          f32x4 tp[2] = {pt[0][kt], pt[1][kt]}, td[2] = {dst[0][kt], dst[1][kt]};
+          const f16x8 pf = Mma<half_t>::from_tiles(tp), dsf = Mma<half_t>::from_tiles(td);
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) {
+            dvt[dt][kt] = mma16(ado[dt], pf, dvt[dt][kt]);
+            dkt[dt][kt] = mma16(aq[dt], dsf, dkt[dt][kt]);
+          }
+          const int krow = (kt * NW + wave) * 16 + li;
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) {
+            f16x4 v = f16x4{(half_t)dst[qt][kt][0], (half_t)dst[qt][kt][1], (half_t)dst[qt][kt][2], (half_t)dst[qt][kt][3]};
+            *(f16x4 *)(dsb + swo<32>(krow, (qt * 16 + 4 * lg) * 2)) = v;
+          }
+        }
+      }
+    }
+    if (more) stash(buf ^ 1, nv, nl2, ndl);     // the other ring slot was last read before the previous barrier
+    __syncthreads();                            // dS^T of this step and the next step's rows are visible
+    // ---- dQ^T[d][q] contribution of this key block, one (qt, dt) piece per wave -> fp32 slab
+    {
+      const int qt = wave / NDT, dt = wave - qt * NDT;
+      f32x4 acc = zero4;
+      for (int c = 0; c < nkc; ++c)
+        acc = mma16(tr_frag<DH>(sK, c * 32, dt * 16, li, lg), tr_frag<32>(dsb, c * 32, qt * 16, li, lg), acc);
+      const int qr = qs + qt * 16 + li;
+      if (qr < N) *(f32x4 *)(dqw + (int64_t)qr * DH + dt * 16 + 4 * lg) = acc * scale;
+    }
+  }
+
+  // ---- dK, dV rows of this wave's keys
+#pragma unroll
+  for (int kt = 0; kt < KTW; ++kt) {
+    const int key = kb0 + (kt * NW + wave) * 16 + li;
+    if (key < N) {
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        Vec4<half_t>::store(dqbase + C + (int64_t)key * ld + dt * 16 + 4 * lg, dkt[dt][kt] * scale);
+        Vec4<half_t>::store(dqbase + 2 * C + (int64_t)key * ld + dt * 16 + 4 * lg, dvt[dt][kt]);
+      }
+    }
+  }
+}
+
+size_t attn_stream_bwd_lds(int dh) { return (size_t)256 * dh * 2 + 4 * 32 * dh * 2 + 2 * 256 * 64 + 128 * sizeof(float); }
+
+// dq_ws: [nkb][B*heads][N][dh] slabs followed by delta [B*N*heads]
+int launch_attention_bwd_stream(const void *qkv, const void *o, const void *d_o, const float *lse, int B, int N, int heads,
+                                int dh, void *dqkv, float *dq_ws, float scale, hipStream_t s) {
+  const int nkb = (N + 255) / 256;
+  float *delta = dq_ws + (int64_t)nkb * B * heads * N * dh;
+  const int64_t rows = (int64_t)B * N;
+  const unsigned dblocks = (unsigned)((rows * heads + 63) / 64);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)attention_bwd_stream_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)attn_stream_bwd_lds(32));
+    (void)hipFuncSetAttribute((const void *)attention_bwd_stream_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)attn_stream_bwd_lds(64));
+    attr_set = true;
+  }
+  if (dh == 32) {
+    hipLaunchKernelGGL(attention_delta_kernel<32>, dim3(dblocks), dim3(64), 0, s, (const half_t *)o, (const half_t *)d_o, rows,
+                       heads, delta);
+    hipLaunchKernelGGL(attention_bwd_stream_kernel<32>, dim3(B * heads * nkb), dim3(256), attn_stream_bwd_lds(32), s,
+                       (const half_t *)qkv, (const half_t *)d_o, lse, delta, N, heads, (half_t *)dqkv, dq_ws, scale);
+  } else {
+    hipLaunchKernelGGL(attention_delta_kernel<64>, dim3(dblocks), dim3(64), 0, s, (const half_t *)o, (const half_t *)d_o, rows,
+                       heads, delta);
+    hipLaunchKernelGGL(attention_bwd_stream_kernel<64>, dim3(B * heads * nkb), dim3(512), attn_stream_bwd_lds(64), s,
+                       (const half_t *)qkv, (const half_t *)d_o, lse, delta, N, heads, (half_t *)dqkv, dq_ws, scale);
+  }
+  return check_launch("m3_attention_bwd");
+}
+
 size_t attn_res_fwd_lds(int N, int dh) { return (size_t)2 * ((N + 31) & ~31) * dh * 2; }
 size_t attn_res_bwd_lds(int N, int dh) {
   const size_t np = (N + 31) & ~31;
