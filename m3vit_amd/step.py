@@ -144,13 +144,15 @@ class MultiTaskStep:
                 self.compute()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            # thread_local: other threads of the process (the RCCL watchdog of torch.distributed polls events)
+            # may keep making HIP calls while this thread captures
             ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
+            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                 self.part_a()
             gb = None
             if self.two_parts:
                 gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb):
+                with torch.cuda.graph(gb, capture_error_mode="thread_local"):
                     self.part_b()
             self.graph_a, self.graph_b = ga, gb
             return True
