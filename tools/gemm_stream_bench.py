@@ -15,6 +15,7 @@ from m3vit_amd import ops  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--ring", type=int, default=12)
 ap.add_argument("--iters", type=int, default=48)
+ap.add_argument("--only", default="")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 M = 128 * 197
@@ -35,6 +36,8 @@ def timeit(fn):
 
 for name, N, K, two_out in (("qkv", 1152, 384, False), ("proj", 384, 384, False), ("fc1+gelu+pre", 1536, 384, True),
                             ("fc2", 384, 1536, False)):
+    if a.only and name != a.only:
+        continue
     As = [torch.randn(M, K, device=dev).half() for _ in range(a.ring)]
     B = (torch.randn(N, K, device=dev) * 0.05).half()
     Cs = [torch.empty(M, N, dtype=torch.float16, device=dev) for _ in range(a.ring)]
