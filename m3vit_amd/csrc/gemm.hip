@@ -476,7 +476,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const Gemm
   }
 }
 
-
 }  // namespace m3
 
 using namespace m3;
