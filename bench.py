@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--dp-parts", type=int, default=6, help="N > 1, replicated experts: cut the step into this many graphs with an all-reduce behind each")
     ap.add_argument("--serial-tasks", action="store_true", help="run the task passes one after the other on one "
                     "stream (default: one HIP stream per task pass, gradients summed at the end)")
     ap.add_argument("--wgrad-streams", action="store_true", help="also launch the weight-gradient GEMMs of each "
@@ -155,7 +156,7 @@ def main():
     # all-reduce of the upper blocks' gradients overlapped with the lower blocks' backward
     runner = MultiTaskStep(cfg, params, batch=args.batch, dtype=dtype, device=str(dev), cv_weight=CV_WEIGHT,
                            parallel_tasks=not args.serial_tasks, graph=not args.no_graph, world=world, rank=rank,
-                           expert_parallel=args.ep, wgrad_streams=args.wgrad_streams)
+                           expert_parallel=args.ep, wgrad_streams=args.wgrad_streams, dp_parts=args.dp_parts)
     use_ep, par_tasks, ntasks = runner.use_ep, runner.par, len(runner.tasks)
     g = torch.Generator().manual_seed(1000 + rank)          # each rank its own images
     images = torch.randn(args.batch, 3, *cfg.img_size, generator=g).to(dev)
@@ -179,11 +180,10 @@ def main():
     # The step is ~760 dependent kernel launches with no host decisions in between: capture it once
     # into hipGraph(s) and replay (the launch-bound inner loop is the graph, not the Python loop).
     if runner.capture():
-        log("step captured into a hipGraph" + (" (two halves around the first all-reduce)" if runner.two_parts else ""))
+        log("step captured into a hipGraph" + (f" ({len(runner.graphs)} parts, an all-reduce behind each)" if runner.two_parts else ""))
     elif runner.want_graph:
         log("graph capture unavailable; running eagerly")
     run = runner.step
-    graph = runner.graph_a
     for i in range(args.warmup):
         run()
     barrier()

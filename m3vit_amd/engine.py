@@ -78,13 +78,14 @@ class BackboneEngine:
                 names = [n for n in params if not is_exp(n)] + [n for n in params if is_exp(n)]     # experts last
             else:
                 # replicated experts: everything is all-reduced, so order the flat buffer by WHEN a gradient is
-                # final in backward() - the parameters of the upper half of the blocks first (one contiguous
-                # slice that can be all-reduced while the lower half still runs), then the rest
-                names = [n for n in params if self._is_upper(n)] + [n for n in params if not self._is_upper(n)]
+                # final in backward() - blocks from the top down, then the embeddings: after
+                # backward_blocks(.., b) the prefix flat_grads[:grad_prefix(b)] is final and can be all-reduced
+                # while the blocks below still run
+                names = sorted(params, key=lambda n: -self._block_of(n))
             self.params = {n: (params[n][lo:hi] if (is_exp(n) and self.ep_world > 1) else params[n])
                            .to(self.dev, torch.float32).contiguous() for n in names}
         self.n_dense = sum(p.numel() for n, p in self.params.items() if not is_exp(n))
-        self.n_upper = 0 if self.ep_world > 1 else sum(p.numel() for n, p in self.params.items() if self._is_upper(n))
+        self.n_upper = self.grad_prefix(self.split_block)
         # one flat fp32 gradient buffer (views per parameter): zeroing is one memset and the data-parallel
         # sync is one RCCL all-reduce (xGMI is point-to-point: few large collectives)
         total = sum(p.numel() for p in self.params.values())
@@ -108,10 +109,16 @@ class BackboneEngine:
         """first block of the 'upper half' (its gradients occupy flat_grads[:n_upper])"""
         return self.cfg.depth // 2
 
-    def _is_upper(self, name: str) -> bool:
-        if not name.startswith("blocks."):
-            return False
-        return int(name.split(".")[1]) >= self.cfg.depth // 2
+    @staticmethod
+    def _block_of(name: str) -> int:
+        return int(name.split(".")[1]) if name.startswith("blocks.") else -1
+
+    def grad_prefix(self, block: int) -> int:
+        """number of leading elements of flat_grads that belong to blocks >= `block` (0 under expert parallelism,
+        where the buffer is ordered dense-first instead)"""
+        if self.ep_world > 1:
+            return 0
+        return sum(p.numel() for n, p in self.params.items() if self._block_of(n) >= block)
 
     # ------------------------------------------------------------------ buffers
     def _e(self, *shape, dtype=None):

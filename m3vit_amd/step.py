@@ -8,9 +8,11 @@ accumulated), laid out for the GPU:
   under another's MFMA phases, and the ragged last round of workgroups of one kernel is filled by the others';
 * the whole step (no host decisions) is captured into hipGraphs and replayed;
 * data parallel (replicated experts, the reference's --moe_data_distributed mode, utils/common_config.py:179-181):
-  the step is split in two graphs - A: forward + backward of the upper blocks, B: backward of the lower blocks - and
-  the all-reduce of the upper blocks' gradients (one contiguous slice of the flat buffer) is issued between them, so
-  it runs on RCCL's stream under graph B; the rest follows B.  Two large collectives per step.
+  the step is cut into `dp_parts` graphs - the first is the forward + the backward of the top blocks, the others the
+  backward of the next blocks down - and after each part the all-reduce of the gradients that part completed (one
+  contiguous slice of the flat buffer, ordered top block first) is issued asynchronously, so it runs on RCCL's
+  stream under the following parts; only the last slice's all-reduce is exposed.  `dp_parts` large collectives per step
+  (replicated experts make the gradient buffer ~0.5 GB: with 6 parts one MoE block's ~80 MB are left for the end).
 
 Expert-parallel runs (ep_world > 1) read per-layer counts on the host and therefore execute eagerly on one stream."""
 from __future__ import annotations
@@ -26,7 +28,7 @@ from .engine import BackboneEngine
 class MultiTaskStep:
     def __init__(self, cfg, params, batch: int, dtype=torch.float16, device="cuda:0", tasks=None, cv_weight: float = 0.01,
                  parallel_tasks: bool = True, graph: bool = True, world: int = 1, rank: int = 0, expert_parallel: bool = False,
-                 wgrad_streams: bool = False):
+                 wgrad_streams: bool = False, dp_parts: int = 6):
         self.cfg, self.dev, self.world, self.cv_weight = cfg, torch.device(device), int(world), float(cv_weight)
         if tasks is None:
             tasks = list(range(cfg.num_tasks)) if (cfg.multi_gate or cfg.gate_task_specific_dim >= 0) else [None]
@@ -41,11 +43,17 @@ class MultiTaskStep:
                                                    wgrad_stream=wg) for _ in self.tasks[1:]] if self.par else [])
         self.streams = [torch.cuda.Stream(device=self.dev) for _ in self.engs[1:]]
         self.flat = self.eng.flat_grads
-        # two halves only make sense when there is a collective to hide and the passes run side by side
-        self.two_parts = self.par and self.world > 1
-        self.n_up = self.eng.n_upper if self.two_parts else 0
+        # cutting the step only makes sense when there is a collective to hide and the passes run side by side
+        depth = self.eng.depth
+        nparts = max(1, min(int(dp_parts), depth)) if (self.par and self.world > 1) else 1
+        # part j runs blocks [lo_j, hi_j] of the backward (top down); its gradients are flat[seg_j[0]:seg_j[1]]
+        cuts = [depth - (depth * j) // nparts for j in range(1, nparts)]          # first block of parts 0..nparts-2
+        self.block_ranges = [(hi - 1, lo) for hi, lo in zip([depth] + cuts, cuts + [0])]
+        ends = [self.eng.grad_prefix(lo) for lo in cuts] + [self.flat.numel()]
+        self.segments = list(zip([0] + ends[:-1], ends))
+        self.two_parts = nparts > 1
         self.want_graph = bool(graph) and not self.use_ep and not wg     # ROCm 7.2 crashes capturing the wgrad-stream pattern
-        self.graph_a = self.graph_b = None
+        self.graphs = None
         self.images = self.dtok = None
 
     # ------------------------------------------------------------------ pieces
@@ -73,17 +81,21 @@ class MultiTaskStep:
         e.forward(self.images, t)
         e.backward(self.dtok, cv_weight=self.cv_weight)
 
-    def _upper(self, e, t):
-        e.zero_grad()
-        e.forward(self.images, t)
-        e.backward_begin(self.dtok, cv_weight=self.cv_weight)
-        e.backward_blocks(e.depth - 1, e.split_block)
-        e.backward_sync_wgrad()
+    def _part(self, j):
+        hi, lo = self.block_ranges[j]
+        last = j == len(self.block_ranges) - 1
 
-    @staticmethod
-    def _lower(e, t):
-        e.backward_blocks(e.split_block - 1, 0)
-        e.backward_end()
+        def fn(e, t):
+            if j == 0:
+                e.zero_grad()
+                e.forward(self.images, t)
+                e.backward_begin(self.dtok, cv_weight=self.cv_weight)
+            e.backward_blocks(hi, lo)
+            if last:
+                e.backward_end()
+            else:
+                e.backward_sync_wgrad()
+        return fn
 
     def serial_step(self):
         """the whole step on the current stream with one engine context (reference order)"""
@@ -92,46 +104,45 @@ class MultiTaskStep:
         for t in self.tasks:
             self._full(self.eng, t)
 
-    def part_a(self):
+    def part(self, j: int):
+        """part j of the step on the current stream (part 0 alone is the whole step unless the step is cut)"""
         if not self.par:
             return self.serial_step()
-        self.eng.prepare_weights()
-        if self.two_parts:
-            self._run_tasks(self._upper)
-            self._add(0, self.n_up)
-        else:
-            self._run_tasks(lambda e, t: (e.zero_grad(), self._full(e, t)))
-            self._add(0, self.flat.numel())
-
-    def part_b(self):
-        self._run_tasks(self._lower)
-        self._add(self.n_up, self.flat.numel())
+        if j == 0:
+            self.eng.prepare_weights()
+        self._run_tasks(self._part(j))
+        self._add(*self.segments[j])
 
     def compute(self):
-        self.part_a()
-        if self.two_parts:
-            self.part_b()
+        for j in range(len(self.block_ranges)):
+            self.part(j)
 
     # --------------------------------------------------------------- execution
     def bind(self, images: torch.Tensor, d_tokens: torch.Tensor):
         """the (device-resident) batch and upstream token gradients the step reads; graphs replay on these buffers"""
         self.images, self.dtok = images, d_tokens
 
-    def _collective_step(self, a, b):
-        import torch.distributed as dist
-        a()
+    def _collective_step(self, parts):
         if not self.two_parts:
+            parts[0]()
             self.eng.sync_grads(world=self.world)       # mean over ranks; the experts stay local under expert parallelism
             return
-        w1 = dist.all_reduce(self.flat[: self.n_up], async_op=True)      # overlaps part B
-        b()
-        w2 = dist.all_reduce(self.flat[self.n_up:], async_op=True)
-        w1.wait()
-        w2.wait()
+        import torch.distributed as dist
+        # RCCL queues the collectives in order on its own stream; gloo (CPU rehearsals) serves them from a pool of two
+        # worker threads and stalls with more than two outstanding
+        inflight = 2 if dist.get_backend() == "gloo" else len(parts)
+        works = []
+        for j, (run, (lo, hi)) in enumerate(zip(parts, self.segments)):
+            run()
+            if j >= inflight:
+                works[j - inflight].wait()
+            works.append(dist.all_reduce(self.flat[lo:hi], async_op=True))      # runs under the parts that follow
+        for w in works:
+            w.wait()
         self.flat.div_(self.world)
 
     def step_eager(self):
-        self._collective_step(self.part_a, self.part_b)
+        self._collective_step([lambda j=j: self.part(j) for j in range(len(self.block_ranges))])
 
     def capture(self) -> bool:
         """Capture the compute of a step into hipGraph(s).  Returns False (and stays eager) if capture is unavailable."""
@@ -146,27 +157,25 @@ class MultiTaskStep:
             torch.cuda.synchronize()
             # thread_local: other threads of the process (the RCCL watchdog of torch.distributed polls events)
             # may keep making HIP calls while this thread captures
-            ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
-                self.part_a()
-            gb = None
-            if self.two_parts:
-                gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb, capture_error_mode="thread_local"):
-                    self.part_b()
-            self.graph_a, self.graph_b = ga, gb
+            graphs = []
+            for j in range(len(self.block_ranges)):
+                gj = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gj, capture_error_mode="thread_local"):
+                    self.part(j)
+                graphs.append(gj)
+            self.graphs = graphs
             return True
         except Exception:          # capture is an optimisation, never a requirement
-            self.graph_a = self.graph_b = None
+            self.graphs = None
             torch.cuda.synchronize()
             return False
 
     def step(self):
         """one step: replay the captured graphs if there are any, else launch eagerly; collectives stay outside the graphs"""
-        if self.graph_a is None:
+        if self.graphs is None:
             return self.step_eager()
-        self._collective_step(self.graph_a.replay, self.graph_b.replay if self.graph_b is not None else None)
+        self._collective_step([g.replay for g in self.graphs])
 
     @property
     def launch(self) -> str:
-        return "hipGraph replay" if self.graph_a is not None else "eager"
+        return "hipGraph replay" if self.graphs is not None else "eager"
