@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--noisy", action="store_true", help="variant: noisy-gate training (vmoe_noisy_std = 1, caller-supplied noise, CDF load loss)")
+    ap.add_argument("--skew", action="store_true", help="variant: +8 on expert 0's gate logit - every token routes to it (4x the mean load)")
     ap.add_argument("--dp-parts", type=int, default=6, help="N > 1, replicated experts: cut the step into this many graphs with an all-reduce behind each")
     ap.add_argument("--serial-tasks", action="store_true", help="run the task passes one after the other on one "
                     "stream (default: one HIP stream per task pass, gradients summed at the end)")
@@ -161,7 +163,16 @@ def main():
     g = torch.Generator().manual_seed(1000 + rank)          # each rank its own images
     images = torch.randn(args.batch, 3, *cfg.img_size, generator=g).to(dev)
     dtok = (torch.randn(args.batch, cfg.num_tokens, cfg.embed_dim, generator=g) * 0.05).to(dev)
-    runner.bind(images, dtok)                                # inputs resident in HBM before anything is timed
+    noises = bias = None
+    if args.noisy:          # second run with std = 1 and a caller-supplied noise tensor (seed 2)
+        cfg.vmoe_noisy_std = 1.0
+        gn = torch.Generator().manual_seed(2)
+        noises = {t: {i: torch.randn(args.batch * cfg.num_tokens, cfg.moe_experts, generator=gn).to(dev)
+                      for i in range(cfg.depth) if i % 2 == 1} for t in runner.tasks}
+    if args.skew:           # routing-skew variant: one expert receives ~4x the mean load
+        b = torch.zeros(cfg.moe_experts); b[0] = 8.0
+        bias = {i: b.to(dev) for i in range(cfg.depth) if i % 2 == 1}
+    runner.bind(images, dtok, noises=noises, logit_bias=bias)     # inputs resident in HBM before anything is timed
     step, serial_step = runner.step_eager, runner.serial_step
 
     def barrier():
@@ -269,6 +280,8 @@ def main():
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "task_passes": ntasks,
                    "tokens_per_image": cfg.num_tokens, "cv_loss_weight": CV_WEIGHT,
                    "launch": runner.launch,
+                   "routing": ("noisy gate std=1 (supplied noise, CDF load loss)" if args.noisy else "deterministic (std=0)") +
+                              (", skewed: expert 0 in every token's top-k" if args.skew else ""),
                    "task_streams": ntasks if par_tasks else 1, "wgrad_streams": len(runner.engs) if args.wgrad_streams else 0,
                    "parallelism": "single" if world == 1 else (f"dp{world}+ep{world} (experts sharded, RCCL all-to-all + all-reduce)"
                                                                     if use_ep else f"dp{world} (replicated experts, RCCL all-reduce)")},

@@ -54,7 +54,7 @@ class MultiTaskStep:
         self.two_parts = nparts > 1
         self.want_graph = bool(graph) and not self.use_ep and not wg     # ROCm 7.2 crashes capturing the wgrad-stream pattern
         self.graphs = None
-        self.images = self.dtok = None
+        self.images = self.dtok = self.noises = self.logit_bias = None
 
     # ------------------------------------------------------------------ pieces
     def _run_tasks(self, fn):
@@ -77,8 +77,11 @@ class MultiTaskStep:
         for e in self.engs[1:]:
             ops.add_f32(self.flat[lo:hi], e.flat_grads[lo:hi])          # flat += gradients of the other passes
 
+    def _forward(self, e, t):
+        e.forward(self.images, t, tsf_bias=self.logit_bias, noises=None if self.noises is None else self.noises.get(t))
+
     def _full(self, e, t):
-        e.forward(self.images, t)
+        self._forward(e, t)
         e.backward(self.dtok, cv_weight=self.cv_weight)
 
     def _part(self, j):
@@ -88,7 +91,7 @@ class MultiTaskStep:
         def fn(e, t):
             if j == 0:
                 e.zero_grad()
-                e.forward(self.images, t)
+                self._forward(e, t)
                 e.backward_begin(self.dtok, cv_weight=self.cv_weight)
             e.backward_blocks(hi, lo)
             if last:
@@ -118,9 +121,12 @@ class MultiTaskStep:
             self.part(j)
 
     # --------------------------------------------------------------- execution
-    def bind(self, images: torch.Tensor, d_tokens: torch.Tensor):
-        """the (device-resident) batch and upstream token gradients the step reads; graphs replay on these buffers"""
-        self.images, self.dtok = images, d_tokens
+    def bind(self, images: torch.Tensor, d_tokens: torch.Tensor, noises=None, logit_bias=None):
+        """the (device-resident) batch and upstream token gradients the step reads; graphs replay on these buffers.
+        noises: {task: {block: N(0,1) [T, E]}} caller-supplied gate noise (noisy-gate training, std = vmoe_noisy_std / E);
+        logit_bias: {block: [E]} added to the gate logits of every pass (routing-skew experiments; overrides the
+        task-conditioned bias)"""
+        self.images, self.dtok, self.noises, self.logit_bias = images, d_tokens, noises, logit_bias
 
     def _collective_step(self, parts):
         if not self.two_parts:

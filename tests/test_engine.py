@@ -300,6 +300,23 @@ def test_multitask_step_runner_graph_and_streams_match_serial():
         run.step()
         torch.cuda.synchronize()
         assert rel(run.flat, want) < 1e-5
+    # bench variants: per-task gate noise (noisy-gate training) and a logit bias that skews the routing
+    cfg.vmoe_noisy_std = 1.0
+    T = 4 * cfg.num_tokens
+    noises = {t: {i: torch.randn(T, 8).cuda() for i in (1, 3)} for t in run.tasks}
+    bias = {i: torch.tensor([6.0] + [0.0] * 7).cuda() for i in (1, 3)}
+    run2 = MultiTaskStep(cfg, P, batch=4, dtype=torch.float16, cv_weight=0.01)
+    run2.bind(img, dtok, noises=noises, logit_bias=bias)
+    run2.serial_step()
+    torch.cuda.synchronize()
+    want2 = run2.flat.clone()
+    assert rel(want2, want) > 1e-3                       # the variants do change the step
+    assert bool((run2.eng.act[1]["gate"]["idx32"] == 0).any(dim=1).all())      # expert 0 in every token's top-k
+    assert run2.capture()
+    run2.flat.zero_()
+    run2.step()
+    torch.cuda.synchronize()
+    assert rel(run2.flat, want2) < 1e-5
 
 
 def test_multitask_step_data_parallel_parts():
