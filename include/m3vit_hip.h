@@ -178,8 +178,21 @@ typedef struct {
   float *bias_ws;                  /* optional [splits][G][N]: bias-grad column sums of dC, fused into the
                                       same pass (one extra MFMA row); reduced by m3_wgrad_reduce (same launch as
                                       the weight slabs) or m3_wgrad_bias_reduce */
+  int32_t chunk_rows;              /* 0: every group is cut into `splits` equal parts.  > 0 (grouped calls, a
+                                      multiple of 32): balanced mode - a work unit is chunk_rows rows of one group,
+                                      group g gets ceil(rows_g / chunk_rows) consecutive units of equal size (taken from the
+                                      device-resident offsets: a hot expert gets proportionally more workgroups), ws is
+                                      [units][N][K] (bias_ws [units][N]) and m3_wgrad_reduce_grouped sums each
+                                      group's slabs */
+  int32_t units;                   /* balanced mode: slab slots >= sum_g ceil(rows_g / chunk_rows)
+                                      (M / chunk_rows + G always suffices) */
 } m3_wgrad_args;
 int m3_wgrad_tn(const m3_wgrad_args *args, void *stream);
+/* balanced mode: dW[g] (+)= sum over group g's units of ws[u] (elems = N*K per group), unit order; optionally the
+ * same for the bias slabs (bias_elems = N per group) */
+int m3_wgrad_reduce_grouped(const float *ws, const int32_t *group_offsets, int G, int chunk_rows, int64_t elems,
+                            float *dW, int beta, const float *bias_ws, int64_t bias_elems, float *db, int beta_db,
+                            void *stream);
 /* dW (+)= sum over the splits of the weight slabs, fixed order; optionally db (+)= the same over
  * the bias slabs (bias_ws NULL to skip). */
 int m3_wgrad_reduce(const float *ws, int splits, int64_t elems, float *dW, int beta,

@@ -50,6 +50,7 @@ class WgradArgs(Structure):
         ("ws", c_void_p),
         ("dtype", c_int32),
         ("bias_ws", c_void_p),
+        ("chunk_rows", c_int32), ("units", c_int32),
     ]
 
 
@@ -100,6 +101,7 @@ SIGNATURES = {
     "m3_gemm_nt": (c_int, [POINTER(GemmArgs), _V]),
     "m3_wgrad_tn": (c_int, [POINTER(WgradArgs), _V]),
     "m3_wgrad_reduce": (c_int, [_V, _I, _L, _V, _I, _V, _L, _V, _I, _V]),
+    "m3_wgrad_reduce_grouped": (c_int, [_V, _V, _I, _I, _L, _V, _I, _V, _L, _V, _I, _V]),
     "m3_wgrad_bias_reduce": (c_int, [_V, _I, _L, _V, _I, _V]),
     "m3_colsum_ws_elems": (c_int64, [_L, _I, _I]),
     "m3_colsum": (c_int, [_V, _I, _L, _V, _L, _I, _I, _V, _V, _V, _I, _V]),

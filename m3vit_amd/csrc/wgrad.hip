@@ -34,7 +34,38 @@ struct WgradDev {
   float *ws;
   float *bias_ws;                  // optional [splits][G][N]: column sums of dC (bias grads), fused
   int32_t tiles_k;
+  int32_t chunk_rows;              // > 0: balanced grouped mode - a work unit is `chunk_rows` rows of ONE group
 };
+
+// balanced grouped mode: units are dealt to the groups in order, n_g = ceil(rows_g / chunk) each, a group's rows
+// divided evenly over its units (a hot expert gets proportionally more units; the slab of unit u is ws[u]).
+// One lane per group (G <= 64): ONE load of the offsets per wave and a shuffle scan instead of G dependent loads.
+// Returns this lane's group's (rows, n, exclusive prefix of n).
+__device__ __forceinline__ void wgrad_unit_scan(const int32_t *off, int G, int chunk, int lane, int &rows, int &n, int &first) {
+  rows = lane < G ? off[lane + 1] - off[lane] : 0;
+  n = (rows + chunk - 1) / chunk;
+  int incl = n;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  first = incl - n;
+}
+
+// unit u -> (group, first row, end row); false: u is past the last unit
+__device__ __forceinline__ bool wgrad_unit(const int32_t *off, int G, int chunk, int u, int lane, int &g, int64_t &r0, int64_t &r1) {
+  int rows, n, first;
+  wgrad_unit_scan(off, G, chunk, lane, rows, n, first);
+  const unsigned long long m = __ballot(u >= first && u < first + n);
+  if (m == 0) return false;
+  g = __ffsll((long long)m) - 1;
+  rows = __shfl(rows, g, 64); n = __shfl(n, g, 64); first = __shfl(first, g, 64);
+  const int per = ((rows + n - 1) / n + WG_ROWS - 1) / WG_ROWS * WG_ROWS;      // 32-row granules; per <= chunk
+  r0 = (int64_t)off[g] + (int64_t)(u - first) * per;
+  r1 = r0 + per < off[g + 1] ? r0 + per : off[g + 1];
+  return true;
+}
 
 template <typename T> struct WgLds;
 template <> struct WgLds<half_t> { static constexpr int STRIDE = 288; };
@@ -98,19 +129,28 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
   const int lin = blockIdx.x + tiles * (blockIdx.y + gridDim.y * blockIdx.z);
   const int log_id = xcd_remap(lin, tiles * gridDim.y * gridDim.z);
   const int tile = log_id % tiles, gs = log_id / tiles;
-  const int g = gs % (int)gridDim.y, sp = gs / (int)gridDim.y;
   const int tn = tile / p.tiles_k, tk = tile - tn * p.tiles_k;
   const int n0 = tn * WG_T, k0 = tk * WG_T;
 
-  int64_t r0, r1;
-  if (p.group_offsets) { r0 = p.group_offsets[g]; r1 = p.group_offsets[g + 1]; }
-  else { r0 = 0; r1 = p.M; }
-  const int64_t nsteps_all = (r1 - r0 + WG_ROWS - 1) / WG_ROWS;
-  const int64_t per = (nsteps_all + p.splits - 1) / p.splits;
-  const int64_t s_begin = (int64_t)sp * per;
-  int64_t s_end = s_begin + per;
-  if (s_end > nsteps_all) s_end = nsteps_all;
-  const int nst = (int)(s_end > s_begin ? s_end - s_begin : 0);
+  int g, sp, nst;
+  int64_t r0, r1, s_begin;
+  if (p.chunk_rows) {                          // gs = work unit; its slab is ws[gs]
+    if (!wgrad_unit(p.group_offsets, p.G, p.chunk_rows, gs, lane, g, r0, r1)) return;
+    sp = gs; s_begin = 0;
+    nst = (int)((r1 - r0 + WG_ROWS - 1) / WG_ROWS);
+  } else {
+    g = gs % (int)gridDim.y; sp = gs / (int)gridDim.y;
+    if (p.group_offsets) { r0 = p.group_offsets[g]; r1 = p.group_offsets[g + 1]; }
+    else { r0 = 0; r1 = p.M; }
+    const int64_t nsteps_all = (r1 - r0 + WG_ROWS - 1) / WG_ROWS;
+    const int64_t per = (nsteps_all + p.splits - 1) / p.splits;
+    s_begin = (int64_t)sp * per;
+    int64_t s_end = s_begin + per;
+    if (s_end > nsteps_all) s_end = nsteps_all;
+    nst = (int)(s_end > s_begin ? s_end - s_begin : 0);
+  }
+  // slab / bias slab of this workgroup
+  const int64_t slab_id = p.chunk_rows ? (int64_t)sp : (int64_t)sp * p.G + g;
 
   f32x4 acc[4][4];   // [ki][ni]: MFMA rows = k, cols = n
 #pragma unroll
@@ -244,7 +284,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
   }
 
   if (do_bias && lg == 0) {                       // every row of the ones-product is the column sum: take row 0
-    float *bs = p.bias_ws + ((int64_t)sp * p.G + g) * p.N;
+    float *bs = p.bias_ws + slab_id * p.N;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int n = n0 + wc * 64 + ni * 16 + li;
@@ -252,7 +292,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
     }
   }
   // slab[sp][g][n][k]; lane holds k = kb + 4*lg + r, n = nb + li
-  float *slab = p.ws + ((int64_t)sp * p.G + g) * (int64_t)p.N * p.K;
+  float *slab = p.ws + slab_id * (int64_t)p.N * p.K;
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
     const int n = n0 + wc * 64 + ni * 16 + li;
@@ -278,6 +318,27 @@ __global__ void wgrad_reduce_kernel(const float *ws, int splits, int64_t elems4,
   f32x4 s = beta ? ((const f32x4 *)dW)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
   for (int sp = 0; sp < splits; ++sp) s += ((const f32x4 *)ws)[(int64_t)sp * elems4 + i];
   ((f32x4 *)dW)[i] = s;
+}
+
+// balanced grouped mode: dW[g] (+)= sum of the slabs of group g's units, in unit order; blockIdx.y = group,
+// blocks [0, nb_w) the weight elements, [nb_w, ..) the bias elements
+__global__ void wgrad_reduce_grouped_kernel(const float *ws, const int32_t *off, int G, int chunk, int64_t elems4,
+                                            float *dW, int beta, int nb_w, const float *bias_ws, int64_t belems4,
+                                            float *db, int beta_db) {
+  int64_t blk = blockIdx.x;
+  if (blk >= nb_w) {
+    blk -= nb_w; ws = bias_ws; elems4 = belems4; dW = db; beta = beta_db;
+  }
+  const int64_t i = blk * blockDim.x + threadIdx.x;
+  const int g = blockIdx.y;
+  int rows, n, first;
+  wgrad_unit_scan(off, G, chunk, threadIdx.x & 63, rows, n, first);       // all lanes take part in the scan
+  n = __shfl(n, g, 64); first = __shfl(first, g, 64);
+  if (i >= elems4) return;
+  f32x4 *out = (f32x4 *)dW + (int64_t)g * elems4 + i;
+  f32x4 s = beta ? *out : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int u = first; u < first + n; ++u) s += ((const f32x4 *)ws)[(int64_t)u * elems4 + i];
+  *out = s;
 }
 
 // ------------------------------------------------------------------ column sums
@@ -351,9 +412,12 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   d.A = (const char *)a->A; d.lda_b = a->lda * es; d.a_row_idx = a->a_row_idx; d.a_row_div = a->a_row_idx ? a->a_row_div : 1;
   d.M = a->M; d.N = a->N; d.K = a->K; d.G = a->G; d.group_offsets = a->group_offsets;
   d.splits = a->splits; d.ws = a->ws; d.bias_ws = a->bias_ws;
+  M3_REQUIRE(a->chunk_rows >= 0 && (a->chunk_rows == 0 || (a->group_offsets && a->chunk_rows % WG_ROWS == 0 && a->units >= 1 && a->G <= 64)),
+             "m3_wgrad_tn: balanced mode needs group_offsets, G <= 64, chunk_rows a multiple of %d and units >= 1", WG_ROWS);
+  d.chunk_rows = a->chunk_rows;
   const int tiles_n = (a->N + WG_T - 1) / WG_T;
   d.tiles_k = (a->K + WG_T - 1) / WG_T;
-  const dim3 grid(tiles_n * d.tiles_k, a->G, a->splits), block(WG_THREADS);
+  const dim3 grid(tiles_n * d.tiles_k, a->chunk_rows ? a->units : a->G, a->chunk_rows ? 1 : a->splits), block(WG_THREADS);
   hipStream_t s = (hipStream_t)stream;
   M3_REQUIRE(a->N * es >= 16 && a->K * es >= 16, "m3_wgrad_tn: N, K too small");
   const bool gc = a->c_row_idx != nullptr, ga = a->a_row_idx != nullptr;
@@ -395,6 +459,23 @@ extern "C" int m3_wgrad_reduce(const float *ws, int splits, int64_t elems, float
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nb_w + nb_b)), dim3(256), 0, (hipStream_t)stream, ws,
                      splits, e4, dW, beta, nb_w, bias_ws, b4, db, beta_db);
   return check_launch("m3_wgrad_reduce");
+}
+
+extern "C" int m3_wgrad_reduce_grouped(const float *ws, const int32_t *group_offsets, int G, int chunk_rows, int64_t elems,
+                                       float *dW, int beta, const float *bias_ws, int64_t bias_elems, float *db,
+                                       int beta_db, void *stream) {
+  M3_REQUIRE(ws && dW && group_offsets && G >= 1 && G <= 64 && chunk_rows >= 1 && elems >= 0 && elems % 4 == 0,
+             "m3_wgrad_reduce_grouped: bad args");
+  M3_REQUIRE(((uintptr_t)ws % 16) == 0 && ((uintptr_t)dW % 16) == 0, "m3_wgrad_reduce_grouped: alignment");
+  M3_REQUIRE(!bias_ws || (db && bias_elems > 0 && bias_elems % 4 == 0 && ((uintptr_t)bias_ws % 16) == 0 &&
+                          ((uintptr_t)db % 16) == 0),
+             "m3_wgrad_reduce_grouped: bias slabs need db, 16-byte alignment and a multiple of 4 elements");
+  if (elems == 0) return M3_OK;
+  const int64_t e4 = elems / 4, b4 = bias_ws ? bias_elems / 4 : 0;
+  const int nb_w = (int)((e4 + 255) / 256), nb_b = (int)((b4 + 255) / 256);
+  hipLaunchKernelGGL(wgrad_reduce_grouped_kernel, dim3((unsigned)(nb_w + nb_b), (unsigned)G), dim3(256), 0,
+                     (hipStream_t)stream, ws, group_offsets, G, chunk_rows, e4, dW, beta, nb_w, bias_ws, b4, db, beta_db);
+  return check_launch("m3_wgrad_reduce_grouped");
 }
 
 extern "C" int m3_wgrad_bias_reduce(const float *bias_ws, int splits, int64_t elems, float *db, int beta, void *stream) {

@@ -9,6 +9,8 @@ from __future__ import annotations
 from ctypes import byref, c_void_p
 from typing import Optional
 
+import os
+
 import torch
 
 from . import _lib
@@ -194,7 +196,15 @@ def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None,
         M = dC.shape[0]
     if splits is None:
         splits = default_wgrad_splits(M, N, K, G)
-    need = splits * G * N * K + (splits * G * N if db is not None else 0)
+    # grouped calls: work units of equal row counts dealt to the groups by their (device-resident) sizes, so that a hot
+    # expert gets more workgroups instead of longer ones; `splits` is the average number of units per group
+    balanced = group_offsets is not None and 1 < G <= 64 and M > 0
+    if balanced:
+        chunk = max(32, (-(-M * 9 // (8 * splits * G)) + 31) // 32 * 32)      # 1/8 above the mean part: groups near the mean keep `splits` units
+        units = M // chunk + G
+    else:
+        chunk, units = 0, splits * G
+    need = units * N * K + (units * N if db is not None else 0)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.float32, device=dW.device)
     a = WgradArgs()
@@ -206,9 +216,10 @@ def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None,
     a.M = M; a.N = N; a.K = K; a.G = G
     a.group_offsets = group_offsets.data_ptr() if group_offsets is not None else None
     a.splits = splits
+    a.chunk_rows = chunk; a.units = units
     a.ws = ws.data_ptr()
     a.dtype = dt_code(dC.dtype)
-    bias_ws = ws[splits * G * N * K:] if db is not None else None
+    bias_ws = ws[units * N * K:] if db is not None else None
     a.bias_ws = bias_ws.data_ptr() if bias_ws is not None else None
     check(lib().m3_wgrad_tn(byref(a), _stream()), "m3_wgrad_tn")
     bdb = beta if beta_db is None else beta_db
@@ -216,6 +227,12 @@ def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None,
     if db is not None:
         _req(db, torch.float32, "db")
         fuse = db.data_ptr() % 16 == 0 and bias_ws.data_ptr() % 16 == 0      # both slab reductions in one launch
+    if balanced:
+        assert db is None or fuse, "balanced grouped wgrad: db and the bias slabs must be 16-byte aligned"
+        check(lib().m3_wgrad_reduce_grouped(_p(ws), _p(group_offsets), G, chunk, N * K, _p(dW), beta,
+                                            _p(bias_ws) if fuse else None, N, _p(db) if fuse else None, bdb, _stream()),
+              "m3_wgrad_reduce_grouped")
+        return dW
     check(lib().m3_wgrad_reduce(_p(ws), splits, G * N * K, _p(dW), beta, _p(bias_ws) if fuse else None, G * N,
                                 _p(db) if fuse else None, bdb, _stream()), "m3_wgrad_reduce")
     if db is not None and not fuse:
