@@ -53,12 +53,19 @@ __device__ __forceinline__ void wgrad_unit_scan(const int32_t *off, int G, int c
   first = incl - n;
 }
 
-// unit u -> (group, first row, end row); false: u is past the last unit
-__device__ __forceinline__ bool wgrad_unit(const int32_t *off, int G, int chunk, int u, int lane, int &g, int64_t &r0, int64_t &r1) {
+// logical id (after the XCD remap over the LIVE workgroups only: tiles x sum of n_g - the grid is sized for the upper
+// bound, and remapping over the whole grid would park the surplus ids, i.e. no work at all, on the last XCDs)
+// -> (tile, unit, group, first row, end row); false: this workgroup is surplus
+__device__ __forceinline__ bool wgrad_unit(const int32_t *off, int G, int chunk, int lin, int tiles, int lane, int &tile,
+                                           int &u, int &g, int64_t &r0, int64_t &r1) {
   int rows, n, first;
   wgrad_unit_scan(off, G, chunk, lane, rows, n, first);
+  const int units = __shfl(first + n, 63, 64);
+  if (lin >= units * tiles) return false;
+  const int log_id = xcd_remap(lin, units * tiles);
+  tile = log_id % tiles;
+  u = log_id / tiles;
   const unsigned long long m = __ballot(u >= first && u < first + n);
-  if (m == 0) return false;
   g = __ffsll((long long)m) - 1;
   rows = __shfl(rows, g, 64); n = __shfl(n, g, 64); first = __shfl(first, g, 64);
   const int per = ((rows + n - 1) / n + WG_ROWS - 1) / WG_ROWS * WG_ROWS;      // 32-row granules; per <= chunk
@@ -127,18 +134,15 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
   // remap places on one XCD: the re-reads hit that XCD's L2 instead of the fabric.
   const int tiles = gridDim.x;
   const int lin = blockIdx.x + tiles * (blockIdx.y + gridDim.y * blockIdx.z);
-  const int log_id = xcd_remap(lin, tiles * gridDim.y * gridDim.z);
-  const int tile = log_id % tiles, gs = log_id / tiles;
-  const int tn = tile / p.tiles_k, tk = tile - tn * p.tiles_k;
-  const int n0 = tn * WG_T, k0 = tk * WG_T;
-
-  int g, sp, nst;
+  int tile, gs, g, sp, nst;
   int64_t r0, r1, s_begin;
   if (p.chunk_rows) {                          // gs = work unit; its slab is ws[gs]
-    if (!wgrad_unit(p.group_offsets, p.G, p.chunk_rows, gs, lane, g, r0, r1)) return;
+    if (!wgrad_unit(p.group_offsets, p.G, p.chunk_rows, lin, tiles, lane, tile, gs, g, r0, r1)) return;
     sp = gs; s_begin = 0;
     nst = (int)((r1 - r0 + WG_ROWS - 1) / WG_ROWS);
   } else {
+    const int log_id = xcd_remap(lin, tiles * gridDim.y * gridDim.z);
+    tile = log_id % tiles; gs = log_id / tiles;
     g = gs % (int)gridDim.y; sp = gs / (int)gridDim.y;
     if (p.group_offsets) { r0 = p.group_offsets[g]; r1 = p.group_offsets[g + 1]; }
     else { r0 = 0; r1 = p.M; }
@@ -149,6 +153,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
     if (s_end > nsteps_all) s_end = nsteps_all;
     nst = (int)(s_end > s_begin ? s_end - s_begin : 0);
   }
+  const int tn = tile / p.tiles_k, tk = tile - tn * p.tiles_k;
+  const int n0 = tn * WG_T, k0 = tk * WG_T;
   // slab / bias slab of this workgroup
   const int64_t slab_id = p.chunk_rows ? (int64_t)sp : (int64_t)sp * p.G + g;
 
