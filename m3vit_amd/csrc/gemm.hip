@@ -66,14 +66,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
   const int wr = wave >> 1, wc = wave & 1;
 
   // ---- which tile
-  const int nwg = gridDim.x;
+  // grouped: the grid is sized for the upper bound of row tiles; remap only the LIVE workgroups over the XCDs (a remap
+  // over the whole grid would park the surplus ids, i.e. no work, on the last XCD)
+  const int nwg = p.tile_starts ? p.tile_starts[p.G] * p.n_tiles : (int)gridDim.x;
+  if ((int)blockIdx.x >= nwg) return;
   const int t = xcd_remap(blockIdx.x, nwg);
   const int mt = t / p.n_tiles, nt = t - mt * p.n_tiles;
   int g = 0;
   int64_t m_begin, m_end;
   if (p.tile_starts) {
-    const int total = p.tile_starts[p.G];
-    if (mt >= total) return;
     while (g + 1 < p.G && p.tile_starts[g + 1] <= mt) ++g;
     m_begin = (int64_t)p.group_offsets[g] + (int64_t)(mt - p.tile_starts[g]) * BM;
     m_end = p.group_offsets[g + 1];
@@ -335,13 +336,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const Gemm
   const int li = lane & 15, lg = lane >> 4;
   const int wr = wave >> 1, wc = wave & 1;
 
-  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int nwg = p.tile_starts ? p.tile_starts[p.G] * p.n_tiles : (int)gridDim.x;     // live workgroups (see above)
+  if ((int)blockIdx.x >= nwg) return;
+  const int t = xcd_remap(blockIdx.x, nwg);
   const int mt = t / p.n_tiles, nt = t - mt * p.n_tiles;
   int g = 0;
   int64_t m_begin, m_end;
   if (p.tile_starts) {
-    const int total = p.tile_starts[p.G];
-    if (mt >= total) return;
     while (g + 1 < p.G && p.tile_starts[g + 1] <= mt) ++g;
     m_begin = (int64_t)p.group_offsets[g] + (int64_t)(mt - p.tile_starts[g]) * BM;
     m_end = p.group_offsets[g + 1];
