@@ -28,7 +28,7 @@ if ROOT not in sys.path:
 
 PEAK = {"f16": 2500.0, "f32": 157.3}      # dense MFMA TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM = 8000.0                          # GB/s, MI355X_MICROARCH.md
-CV_WEIGHT = 0.01                           # moe_noisy_gate_loss_weight (CLAUDE.md:66-70)
+CV_WEIGHT = 0.01                           # --moe_noisy_gate_loss_weight default (train_fastmoe.py:118; applied at train/train_utils.py:277)
 
 
 def parse():
