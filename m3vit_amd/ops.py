@@ -9,8 +9,6 @@ from __future__ import annotations
 from ctypes import byref, c_void_p
 from typing import Optional
 
-import os
-
 import torch
 
 from . import _lib

@@ -17,8 +17,6 @@ accumulated), laid out for the GPU:
 Expert-parallel runs (ep_world > 1) read per-layer counts on the host and therefore execute eagerly on one stream."""
 from __future__ import annotations
 
-from typing import Optional
-
 import torch
 
 from . import ops
