@@ -194,14 +194,9 @@ def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None,
         M = dC.shape[0]
     if splits is None:
         splits = default_wgrad_splits(M, N, K, G)
-    # grouped calls: work units of equal row counts dealt to the groups by their (device-resident) sizes, so that a hot
-    # expert gets more workgroups instead of longer ones; `splits` is the average number of units per group
-    balanced = group_offsets is not None and 1 < G <= 64 and M > 0
-    if balanced:
-        chunk = max(32, (-(-M * 9 // (8 * splits * G)) + 31) // 32 * 32)      # 1/8 above the mean part: groups near the mean keep `splits` units
-        units = M // chunk + G
-    else:
-        chunk, units = 0, splits * G
+    balanced = group_offsets is not None
+    chunk, units = wgrad_plan(M, G, splits, balanced)
+    balanced = chunk > 0
     need = units * N * K + (units * N if db is not None else 0)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.float32, device=dW.device)
@@ -236,6 +231,23 @@ def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None,
     if db is not None and not fuse:
         check(lib().m3_wgrad_bias_reduce(_p(bias_ws), splits, G * N, _p(db), bdb, _stream()), "m3_wgrad_bias_reduce")
     return dW
+
+
+def wgrad_plan(M, G, splits, grouped):
+    """(chunk_rows, slab slots) of a weight-gradient call.  Grouped calls: work units of equal row counts dealt to the
+    groups by their (device-resident) sizes, so that a hot expert gets more workgroups instead of longer ones; `splits`
+    is the average number of units per group and the chunk sits 1/8 above the mean part, so that groups near the mean keep
+    `splits` units.  chunk 0: every group in `splits` equal parts."""
+    if grouped and 1 < G <= 64 and M > 0:
+        chunk = max(32, (-(-M * 9 // (8 * splits * G)) + 31) // 32 * 32)
+        return chunk, M // chunk + G
+    return 0, splits * G
+
+
+def wgrad_ws_elems(M, N, K, G, grouped, bias=True):
+    """fp32 elements of workspace wgrad_tn needs for this shape with the default splits"""
+    _, units = wgrad_plan(M, G, default_wgrad_splits(M, N, K, G), grouped)
+    return units * N * (K + (1 if bias else 0))
 
 
 _WGRAD_MIN_STEPS = 16      # 32-row steps per split at least (measured on the 8-image configs; no effect at batch 128)
