@@ -36,3 +36,29 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.M3Error):
         _lib.lib()
+
+
+def test_wgrad_plan_covers_every_group_layout():
+    """host logic of the balanced grouped weight gradient: for any split of M rows over G groups the slab slots the
+    host reserves (M // chunk + G) cover the units the kernel deals out (sum of ceil(rows_g / chunk)), the chunk is a
+    multiple of the 32-row step, and groups at the mean size keep `splits` units"""
+    import random
+    from m3vit_amd import ops
+    rng = random.Random(7)
+    for _ in range(300):
+        G = rng.choice([2, 4, 16, 64])
+        M = rng.randint(1, 200000)
+        N, K = rng.choice([(384, 384), (1536, 384), (768, 3072)])
+        splits = ops.default_wgrad_splits(M, N, K, G)
+        chunk, units = ops.wgrad_plan(M, G, splits, grouped=True)
+        assert chunk % 32 == 0 and chunk >= 32
+        cuts = sorted(rng.randint(0, M) for _ in range(G - 1))
+        rows = [b - a for a, b in zip([0] + cuts, cuts + [M])]
+        if rng.random() < 0.3:                      # everything on one group
+            rows = [M] + [0] * (G - 1)
+        need = sum(-(-r // chunk) for r in rows)
+        assert need <= units, (M, G, splits, chunk, rows)
+        assert -(-(M // G) // chunk) <= splits
+        assert ops.wgrad_ws_elems(M, N, K, G, grouped=True) == units * N * (K + 1)
+    assert ops.wgrad_plan(1000, 1, 4, grouped=True) == (0, 4)          # one group: equal parts
+    assert ops.wgrad_plan(1000, 128, 2, grouped=True) == (0, 256)      # more groups than lanes: equal parts
