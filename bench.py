@@ -129,9 +129,22 @@ def cpu_baseline(cfg_kwargs, batch, threads):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly with --gpus N: become the launcher (one rank per GPU), as a CHILD process - nothing has
+        # touched the GPU yet in this one
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr, flush=True)
     dist = None
     # rehearsal knobs (tests only): M3_BENCH_BACKEND=gloo + M3_BENCH_ONE_DEVICE=1 run N ranks on ONE GPU
     backend = os.environ.get("M3_BENCH_BACKEND", "nccl")
