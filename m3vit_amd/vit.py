@@ -2,7 +2,8 @@
 (models/moe/ckpt/vision_transformer_moe.py:244-261,283-341,379-562,564-886) with the reference's
 module names, state_dict keys and forward signatures, running on the HIP kernels.
 
-Scope notes: drop / attn_drop / drop_path must be 0 (as in every BASELINE config); pretrained
+Scope notes: drop / attn_drop must be 0 (as in every BASELINE config), drop_path is supported (torch-level per-sample
+scaling of the residual branches, as pretrain/configs/deit_moe_small.yaml uses it); pretrained
 weight loading, hybrid backbones, distilled tokens, wandb statistics and the sem regularisers are
 out of scope.  `forward` returns (tokens [B,N,D], total_cv_loss) like :882-886."""
 from functools import partial
@@ -83,6 +84,26 @@ class Attention(nn.Module):
         return PlainLinearFn.apply(o, self.proj.weight, self.proj.bias)
 
 
+class DropPath(nn.Module):
+    """Stochastic depth per sample on a residual branch (vision_transformer_moe.py:167-185): in training the branch of
+    a sample is dropped with probability drop_prob and the kept ones are scaled by 1 / (1 - drop_prob).  The factor
+    drawn last is kept in `last_scale` ([B], for tests)."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = float(drop_prob or 0.0)
+        self.last_scale = None
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        draw = torch.rand((x.shape[0],) + (1,) * (x.dim() - 1), dtype=x.dtype, device=x.device)
+        scale = torch.floor(keep + draw) / keep
+        self.last_scale = scale.flatten()
+        return x * scale
+
+
 class PatchEmbed(nn.Module):
     def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
         super().__init__()
@@ -114,11 +135,11 @@ class Block(nn.Module):
                  regu_experts_fromtask=False, num_experts_pertask=-1, num_tasks=-1, gate_input_ahead=False,
                  regu_sem=False, sem_force=False, regu_subimage=False, expert_prune=False, use_checkpointing=False):
         super().__init__()
-        assert drop == 0.0 and attn_drop == 0.0 and drop_path == 0.0
+        assert drop == 0.0 and attn_drop == 0.0, "dropout inside the fused MLP / attention kernels is not supported"
         self.moe = moe
         self.norm1 = norm_layer(dim)
         self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale)
-        self.drop_path = nn.Identity()
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()      # :397-398 (one module, two draws per block)
         self.norm2 = norm_layer(dim)
         self.gate_input_ahead = gate_input_ahead
         if moe:
@@ -145,12 +166,12 @@ class Block(nn.Module):
     def forward(self, x, gate_inp=None, task_id=None, task_specific_feature=None, sem=None):
         if self.gate_input_ahead:
             gate_inp = x
-        x = x + self.attn(self.norm1(x)).to(x.dtype)
+        x = x + self.drop_path(self.attn(self.norm1(x)).to(x.dtype))
         normed = self.norm2(x)
         if not self.moe:
-            return x + self.mlp(normed).to(x.dtype), None
+            return x + self.drop_path(self.mlp(normed).to(x.dtype)), None
         out, clean, noisy, std, top_logits, gates = self.mlp(normed, gate_inp, task_id, task_specific_feature, sem)
-        x = x + out.to(x.dtype)
+        x = x + self.drop_path(out.to(x.dtype))
         importance = gates.sum(0)
         if self.mlp.top_k < gates.shape[1] and abs(std) > 1e-6:          # :456-459
             load = _prob_in_top_k(clean, noisy, std, top_logits, self.mlp.top_k).sum(0)
@@ -183,7 +204,8 @@ class VisionTransformerMoE(nn.Module):
                  gate_input_ahead=False, expert_prune=False, use_checkpointing=False, act_dtype=torch.float32,
                  random_init=True, sem_force=False, **kwargs):
         super().__init__()
-        assert drop_rate == 0.0 and attn_drop_rate == 0.0 and drop_path_rate == 0.0
+        assert drop_rate == 0.0 and attn_drop_rate == 0.0, "dropout inside the fused kernels is not supported"
+        dpr = [drop_path_rate * i / max(depth - 1, 1) for i in range(depth)]          # linspace(0, rate, depth), :632
         self.img_size = tuple(img_size) if isinstance(img_size, (tuple, list)) else (img_size, img_size)
         self.patch_size = patch_size
         self.embed_dim = self.num_features = embed_dim
@@ -206,9 +228,11 @@ class VisionTransformerMoE(nn.Module):
         blocks = []
         for i in range(depth):
             if i % 2 == 0:
-                blocks.append(Block(embed_dim, num_heads, mlp_ratio, qkv_bias, qk_scale, norm_layer=norm_layer))
+                blocks.append(Block(embed_dim, num_heads, mlp_ratio, qkv_bias, qk_scale, drop_path=dpr[i],
+                                    norm_layer=norm_layer))
             else:
-                blocks.append(Block(embed_dim, num_heads, mlp_ratio, qkv_bias, qk_scale, norm_layer=norm_layer, moe=True,
+                blocks.append(Block(embed_dim, num_heads, mlp_ratio, qkv_bias, qk_scale, drop_path=dpr[i],
+                                    norm_layer=norm_layer, moe=True,
                                     moe_mlp_ratio=moe_mlp_ratio, moe_experts=moe_experts, moe_top_k=moe_top_k,
                                     moe_gate_dim=gate_dim, world_size=world_size, moe_gate_type=moe_gate_type,
                                     vmoe_noisy_std=vmoe_noisy_std, gate_task_specific_dim=gate_task_specific_dim,

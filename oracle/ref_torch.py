@@ -307,19 +307,23 @@ def patch_embed(images, w, b, cls_token, pos_embed):
 
 
 def block_forward(params, cfg: BackboneCfg, i: int, x, task_id: Optional[int], tsf=None,
-                  training: bool = True, noise=None, idx_override=None):
+                  training: bool = True, noise=None, idx_override=None, path_scale=None):
     """Block._ckpt_main_moe / _ckpt_non_moe, vision_transformer_moe.py:438-487, and the
-    cv-loss part of Block.forward :539-543 (drop_path = 0, mlp_drop = 0).
+    cv-loss part of Block.forward :539-543 (mlp_drop = 0).  path_scale: None (drop_path = 0) or the two per-sample
+    factors DropPath (:167-185) multiplies the attention and the MLP / MoE branch with: mask / keep_prob, each [B].
     Returns (x_out, cv_loss or None, aux dict)."""
     p = params
     b = f"blocks.{i}."
-    x = x + attention(layernorm(x, p[b + "norm1.weight"], p[b + "norm1.bias"]),
-                      p[b + "attn.qkv.weight"], p[b + "attn.qkv.bias"],
-                      p[b + "attn.proj.weight"], p[b + "attn.proj.bias"], cfg.num_heads)
+    s_attn = s_mlp = 1.0
+    if path_scale is not None:
+        s_attn, s_mlp = (v.to(x.dtype).view(-1, 1, 1) for v in path_scale)
+    x = x + s_attn * attention(layernorm(x, p[b + "norm1.weight"], p[b + "norm1.bias"]),
+                               p[b + "attn.qkv.weight"], p[b + "attn.qkv.bias"],
+                               p[b + "attn.proj.weight"], p[b + "attn.proj.bias"], cfg.num_heads)
     normed = layernorm(x, p[b + "norm2.weight"], p[b + "norm2.bias"])
     if not cfg.is_moe(i):
-        x = x + mlp_dense(normed, p[b + "mlp.fc1.weight"], p[b + "mlp.fc1.bias"],
-                          p[b + "mlp.fc2.weight"], p[b + "mlp.fc2.bias"])
+        x = x + s_mlp * mlp_dense(normed, p[b + "mlp.fc1.weight"], p[b + "mlp.fc1.bias"],
+                                  p[b + "mlp.fc2.weight"], p[b + "mlp.fc2.bias"])
         return x, None, {}
     T = normed.shape[0] * normed.shape[1]
     flat = normed.reshape(T, -1)
@@ -337,7 +341,7 @@ def block_forward(params, cfg: BackboneCfg, i: int, x, task_id: Optional[int], t
         p[b + "mlp.experts.h4toh.weight"], p[b + "mlp.experts.h4toh.bias"],
         cfg.moe_top_k, noise=noise, noise_std=cfg.vmoe_noisy_std, training=training,
         idx_override=idx_override)
-    x = x + out
+    x = x + s_mlp * out
     importance = gates.sum(0)                                  # :453
     E = gates.shape[1]
     if cfg.moe_top_k < E and abs(std) > 1e-6:                  # :456-459
@@ -350,7 +354,7 @@ def block_forward(params, cfg: BackboneCfg, i: int, x, task_id: Optional[int], t
 
 
 def backbone_forward(params, cfg: BackboneCfg, images, task_id: Optional[int], training: bool = True,
-                     noises=None, route_override=None):
+                     noises=None, route_override=None, path_scales=None):
     """VisionTransformerMoE.forward_features, vision_transformer_moe.py:780-880:
     returns (tokens[B,N,D] of the last block, total_cv_loss)."""
     p = params
@@ -364,7 +368,8 @@ def backbone_forward(params, cfg: BackboneCfg, images, task_id: Optional[int], t
     for i in range(cfg.depth):
         noise = None if noises is None else noises.get(i)
         ovr = None if route_override is None else route_override.get(i)
-        x, cv, aux = block_forward(p, cfg, i, x, task_id, tsf, training, noise, ovr)
+        ps = None if path_scales is None else path_scales.get(i)
+        x, cv, aux = block_forward(p, cfg, i, x, task_id, tsf, training, noise, ovr, ps)
         if cv is not None:
             total_cv = total_cv + cv
         aux_all.append(aux)

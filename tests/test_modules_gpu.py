@@ -51,6 +51,48 @@ def test_vit_mirror_matches_oracle_fwd_bwd(std):
     assert not bad, bad
 
 
+def test_vit_mirror_drop_path_matches_oracle():
+    """Stochastic depth (drop_path_rate > 0, pretrain/configs/deit_moe_small.yaml:51): every block draws two per-sample
+    masks in training (attention branch, MLP / MoE branch), rate rising linearly over the blocks; the factors the
+    modules drew are fed to the oracle.  Eval mode is the identity."""
+    _need_gpu()
+    from m3vit_amd.vit import DropPath, VisionTransformerMoE
+    from oracle import ref_torch as R
+    kw = dict(img_size=(32, 32), embed_dim=64, depth=4, num_heads=2, moe_experts=4, moe_top_k=2, gate_dim=66,
+              multi_gate=True)
+    cfg = R.BackboneCfg(mlp_ratio=4.0, moe_mlp_ratio=1.0, vmoe_noisy_std=0.0, **kw)
+    P = R.init_backbone_params(cfg, seed=12)
+    m = VisionTransformerMoE(mlp_ratio=4.0, moe_mlp_ratio=1, vmoe_noisy_std=0.0, drop_path_rate=0.5, **kw).cuda()
+    m.load_state_dict(P)
+    rates = [blk.drop_path.drop_prob if isinstance(blk.drop_path, DropPath) else 0.0 for blk in m.blocks]
+    assert rates == pytest.approx([0.0, 0.5 / 3, 1.0 / 3, 0.5])
+    drawn = {}
+    for i, blk in enumerate(m.blocks):
+        if isinstance(blk.drop_path, DropPath):
+            blk.drop_path.register_forward_hook(lambda mod, a, out, i=i: drawn.setdefault(i, []).append(mod.last_scale.cpu()))
+    img = torch.randn(6, 3, 32, 32)
+    dtok = torch.randn(6, cfg.num_tokens, 64) * 0.1
+    m.train()
+    torch.manual_seed(3)
+    tok, cv = m(img.cuda(), task_id=1)
+    assert all(len(v) == 2 for v in drawn.values()) and sorted(drawn) == [1, 2, 3]
+    allv = torch.cat([torch.cat(v) for v in drawn.values()])
+    assert bool((allv == 0).any()) and bool((allv > 1).any())           # some branches dropped, the kept ones scaled up
+    scales = {i: (torch.ones(6), torch.ones(6)) if i not in drawn else tuple(drawn[i]) for i in range(4)}
+    Pr = {k: v.clone().double().requires_grad_() for k, v in P.items()}
+    tr, cr, _ = R.backbone_forward(Pr, cfg, img.double(), 1, path_scales=scales)
+    assert rel(tok, tr) < 2e-4
+    ((tok * dtok.cuda()).sum() + 0.01 * cv).backward()
+    ((tr * dtok.double()).sum() + 0.01 * cr).backward()
+    bad = [(n, rel(p.grad, Pr[n].grad)) for n, p in m.named_parameters() if Pr[n].grad is not None and rel(p.grad, Pr[n].grad) > 1e-3]
+    assert not bad, bad
+    m.eval()
+    with torch.no_grad():
+        tok_e, _ = m(img.cuda(), task_id=1)
+        te, _, _ = R.backbone_forward(Pr, cfg, img.double(), 1, training=False)
+    assert rel(tok_e, te) < 2e-4
+
+
 def test_composable_fmoe_path_with_custom_activation():
     """_fmoe_general_global_forward + FMoELinear with an activation the fused path does not cover."""
     _need_gpu()
