@@ -83,3 +83,65 @@ def test_engine_expert_parallel_two_ranks_one_gpu():
     for p in procs:
         p.join(timeout=30)
     assert all(r[1] == "ok" for r in res), res
+
+
+def _dp_worker(rank, world, port, q):
+    """data parallel, replicated experts: the step cut into parts with an all-reduce behind each (MultiTaskStep) must
+    leave on EVERY rank the mean over the ranks of the serial per-rank gradients, eagerly and as replayed graphs"""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from m3vit_amd.config import BackboneConfig, init_params
+        from m3vit_amd.step import MultiTaskStep
+        torch.cuda.set_device(0)
+        cfg = BackboneConfig(img_size=(32, 48), embed_dim=64, depth=4, num_heads=2, moe_experts=4, moe_top_k=2,
+                             gate_dim=66, multi_gate=True)
+        P = init_params(cfg, seed=3, zero_bias=False)
+        B = 3
+        g = torch.Generator().manual_seed(70 + rank)                      # every rank its own images
+        img = torch.randn(B, 3, 32, 48, generator=g).cuda()
+        dtok = (torch.randn(B, cfg.num_tokens, 64, generator=g) * 0.1).cuda()
+        ref = MultiTaskStep(cfg, P, batch=B, dtype=torch.float32, cv_weight=0.01)          # world 1: this rank alone
+        ref.bind(img, dtok)
+        ref.serial_step()
+        torch.cuda.synchronize()
+        want = {n: v.clone() for n, v in ref.eng.grads.items()}
+        for v in want.values():                                            # mean over the ranks
+            dist.all_reduce(v)
+            v /= world
+        for parts in (1, 3):
+            run = MultiTaskStep(cfg, P, batch=B, dtype=torch.float32, cv_weight=0.01, world=world, rank=rank, dp_parts=parts)
+            run.bind(img, dtok)
+            run.step()
+            torch.cuda.synchronize()
+            bad = [(n, rel(v, want[n])) for n, v in run.eng.grads.items() if rel(v, want[n]) > 1e-5]
+            assert not bad, (parts, "eager", bad[:3])
+            assert run.capture() and len(run.graphs) == parts
+            run.flat.fill_(5.0)
+            run.step()
+            torch.cuda.synchronize()
+            bad = [(n, rel(v, want[n])) for n, v in run.eng.grads.items() if rel(v, want[n]) > 1e-5]
+            assert not bad, (parts, "graph", bad[:3])
+        q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_parts_two_ranks_one_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert all(r[1] == "ok" for r in res), res
