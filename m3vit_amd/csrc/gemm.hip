@@ -23,6 +23,20 @@
 
 namespace m3 {
 
+// Diagnostic build only (make CXXFLAGS+=-DM3_GEMM_STAMPS, tools/gemm_stamps.py): lane 0 of wave 0 of every workgroup of
+// the LDS-DMA kernel records s_memtime at its phase boundaries; m3_debug_gemm_stamps copies them out.
+#ifdef M3_GEMM_STAMPS
+constexpr int STAMP_WGS = 4096, STAMP_N = 64;      // 0 entry, 1 set-up, 2+2ks / 3+2ks K step ks (< 27), 56..58 epilogue, 63 hw id
+__device__ unsigned long long g_gemm_stamps[STAMP_WGS][STAMP_N];
+#define M3_STAMP(i)                                                                         \
+  do {                                                                                      \
+    if (threadIdx.x == 0 && blockIdx.x < STAMP_WGS && (i) < STAMP_N)                        \
+      g_gemm_stamps[blockIdx.x][(i)] = __builtin_amdgcn_s_memtime();                        \
+  } while (0)
+#else
+#define M3_STAMP(i) do { } while (0)
+#endif
+
 constexpr int BM = 128, BN = 128, ROWB = 128;  // ROWB: bytes of K per row per step
 constexpr int GEMM_THREADS = 256;
 
@@ -335,6 +349,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const Gemm
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
   const int wr = wave >> 1, wc = wave & 1;
+  M3_STAMP(0);                                                                         // entry
+#ifdef M3_GEMM_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < STAMP_WGS) {                                    // which CU / XCC this workgroup ran on
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_gemm_stamps[blockIdx.x][STAMP_N - 1] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
 
   const int nwg = p.tile_starts ? p.tile_starts[p.G] * p.n_tiles : (int)gridDim.x;     // live workgroups (see above)
   if ((int)blockIdx.x >= nwg) return;
@@ -412,11 +435,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const Gemm
     }
   };
 
+  M3_STAMP(1);                                                                         // set-up done
   for (int ks = 0; ks < nk; ++ks) {
     dma(ks);
     __syncthreads();          // vmcnt(0) + barrier: the slice has landed
+    if (ks < 27) M3_STAMP(2 + 2 * ks);                                                 // slice ks landed
     compute();
     __syncthreads();          // everyone has read it
+    if (ks < 27) M3_STAMP(3 + 2 * ks);                                                 // slice ks multiplied
   }
 
   // ---- epilogue: the fp32 tile goes through the (now free) 32 KiB in two 64-row halves (half h = waves wr == h),
@@ -474,7 +500,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const Gemm
         }
       }
     }
+    M3_STAMP(56 + h);                                                                  // stores of half h issued
   }
+#ifdef M3_GEMM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  M3_STAMP(58);                                                                        // my stores acknowledged
+#endif
 }
 
 }  // namespace m3
@@ -547,3 +578,10 @@ extern "C" int m3_gemm_nt(const m3_gemm_args *a, void *stream) {
   }
   return check_launch("m3_gemm_nt");
 }
+
+#ifdef M3_GEMM_STAMPS
+extern "C" int m3_debug_gemm_stamps(unsigned long long *dst, int wgs) {
+  if (wgs > STAMP_WGS) wgs = STAMP_WGS;
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemm_stamps), (size_t)wgs * STAMP_N * sizeof(unsigned long long)) == hipSuccess ? M3_OK : M3_ERR_LAUNCH;
+}
+#endif
