@@ -160,6 +160,34 @@ typedef struct {
 } m3_gemm_args;
 int m3_gemm_nt(const m3_gemm_args *args, void *stream);
 
+/* Fused FFN forward (fp16 activations):
+ *   Y[crow(m), :] = (residual[crow(m), :] +) GELU(X[arow(m), :] W1[g]^T + b1[g]) W2[g]^T + b2[g]
+ * One launch for `_Expert.forward` (models/moe/ckpt/custom_moe_layer.py:36-44: htoh4 -> GELU -> h4toh through
+ * FMoELinear :32-33) with the MOEScatter / MOEGather row movement of `_fmoe_general_global_forward` (:263-265)
+ * fused into the operand load / the store, and for the dense `Mlp.forward`
+ * (models/moe/ckpt/vision_transformer_moe.py:255-261) with Block's residual add (:450).  The hidden activations
+ * [rows, H] are never written: this is the forward of the reference's default activation-checkpointing mode
+ * (vision_transformer_moe.py:495-524); the backward recomputes them (m3_ffn_bwd).
+ * X [*, D] (row stride ldx elements), W1 [G][H][D], W2p [G][D][H] = W2 with the h index permuted inside every
+ * aligned group of 32 (position 8a + 4b + c holds h = 16b + 4a + c, a < 4, b < 2, c < 4: M3_CAST_PERM32 of
+ * m3_cast_batch), b1 [G][H], b2 [G][D] fp32 (NULL = 0).  Y [*, D] f16 or fp32 (row stride ldy elements);
+ * residual fp32 only with fp32 Y.  pre_out / act_out (optional, f16 [rows in slot order][H]): x W1^T + b1 and its
+ * GELU, for a backward that keeps the hidden activations instead of recomputing them.  Grouped call: rows are expert-major slots, group g owns
+ * [group_offsets[g], group_offsets[g+1]); x_row_idx / y_row_idx as a_row_idx / c_row_idx of m3_gemm_nt.
+ * D in {384, 768}; H a multiple of 64; G <= 64. */
+typedef struct {
+  const void *X; int64_t ldx; const int32_t *x_row_idx; int32_t x_row_div;
+  const void *W1; const void *W2p;
+  const float *b1; const float *b2;
+  void *Y; int64_t ldy; int32_t y_dtype; const int32_t *y_row_idx;
+  const float *residual; int64_t ld_res;
+  void *pre_out; void *act_out;    /* f16 [M][H] (row m = slot m), or NULL */
+  int64_t M; int32_t D; int32_t H; int32_t G;
+  const int32_t *group_offsets;    /* [G+1] device, or NULL for dense */
+  int32_t dtype;                   /* M3_F16 */
+} m3_ffn_args;
+int m3_ffn_fwd(const m3_ffn_args *args, void *stream);
+
 /* Weight gradient ("TN", contraction over rows):
  *   dW[g][n, k] (+)= sum_{m in group g} dC[crow(m), n] * A[arow(m), k]
  *   FMoELinear backward (fastmoe linear_backward behind custom_moe_layer.py:32-33) and
@@ -262,10 +290,16 @@ int m3_cast_matrix(const float *src, int G, int rows, int cols, int transpose,
  * descs_dev is a DEVICE array of n_desc descriptors; a job writes dst (same layout as src) and/or dst_t
  * (transposed, [g][cols][rows]) - either may be NULL - from one read of src; tile_start = running sum of
  * G * ceil(rows/32) * ceil(cols/32) over the preceding descriptors, total_tiles = the full sum. */
+#define M3_CAST_PERM32 1    /* dst: last index permuted inside aligned groups of 32 (cols % 32 == 0): position
+                               8a + 4b + c holds source column 16b + 4a + c - the k order in which an MFMA 16x16x32
+                               accumulator pair becomes the next product's operand (m3_ffn_fwd) */
+#define M3_CAST_PERM32_T 2  /* the same for the last index (= source row, rows % 32 == 0) of dst_t */
 typedef struct m3_cast_desc {
   const float *src; void *dst; void *dst_t;
   int32_t G, rows, cols;
-  int32_t tile_start, pad0, pad1;
+  int32_t tile_start;
+  int32_t flags;                   /* M3_CAST_PERM32 / M3_CAST_PERM32_T */
+  int32_t pad1;
 } m3_cast_desc;
 int m3_cast_batch(const m3_cast_desc *descs_dev, int n_desc, int total_tiles, int dst_dtype, void *stream);
 /* dst[i] += src[i] (fp32, n elements): sums the flat gradient buffers of task passes that ran

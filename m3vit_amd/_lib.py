@@ -54,9 +54,26 @@ class WgradArgs(Structure):
     ]
 
 
+class FfnArgs(Structure):
+    _fields_ = [
+        ("X", c_void_p), ("ldx", c_int64), ("x_row_idx", c_void_p), ("x_row_div", c_int32),
+        ("W1", c_void_p), ("W2p", c_void_p),
+        ("b1", c_void_p), ("b2", c_void_p),
+        ("Y", c_void_p), ("ldy", c_int64), ("y_dtype", c_int32), ("y_row_idx", c_void_p),
+        ("residual", c_void_p), ("ld_res", c_int64),
+        ("pre_out", c_void_p), ("act_out", c_void_p),
+        ("M", c_int64), ("D", c_int32), ("H", c_int32), ("G", c_int32),
+        ("group_offsets", c_void_p),
+        ("dtype", c_int32),
+    ]
+
+
+M3_CAST_PERM32, M3_CAST_PERM32_T = 1, 2
+
+
 class CastDesc(Structure):
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("dst_t", c_void_p), ("G", c_int32), ("rows", c_int32),
-                ("cols", c_int32), ("tile_start", c_int32), ("pad0", c_int32), ("pad1", c_int32)]
+                ("cols", c_int32), ("tile_start", c_int32), ("flags", c_int32), ("pad1", c_int32)]
 
 
 class GateFwdArgs(Structure):
@@ -99,6 +116,7 @@ SIGNATURES = {
     "m3_route_ws_elems": (c_int64, [_L, _I]),
     "m3_route_build": (c_int, [_V, _L, _I, _V, _V, _V, _V, _V, _V, _V, _V]),
     "m3_gemm_nt": (c_int, [POINTER(GemmArgs), _V]),
+    "m3_ffn_fwd": (c_int, [POINTER(FfnArgs), _V]),
     "m3_wgrad_tn": (c_int, [POINTER(WgradArgs), _V]),
     "m3_wgrad_reduce": (c_int, [_V, _I, _L, _V, _I, _V, _L, _V, _I, _V]),
     "m3_wgrad_reduce_grouped": (c_int, [_V, _V, _I, _I, _L, _V, _I, _V, _L, _V, _I, _V]),

@@ -200,7 +200,7 @@ __global__ void cast_matrix_kernel(const float *__restrict__ src, int rows, int 
 struct CastDesc {            // = m3_cast_desc
   const float *src; void *dst; void *dst_t;
   int32_t G, rows, cols;
-  int32_t tile_start, pad0, pad1;
+  int32_t tile_start, flags, pad1;
 };
 
 template <typename T>
@@ -221,10 +221,13 @@ __global__ __launch_bounds__(256) void cast_batch_kernel(const CastDesc *__restr
   const int64_t goff = (int64_t)g * d.rows * d.cols;
   const float *src = d.src + goff;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  // M3_CAST_PERM32: source index q = 16b + 4a + c of an aligned 32-group goes to position 8a + 4b + c
+  const int txp = ((tx >> 2) & 3) * 8 + (tx >> 4) * 4 + (tx & 3);
+  const int tx_d = (d.flags & 1) ? txp : tx, tx_t = (d.flags & 2) ? txp : tx;
   for (int i = ty; i < 32; i += 8) {
     const int r = r0 + i, c = c0 + tx;
     const float v = (r < d.rows && c < d.cols) ? src[(int64_t)r * d.cols + c] : 0.f;
-    if (d.dst && r < d.rows && c < d.cols) ((T *)d.dst + goff)[(int64_t)r * d.cols + c] = (T)v;
+    if (d.dst && r < d.rows && c < d.cols) ((T *)d.dst + goff)[(int64_t)r * d.cols + c0 + tx_d] = (T)v;
     tile[i][tx] = v;
   }
   if (!d.dst_t) return;
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256) void cast_batch_kernel(const CastDesc *__restr
   T *dst_t = (T *)d.dst_t + goff;
   for (int i = ty; i < 32; i += 8) {
     const int c = c0 + i, r = r0 + tx;   // dst_t[c][r]
-    if (r < d.rows && c < d.cols) dst_t[(int64_t)c * d.rows + r] = (T)tile[tx][i];
+    if (r < d.rows && c < d.cols) dst_t[(int64_t)c * d.rows + r0 + tx_t] = (T)tile[tx][i];
   }
 }
 

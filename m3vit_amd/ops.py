@@ -183,6 +183,54 @@ def gemm_nt(A, B, C, *, M=None, bias=None, act=M3_ACT_NONE, pre_out=None, gelu_g
     return C
 
 
+def ffn_supported(D: int, H: int, dtype: torch.dtype, G: int = 1) -> bool:
+    """shapes the fused FFN kernels take (anything else runs the unfused m3_gemm_nt pair)"""
+    return dtype == torch.float16 and D in (384, 768) and H % 64 == 0 and 64 <= H <= 8192 and G <= 64 and \
+        49152 + 64 * (2 if D == 384 else 1) * D * 2 + (H + D) * 4 <= 163840
+
+
+def ffn_fwd(X, W1, W2p, Y, *, b1=None, b2=None, M=None, residual=None, x_row_idx=None, x_row_div=1, y_row_idx=None,
+            group_offsets=None, pre_out=None, act_out=None):
+    """Y[crow(m)] = (residual +) GELU(X[arow(m)] W1[g]^T + b1[g]) W2[g]^T + b2[g] in one launch (m3_ffn_fwd).
+    X [rows, D] f16; W1 [H, D] or [G, H, D]; W2p = W2 [.., D, H] with the PERM32 column order (CastPlan perm flag);
+    Y [rows, D] f16 or f32.  pre_out / act_out (optional, f16 [M, H], slot order): x W1^T + b1 and its GELU."""
+    _req(X, torch.float16, "X"); _req(W1, torch.float16, "W1"); _req(W2p, torch.float16, "W2p"); _req(Y, name="Y")
+    G = 1 if W1.dim() == 2 else W1.shape[0]
+    H, D = W1.shape[-2], W1.shape[-1]
+    assert W2p.shape[-2] == D and W2p.shape[-1] == H
+    a = _lib.FfnArgs()
+    a.X = X.data_ptr(); a.ldx = X.stride(0)
+    a.x_row_idx = x_row_idx.data_ptr() if x_row_idx is not None else None
+    a.x_row_div = x_row_div
+    a.W1 = W1.data_ptr(); a.W2p = W2p.data_ptr()
+    for b, n in ((b1, "b1"), (b2, "b2")):
+        if b is not None:
+            _req(b, torch.float32, n)
+    a.b1 = b1.data_ptr() if b1 is not None else None
+    a.b2 = b2.data_ptr() if b2 is not None else None
+    a.Y = Y.data_ptr(); a.ldy = Y.stride(0); a.y_dtype = dt_code(Y.dtype)
+    a.y_row_idx = y_row_idx.data_ptr() if y_row_idx is not None else None
+    if residual is not None:
+        _req(residual, torch.float32, "residual")
+    a.residual = residual.data_ptr() if residual is not None else None
+    a.ld_res = residual.stride(0) if residual is not None else 0
+    if M is None:
+        M = x_row_idx.numel() if x_row_idx is not None else X.shape[0]
+    for o, n in ((pre_out, "pre_out"), (act_out, "act_out")):
+        if o is not None:
+            _req(o, torch.float16, n)
+            assert o.shape[-1] == H and o.stride(0) == H and o.shape[0] >= M
+    a.pre_out = pre_out.data_ptr() if pre_out is not None else None
+    a.act_out = act_out.data_ptr() if act_out is not None else None
+    a.M = M; a.D = D; a.H = H; a.G = G
+    a.group_offsets = group_offsets.data_ptr() if group_offsets is not None else None
+    a.dtype = M3_F16
+    if M == 0:
+        return Y
+    check(lib().m3_ffn_fwd(byref(a), _stream()), "m3_ffn_fwd")
+    return Y
+
+
 def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None, a_row_idx=None, a_row_div=1,
              group_offsets=None, db=None, beta_db=None):
     """dW[g][n,k] (+)= sum_m dC[crow(m),n] A[arow(m),k].  dW f32 [N,K] or [G,N,K].
@@ -347,12 +395,14 @@ class CastPlan:
     model, converted by ONE launch per optimizer step."""
 
     def __init__(self, jobs, dst_dtype):
-        # jobs: list of (src fp32 [.., rows, cols], dst [.., rows, cols] or None, dst_t [.., cols, rows] or None):
+        # jobs: list of (src fp32 [.., rows, cols], dst [.., rows, cols] or None, dst_t [.., cols, rows] or None[, flags]):
         # the plain and / or the transposed copy, both written from one read of src
         arr = (_lib.CastDesc * len(jobs))()
         t0 = 0
         self.keep = []
-        for d, (src, dst, dst_t) in zip(arr, jobs):
+        for d, job in zip(arr, jobs):
+            src, dst, dst_t = job[:3]
+            d.flags = job[3] if len(job) > 3 else 0
             _req(src, torch.float32, "src")
             rows, cols = src.shape[-2], src.shape[-1]
             G = src.numel() // (rows * cols)
@@ -361,6 +411,10 @@ class CastPlan:
                     _req(o, dst_dtype, "dst")
                     assert o.numel() == src.numel()
             assert dst is not None or dst_t is not None
+            if d.flags & _lib.M3_CAST_PERM32:
+                assert dst is not None and cols % 32 == 0
+            if d.flags & _lib.M3_CAST_PERM32_T:
+                assert dst_t is not None and rows % 32 == 0
             d.src, d.G, d.rows, d.cols, d.tile_start = src.data_ptr(), G, rows, cols, t0
             d.dst = dst.data_ptr() if dst is not None else None
             d.dst_t = dst_t.data_ptr() if dst_t is not None else None
