@@ -8,8 +8,10 @@ One "step" = what one reference training iteration does to the backbone for one 
 (train/train_utils.py:423-457, multi_gate joint path; models/models.py:299-301): refresh the
 operand copies of the weights, then for EACH of the 2 tasks one full backbone forward (task's
 gate) and one full backward (d tokens + 0.01 * cv_loss), gradients accumulated; for N > 1 the
-gradients are then all-reduced over RCCL (replicated-experts data parallel, the reference's
---moe_data_distributed mode, utils/common_config.py:179-181).  Decoder heads / losses are out
+experts are sharded E/N per rank (expert parallel: all-to-all of the routed rows over RCCL, dense gradients
+all-reduced; utils/common_config.py:179-185) - the primary value when E % N == 0 - and the replicated-experts
+data-parallel form (the reference's --moe_data_distributed mode, :179-181) is timed too (sub-objects "ep" / "dp").
+At N = 1 the fp32 run (train_fastmoe.py's arithmetic) follows the fp16 one as the sub-object "f32".  Decoder heads / losses are out
 of scope: d tokens is a fixed synthetic tensor.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions).
@@ -47,9 +49,11 @@ def parse():
     ap.add_argument("--serial-tasks", action="store_true", help="run the task passes one after the other on one "
                     "stream (default: one HIP stream per task pass, gradients summed at the end)")
     ap.add_argument("--wgrad-streams", action="store_true", help="also launch the weight-gradient GEMMs of each "
-                    "pass on their own stream (eager launch only: hipGraph capture of that pattern crashes in ROCm 7.2)")
-    ap.add_argument("--ep", action="store_true", help="N > 1: shard the experts over the ranks (expert parallel, "
-                    "all-to-all over RCCL) instead of replicating them")
+                    "pass on their own stream (fork / join by events; captured into the hipGraph like the rest)")
+    ap.add_argument("--ep", action="store_true", help="N > 1: time ONLY the expert-parallel form (experts sharded over the "
+                    "ranks, all-to-all over RCCL); default: expert parallel (primary, when E %% N == 0) AND data parallel")
+    ap.add_argument("--dp-only", action="store_true", help="N > 1: time only the replicated-experts data-parallel form")
+    ap.add_argument("--no-f32", action="store_true", help="N = 1: skip the fp32 run reported as the sub-object \"f32\"")
     return ap.parse_args()
 
 
@@ -164,30 +168,6 @@ def main():
     from m3vit_amd.config import VIT_SMALL_MOE, BackboneConfig, init_params
     from m3vit_amd.step import MultiTaskStep
 
-    cfg = BackboneConfig(**VIT_SMALL_MOE)
-    dtype = torch.float16 if args.dtype == "f16" else torch.float32
-    params = init_params(cfg, seed=1)                       # same weights on every rank
-    # m3vit_amd/step.py: one engine context + HIP stream per task pass, hipGraph capture, and for N > 1 the
-    # all-reduce of the upper blocks' gradients overlapped with the lower blocks' backward
-    runner = MultiTaskStep(cfg, params, batch=args.batch, dtype=dtype, device=str(dev), cv_weight=CV_WEIGHT,
-                           parallel_tasks=not args.serial_tasks, graph=not args.no_graph, world=world, rank=rank,
-                           expert_parallel=args.ep, wgrad_streams=args.wgrad_streams, dp_parts=args.dp_parts)
-    use_ep, par_tasks, ntasks = runner.use_ep, runner.par, len(runner.tasks)
-    g = torch.Generator().manual_seed(1000 + rank)          # each rank its own images
-    images = torch.randn(args.batch, 3, *cfg.img_size, generator=g).to(dev)
-    dtok = (torch.randn(args.batch, cfg.num_tokens, cfg.embed_dim, generator=g) * 0.05).to(dev)
-    noises = bias = None
-    if args.noisy:          # second run with std = 1 and a caller-supplied noise tensor (seed 2)
-        cfg.vmoe_noisy_std = 1.0
-        gn = torch.Generator().manual_seed(2)
-        noises = {t: {i: torch.randn(args.batch * cfg.num_tokens, cfg.moe_experts, generator=gn).to(dev)
-                      for i in range(cfg.depth) if i % 2 == 1} for t in runner.tasks}
-    if args.skew:           # routing-skew variant: one expert receives ~4x the mean load
-        b = torch.zeros(cfg.moe_experts); b[0] = 8.0
-        bias = {i: b.to(dev) for i in range(cfg.depth) if i % 2 == 1}
-    runner.bind(images, dtok, noises=noises, logit_bias=bias)     # inputs resident in HBM before anything is timed
-    step, serial_step = runner.step_eager, runner.serial_step
-
     def barrier():
         if world > 1:
             dist.barrier()
@@ -197,110 +177,180 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
-    log("engine ready")
-    step()
-    torch.cuda.synchronize()
-    log("first step done")
-    # The step is ~760 dependent kernel launches with no host decisions in between: capture it once
-    # into hipGraph(s) and replay (the launch-bound inner loop is the graph, not the Python loop).
-    if runner.capture():
-        log("step captured into a hipGraph" + (f" ({len(runner.graphs)} parts, an all-reduce behind each)" if runner.two_parts else ""))
-    elif runner.want_graph:
-        log("graph capture unavailable; running eagerly")
-    run = runner.step
-    for i in range(args.warmup):
-        run()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    t_host = time.perf_counter() - t0
-    barrier()
-    dt = time.perf_counter() - t0
-    log(f"host launch time {1e3 * t_host / args.steps:.2f} ms/step")
-    if world > 1:
-        t = torch.tensor([dt], device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
-    ms_per_step = 1e3 * dt / args.steps
-    log(f"timed region done: {ms_per_step:.2f} ms/step")
-    value = world * args.batch * args.steps / dt
-
-    # ---- roofline of the dominant kernel (m3_gemm_nt: every Linear / FMoELinear forward + input-gradient GEMM;
-    # two device kernels behind it, gemm_nt_dma_kernel for short K and gemm_nt_kernel), measured with HIP events
-    # around each launch, on the launch stream, in a few extra instrumented steps.  Primary figures: the launches
-    # of a step issued on ONE stream, i.e. each kernel by itself - this is what rocprofv3's per-kernel duration
-    # reports too (profiles/).  "as_timed" repeats the measurement with the task passes on concurrent streams as
-    # in the timed region: there the event pair also spans the time a launch waits for CU slots held by the other
-    # pass's kernels, so it is an upper bound of the kernel's duration, not its resource time.
-    n_inst = min(3, args.steps)
-    with GemmTimer(ops) as gt1:
-        for _ in range(n_inst):
-            serial_step()
+    def run_mode(dtype_name, expert_parallel, want_roofline):
+        """One timed configuration: W untimed warm-up steps, exactly K timed steps between barriers, max over ranks.
+        Returns the fields of the JSON line that depend on the mode."""
+        cfg = BackboneConfig(**VIT_SMALL_MOE)
+        dtype = torch.float16 if dtype_name == "f16" else torch.float32
+        params = init_params(cfg, seed=1)                       # same weights on every rank
+        # m3vit_amd/step.py: one engine context + HIP stream per task pass, hipGraph capture, and for N > 1 the
+        # all-reduce of the upper blocks' gradients overlapped with the lower blocks' backward
+        runner = MultiTaskStep(cfg, params, batch=args.batch, dtype=dtype, device=str(dev), cv_weight=CV_WEIGHT,
+                               parallel_tasks=not args.serial_tasks, graph=not args.no_graph, world=world, rank=rank,
+                               expert_parallel=expert_parallel, wgrad_streams=args.wgrad_streams, dp_parts=args.dp_parts)
+        use_ep, par_tasks, ntasks = runner.use_ep, runner.par, len(runner.tasks)
+        g = torch.Generator().manual_seed(1000 + rank)          # each rank its own images
+        images = torch.randn(args.batch, 3, *cfg.img_size, generator=g).to(dev)
+        dtok = (torch.randn(args.batch, cfg.num_tokens, cfg.embed_dim, generator=g) * 0.05).to(dev)
+        noises = bias = None
+        if args.noisy:          # SURVEY section 8(d): second run with std = 1 and a caller-supplied noise tensor (seed 2)
+            cfg.vmoe_noisy_std = 1.0
+            gn = torch.Generator().manual_seed(2)
+            noises = {t: {i: torch.randn(args.batch * cfg.num_tokens, cfg.moe_experts, generator=gn).to(dev)
+                          for i in range(cfg.depth) if i % 2 == 1} for t in runner.tasks}
+        if args.skew:           # routing-skew variant: one expert receives ~4x the mean load
+            b = torch.zeros(cfg.moe_experts); b[0] = 8.0
+            bias = {i: b.to(dev) for i in range(cfg.depth) if i % 2 == 1}
+        runner.bind(images, dtok, noises=noises, logit_bias=bias)     # inputs resident in HBM before anything is timed
+        step, serial_step = runner.step_eager, runner.serial_step
+        tag = f"{dtype_name}/{'ep' if use_ep else ('dp' if world > 1 else 'single')}"
+        log(f"{tag}: engine ready")
+        step()
         torch.cuda.synchronize()
-    g1 = gt1.summary()
-    gs = None
-    if par_tasks:
-        with GemmTimer(ops) as gt:
-            for _ in range(n_inst):
-                step()
-            torch.cuda.synchronize()
-        gs = gt.summary()
-    peak = PEAK[args.dtype]
-    # HBM traffic per launch of that kernel: PMC numbers cannot be read from inside the process; they come from
-    # the committed rocprofv3 --pmc passes over this same workload (profiles/r01_pmc_traffic.json)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-            pm = json.load(fh)
-        if pm.get("dtype") == args.dtype and args.batch == 128:
-            traffic = round(pm["kernels"]["gemm_nt_all"]["hbm_bytes_per_launch"])
-    except Exception:
-        traffic = None
-    # Which roof binds: the launches' arithmetic intensity (algorithmic FLOPs / algorithmic bytes) against the machine
-    # balance peak_flops / peak_bandwidth.  fp16: ~170 FLOP/B < 312 -> the HBM roof (the K = 384 GEMMs of
-    # this model are on the HBM side of the ridge); fp32: ~85 FLOP/B > 19.7 -> the MFMA roof.
-    intensity = g1["flops_per_launch"] / g1["bytes_per_launch"]
-    hbm_bound = intensity < peak * 1e12 / (PEAK_HBM * 1e9)
-    roofline = {"kernel": "m3_gemm_nt (gemm_nt_dma_kernel + gemm_nt_kernel)",
-                "bound": "hbm" if hbm_bound else "mfma",
-                "achieved": round(g1["gbps"], 1) if hbm_bound else round(g1["tflops"], 2),
-                "peak": PEAK_HBM if hbm_bound else peak,
-                "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                "frac": round(g1["gbps"] / PEAK_HBM, 4) if hbm_bound else round(g1["tflops"] / peak, 4),
-                "traffic": traffic,
-                "avg_launch_us": round(g1["avg_us"], 2), "launches_per_step": g1["launches"] // n_inst,
-                "flops_per_launch": g1["flops_per_launch"], "bytes_per_launch": round(g1["bytes_per_launch"]),
-                "flop_per_byte": round(intensity, 1),
-                "mfma_tflops": round(g1["tflops"], 2), "mfma_frac": round(g1["tflops"] / peak, 4),
-                "hbm_gbps": round(g1["gbps"], 1), "hbm_frac": round(g1["gbps"] / PEAK_HBM, 4),
-                "expert_grouped_gemm_tflops": round(g1["grouped_tflops"], 2),
-                "expert_grouped_gemm_frac": round(g1["grouped_tflops"] / peak, 4),
-                "expert_grouped_gemm_gbps": round(g1["grouped_gbps"], 1),
-                "launch_mode": "the step's launches on one stream (kernel by itself)"}
-    if gs is not None:
-        roofline["as_timed"] = {"launch_mode": f"{ntasks} concurrent task streams; event pairs include waiting for CU slots",
-                                "mfma_tflops": round(gs["tflops"], 2), "hbm_gbps": round(gs["gbps"], 1),
-                                "avg_launch_us": round(gs["avg_us"], 2)}
+        log(f"{tag}: first step done")
+        # The step is ~760 dependent kernel launches with no host decisions in between: capture it once
+        # into hipGraph(s) and replay (the launch-bound inner loop is the graph, not the Python loop).
+        if runner.capture():
+            log(f"{tag}: step captured into a hipGraph" + (f" ({len(runner.graphs)} parts, an all-reduce behind each)" if runner.two_parts else ""))
+        elif runner.want_graph:
+            log(f"{tag}: graph capture unavailable ({runner.capture_error}); running eagerly")
+        run = runner.step
+        for i in range(args.warmup):
+            run()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        t_host = time.perf_counter() - t0
+        barrier()
+        dt = time.perf_counter() - t0
+        log(f"{tag}: host launch time {1e3 * t_host / args.steps:.2f} ms/step")
+        if world > 1:
+            t = torch.tensor([dt], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        ms_per_step = 1e3 * dt / args.steps
+        log(f"{tag}: timed region done: {ms_per_step:.2f} ms/step")
+        step_flops = 3.0 * cfg.fwd_flops_per_image() * args.batch * ntasks
+        res = {"value": round(world * args.batch * args.steps / dt, 2), "ms_per_step": round(ms_per_step, 3),
+               "model_tflops": round(step_flops * args.steps / dt / 1e12 * world, 2), "launch": runner.launch,
+               "task_streams": ntasks if par_tasks else 1, "wgrad_streams": len(runner.engs) if args.wgrad_streams else 0,
+               "task_passes": ntasks, "tokens_per_image": cfg.num_tokens,
+               "parallelism": "single" if world == 1 else (f"dp{world}+ep{world} (experts sharded, RCCL all-to-all + all-reduce)"
+                                                            if use_ep else f"dp{world} (replicated experts, RCCL all-reduce)")}
+        if want_roofline:
+            res["roofline"] = roofline_of(ops, runner, dtype_name, step, serial_step, par_tasks, ntasks)
+        del runner
+        torch.cuda.empty_cache()
+        return res
 
-    step_flops = 3.0 * cfg.fwd_flops_per_image() * args.batch * ntasks
+    def roofline_of(ops, runner, dtype_name, step, serial_step, par_tasks, ntasks):
+        # ---- roofline of the dominant kernel (m3_gemm_nt: every Linear / FMoELinear forward + input-gradient GEMM;
+        # two device kernels behind it, gemm_nt_dma_kernel for short K and gemm_nt_kernel), measured with HIP events
+        # around each launch, on the launch stream, in a few extra instrumented steps.  Primary figures: the launches
+        # of a step issued on ONE stream, i.e. each kernel by itself - this is what rocprofv3's per-kernel duration
+        # reports too (profiles/).  "as_timed" repeats the measurement with the task passes on concurrent streams as
+        # in the timed region: there the event pair also spans the time a launch waits for CU slots held by the other
+        # pass's kernels, so it is an upper bound of the kernel's duration, not its resource time.
+        n_inst = min(3, args.steps)
+        with GemmTimer(ops) as gt1:
+            for _ in range(n_inst):
+                serial_step()
+            torch.cuda.synchronize()
+        g1 = gt1.summary()
+        gs = None
+        if par_tasks:
+            with GemmTimer(ops) as gt:
+                for _ in range(n_inst):
+                    step()
+                torch.cuda.synchronize()
+            gs = gt.summary()
+        peak = PEAK[dtype_name]
+        # HBM traffic per launch of that kernel: PMC numbers cannot be read from inside the process; they come from the
+        # newest committed rocprofv3 --pmc passes over this same workload (profiles/rNN_pmc_traffic.json, named in
+        # traffic_source together with the commit they were taken at) - a replayed measurement, not a live one
+        traffic = traffic_source = None
+        try:
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+            with open(files[-1]) as fh:
+                pm = json.load(fh)
+            if pm.get("dtype") == dtype_name and args.batch == 128:
+                traffic = round(pm["kernels"]["gemm_nt_all"]["hbm_bytes_per_launch"])
+                traffic_source = f"profiles/{os.path.basename(files[-1])} (rocprofv3 --pmc passes" + \
+                                 (f", taken at commit {pm['head']}" if pm.get("head") else "") + "; not measured in this run)"
+        except Exception:
+            traffic = traffic_source = None
+        # Which roof binds: the launches' arithmetic intensity (algorithmic FLOPs / algorithmic bytes) against the machine
+        # balance peak_flops / peak_bandwidth.  fp16: ~170 FLOP/B < 312 -> the HBM roof (SURVEY 8d: the K = 384 GEMMs of
+        # this model are on the HBM side of the ridge); fp32: ~85 FLOP/B > 19.7 -> the MFMA roof.
+        intensity = g1["flops_per_launch"] / g1["bytes_per_launch"]
+        hbm_bound = intensity < peak * 1e12 / (PEAK_HBM * 1e9)
+        roofline = {"kernel": "m3_gemm_nt (gemm_nt_dma_kernel + gemm_nt_kernel)",
+                    "bound": "hbm" if hbm_bound else "mfma",
+                    "achieved": round(g1["gbps"], 1) if hbm_bound else round(g1["tflops"], 2),
+                    "peak": PEAK_HBM if hbm_bound else peak,
+                    "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                    "frac": round(g1["gbps"] / PEAK_HBM, 4) if hbm_bound else round(g1["tflops"] / peak, 4),
+                    "traffic": traffic, "traffic_source": traffic_source,
+                    "avg_launch_us": round(g1["avg_us"], 2), "launches_per_step": g1["launches"] // n_inst,
+                    "flops_per_launch": g1["flops_per_launch"], "bytes_per_launch": round(g1["bytes_per_launch"]),
+                    "flop_per_byte": round(intensity, 1),
+                    "mfma_tflops": round(g1["tflops"], 2), "mfma_frac": round(g1["tflops"] / peak, 4),
+                    "hbm_gbps": round(g1["gbps"], 1), "hbm_frac": round(g1["gbps"] / PEAK_HBM, 4),
+                    "expert_grouped_gemm_tflops": round(g1["grouped_tflops"], 2),
+                    "expert_grouped_gemm_frac": round(g1["grouped_tflops"] / peak, 4),
+                    "expert_grouped_gemm_gbps": round(g1["grouped_gbps"], 1),
+                    "launch_mode": "the step's launches on one stream (kernel by itself)"}
+        if gs is not None:
+            roofline["as_timed"] = {"launch_mode": f"{ntasks} concurrent task streams; event pairs include waiting for CU slots",
+                                    "mfma_tflops": round(gs["tflops"], 2), "hbm_gbps": round(gs["gbps"], 1),
+                                    "avg_launch_us": round(gs["avg_us"], 2)}
+        return roofline
+
+    # ---- which configurations this invocation times
+    #  N = 1: the primary dtype (f16, the reference's AMP arithmetic) with the roofline object, then - unless --dtype
+    #         was given explicitly - the fp32 run (the arithmetic of train_fastmoe.py) as the sub-object "f32";
+    #  N > 1: north_star's expert-parallel form (experts sharded E/N per rank, all-to-all over RCCL) is the primary
+    #         when the experts divide over the ranks, and the replicated-experts data-parallel form (the reference's
+    #         --moe_data_distributed mode) is timed as well: both appear as the sub-objects "ep" and "dp".
+    E = VIT_SMALL_MOE["moe_experts"]
+    extra = {}
+    if world == 1:
+        main_res = run_mode(args.dtype, False, True)
+        if args.dtype == "f16" and not args.no_f32:
+            f32 = run_mode("f32", False, True)
+            extra["f32"] = {k: f32[k] for k in ("value", "ms_per_step", "model_tflops", "launch", "roofline")}
+            extra["f32"]["dtype"] = "f32"
+    else:
+        modes = []
+        if args.ep or (not args.dp_only and E % world == 0):
+            modes.append(True)
+        if not args.ep:
+            modes.append(False)
+        results = {ep: run_mode(args.dtype, ep, False) for ep in modes}
+        primary = modes[0]
+        main_res = results[primary]
+        for ep, r in results.items():
+            extra["ep" if ep else "dp"] = {k: r[k] for k in ("value", "ms_per_step", "model_tflops", "launch", "parallelism")}
     out = {
         "metric": "images/sec fwd+bwd ViT-S/16 MoE(E=16,k=4) 224^2 bs=128",
-        "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": main_res["value"], "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "configs[1]: ViT-Small/16 + MoE E=16 top-k=4 multi_gate, synthetic 224x224",
-                   "batch_per_gpu": args.batch, "global_batch": args.batch * world, "task_passes": ntasks,
-                   "tokens_per_image": cfg.num_tokens, "cv_loss_weight": CV_WEIGHT,
-                   "launch": runner.launch,
+                   "batch_per_gpu": args.batch, "global_batch": args.batch * world, "task_passes": main_res["task_passes"],
+                   "tokens_per_image": main_res["tokens_per_image"], "cv_loss_weight": CV_WEIGHT,
+                   "launch": main_res["launch"],
                    "routing": ("noisy gate std=1 (supplied noise, CDF load loss)" if args.noisy else "deterministic (std=0)") +
                               (", skewed: expert 0 in every token's top-k" if args.skew else ""),
-                   "task_streams": ntasks if par_tasks else 1, "wgrad_streams": len(runner.engs) if args.wgrad_streams else 0,
-                   "parallelism": "single" if world == 1 else (f"dp{world}+ep{world} (experts sharded, RCCL all-to-all + all-reduce)"
-                                                                    if use_ep else f"dp{world} (replicated experts, RCCL all-reduce)")},
-        "model_tflops": round(step_flops * args.steps / dt / 1e12 * world, 2),
-        "roofline": roofline,
+                   "task_streams": main_res["task_streams"], "wgrad_streams": main_res["wgrad_streams"],
+                   "parallelism": main_res["parallelism"]},
+        "model_tflops": main_res["model_tflops"],
     }
+    if "roofline" in main_res:
+        out["roofline"] = main_res["roofline"]
+    out.update(extra)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             cores = len(os.sched_getaffinity(0))

@@ -126,6 +126,18 @@ int m3_route_build(const int32_t *idx32, int64_t n, int E, int32_t *counts, int3
                    int32_t *pos, int32_t *row_of_slot, int32_t *tile_starts, int64_t *counts64,
                    int32_t *ws, void *stream);
 
+/* Expert-parallel exchange plan, on the device (what fastmoe's expert_exchange / global_scatter bookkeeping computes
+ * on the host behind _fmoe_general_global_forward with world_size > 1, models/moe/ckpt/custom_moe_layer.py:263-265;
+ * experts sharded E_loc per rank, utils/common_config.py:179-185).
+ * send_counts i64 [W*E_loc]: this rank's route_build counts by GLOBAL expert id (entry d*E_loc+e goes to local expert e
+ * of rank d); recv_counts i64 [W*E_loc]: their all-to-all (entry s*E_loc+e = rows rank s sends to my expert e).
+ * Outputs: splits i64 [2W] = rows sent to each rank, then rows received from each rank (the a2a-v sizes: the ONLY
+ * values the host reads); regroup i32 [regroup_cap >= rows received]: received rows arrive ordered (src, e), the
+ * grouped GEMMs take slot i of the (e, src) order from row regroup[i] (as a_row_idx / c_row_idx); offsets,
+ * tile_starts i32 [E_loc+1] as m3_route_build writes them.  W * E_loc <= 4096. */
+int m3_ep_plan(const int64_t *send_counts, const int64_t *recv_counts, int W, int E_loc, int64_t *splits,
+               int32_t *regroup, int64_t regroup_cap, int32_t *offsets, int32_t *tile_starts, void *stream);
+
 /* -------------------------------------------------- GEMM family (a6, a8, a10)
  * C[m, n] = epilogue( sum_k A[arow(m), k] * B[g(m)][n, k] )      ("NT": both K-contiguous)
  *   FMoELinear fwd/dgrad: custom_moe_layer.py:32-33,41,43; qkv/proj Linear:
@@ -139,7 +151,9 @@ int m3_route_build(const int32_t *idx32, int64_t n, int E, int32_t *counts, int3
  *   row of C for slot m (MOEGather back to token-major).
  * Epilogue, in this order: + bias[g][n] (fp32) ; store pre-activation to pre_out (act
  * dtype) if non-NULL ; act (GELU) ; * gelu'(gelu_grad_pre[m,n]) if non-NULL ;
- * + residual[m,n] (fp32) if non-NULL ; store as c_dtype (M3_F32 or the act dtype).
+ * * row_scale[crow(m) / row_scale_div] (fp32) if non-NULL - the per-sample DropPath factor of the residual branch
+ * the GEMM closes, vision_transformer_moe.py:167-185,441,450 ; + residual[m,n] (fp32) if non-NULL ; store as c_dtype
+ * (M3_F32 or the act dtype).
  * Requirements: K*sizeof(elem) % 16 == 0, lda/ldb rows 16-byte aligned, N % 4 == 0. */
 typedef struct {
   const void *A; int64_t lda;
@@ -157,6 +171,8 @@ typedef struct {
   const int32_t *group_offsets;    /* [G+1] device, or NULL for dense */
   const int32_t *tile_starts;      /* [G+1] device, or NULL for dense */
   int32_t dtype;                   /* M3_F32 / M3_F16: element type of A, B, pre */
+  const float *row_scale;          /* fp32 [ceil(rows / row_scale_div)] or NULL */
+  int32_t row_scale_div;
 } m3_gemm_args;
 int m3_gemm_nt(const m3_gemm_args *args, void *stream);
 
@@ -307,6 +323,11 @@ int m3_cast_batch(const m3_cast_desc *descs_dev, int n_desc, int total_tiles, in
 int m3_add_f32(float *dst, const float *src, int64_t n, void *stream);
 /* dst(T)[i] = src(f32)[i] ; n elements */
 int m3_cast_f32(const float *src, int64_t n, void *dst, int dst_dtype, void *stream);
+/* dst(T)[r, :] = row_scale[r / div] * src(f32)[r, :]  (rows x cols, cols % 4 == 0): the gradient that enters a residual
+ * branch behind a DropPath (vision_transformer_moe.py:167-185: d branch = scale[sample] * d x), as the activation-dtype
+ * operand of the branch's backward GEMMs. */
+int m3_scale_rows_cast(const float *src, int64_t rows, int cols, const float *row_scale, int div, void *dst,
+                       int dst_dtype, void *stream);
 /* patchify: images [B,3,H,W] fp32 NCHW -> rows [B*(H/P)*(W/P), 3*P*P] act dtype in
  * conv-weight order (c, py, px): PatchEmbed conv16/16, vision_transformer_moe.py:330-341 */
 int m3_im2row(const float *img, int B, int Cin, int H, int W, int P, void *rows, int dtype,

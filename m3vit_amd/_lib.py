@@ -37,6 +37,7 @@ class GemmArgs(Structure):
         ("group_offsets", c_void_p),
         ("tile_starts", c_void_p),
         ("dtype", c_int32),
+        ("row_scale", c_void_p), ("row_scale_div", c_int32),
     ]
 
 
@@ -115,6 +116,7 @@ SIGNATURES = {
     "m3_gate_bwd_params": (c_int, [_V, _I, _L, _I, _L, _V, _I, _V, _V, _V, _I, _V, _L, _I, _V]),
     "m3_route_ws_elems": (c_int64, [_L, _I]),
     "m3_route_build": (c_int, [_V, _L, _I, _V, _V, _V, _V, _V, _V, _V, _V]),
+    "m3_ep_plan": (c_int, [_V, _V, _I, _I, _V, _V, _L, _V, _V, _V]),
     "m3_gemm_nt": (c_int, [POINTER(GemmArgs), _V]),
     "m3_ffn_fwd": (c_int, [POINTER(FfnArgs), _V]),
     "m3_wgrad_tn": (c_int, [POINTER(WgradArgs), _V]),
@@ -136,6 +138,7 @@ SIGNATURES = {
     "m3_cast_batch": (c_int, [_V, _I, _I, _I, _V]),
     "m3_add_f32": (c_int, [_V, _V, _L, _V]),
     "m3_cast_f32": (c_int, [_V, _L, _V, _I, _V]),
+    "m3_scale_rows_cast": (c_int, [_V, _L, _I, _V, _I, _V, _I, _V]),
     "m3_im2row": (c_int, [_V, _I, _I, _I, _I, _I, _V, _I, _V]),
     "m3_assemble_tokens": (c_int, [_V, _V, _V, _I, _I, _I, _V, _V]),
     "m3_tokens_bwd": (c_int, [_V, _I, _I, _I, _V, _I, _V, _V, _I, _V]),

@@ -104,28 +104,68 @@ def merge_rank_shards(dirname: str) -> Tuple[dict, "OrderedDict[str, torch.Tenso
     return base, merged, len(ranks)
 
 
-def build_meta(state, source: str, world_size: int = 1, moe_experts_global: Optional[int] = None) -> dict:
+def build_mtl_meta(state, source, world_size: Optional[int] = None, moe_experts_global: Optional[int] = None,
+                   moe_experts_local: Optional[int] = None) -> dict:
+    """`meta` of a global single-file checkpoint, pretrain/utils/moe_checkpoint.py:81-112 (same argument names and
+    defaults; pinned to the reference's outputs by tests/golden/g7_checkpoint_formats.npz): the global expert count
+    defaults to the first expert tensor's dim 0, the local one to dim0 // world_size when that divides, else dim0."""
+    if world_size is None:
+        import torch.distributed as dist
+        world_size = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     d0 = first_expert_dim0(state)
-    glob = int(moe_experts_global if moe_experts_global is not None else (d0 or 0))
-    local = 0 if d0 is None else (glob // world_size if world_size > 0 and glob % world_size == 0 else glob)
-    return {"expert_format": "global", "moe_experts_global": glob, "moe_experts_local": int(local),
-            "world_size": int(world_size), "source": str(source)}
+    if moe_experts_global is None and d0 is not None:
+        moe_experts_global = int(d0)
+    if moe_experts_local is None:
+        if d0 is None:
+            moe_experts_local = 0
+        elif world_size > 0 and d0 % world_size == 0:
+            moe_experts_local = int(d0 // world_size)
+        else:
+            moe_experts_local = int(d0)
+    return {"expert_format": "global", "moe_experts_global": int(moe_experts_global) if moe_experts_global is not None else 0,
+            "moe_experts_local": int(moe_experts_local), "world_size": int(world_size), "source": str(source)}
+
+
+def build_meta(state, source: str, world_size: int = 1, moe_experts_global: Optional[int] = None) -> dict:
+    return build_mtl_meta(state, source, world_size=world_size, moe_experts_global=moe_experts_global)
+
+
+def to_mtl_backbone_state_dict(state):
+    """model / wrapper state_dict -> the backbone-only key space of the MTL loader
+    (pretrain/utils/moe_checkpoint.py:24-50): ONE leading `module.` stripped, then `encoder.` stripped, the wrapper's own
+    top-level `head.*` / `norm.*` dropped.  Returns (state, dropped keys)."""
+    out, dropped = OrderedDict(), []
+    for key, value in state.items():
+        if key.startswith("module."):
+            key = key[len("module."):]
+        if key.startswith("encoder."):
+            out[key[len("encoder."):]] = value
+        elif key.startswith("head.") or key.startswith("norm."):
+            dropped.append(key)
+        else:
+            out[key] = value
+    return out, dropped
 
 
 def infer_expert_format(checkpoint, state, expected_global_experts: Optional[int] = None,
                         expected_world_size: Optional[int] = None) -> str:
-    """'global' | 'local' | 'dense' | 'unknown'; an explicit meta.expert_format wins, then the expert dim 0 against
-    the expected expert count (or checkpoint['args'])."""
-    meta = checkpoint.get("meta", {}) if isinstance(checkpoint, dict) else {}
-    if isinstance(meta, dict) and meta.get("expert_format") in ("global", "local"):
-        return meta["expert_format"]
+    """'global' | 'local' | 'dense' | 'unknown' (pretrain/utils/moe_checkpoint.py:131-171): an explicit
+    meta.expert_format wins; else the first expert tensor's dim 0 against the expected global expert count.
+    checkpoint['args'] is consulted ONLY when expected_global_experts is not given (and its world_size only when
+    expected_world_size is not given either), exactly as the reference does."""
+    if isinstance(checkpoint, dict):
+        meta = checkpoint.get("meta", {})
+        if isinstance(meta, dict) and meta.get("expert_format", None) in ("global", "local"):
+            return meta["expert_format"]
     d0 = first_expert_dim0(state)
     if d0 is None:
         return "dense"
-    args = checkpoint.get("args", {}) if isinstance(checkpoint, dict) else {}
-    if isinstance(args, dict):
-        expected_global_experts = args.get("moe_experts", None) if expected_global_experts is None else expected_global_experts
-        expected_world_size = args.get("world_size", None) if expected_world_size is None else expected_world_size
+    if expected_global_experts is None and isinstance(checkpoint, dict):
+        args = checkpoint.get("args", {})
+        if isinstance(args, dict):
+            expected_global_experts = args.get("moe_experts", None)
+            if expected_world_size is None:
+                expected_world_size = args.get("world_size", None)
     if expected_global_experts is not None:
         if d0 == int(expected_global_experts):
             return "global"
@@ -175,8 +215,17 @@ def to_backbone_state(checkpoint, rank: int = 0, world_size: int = 1, expected_g
     state = adapt_gates(state, multi_gate, num_tasks, extra_gate_rows)
     if grid_hw is not None and "pos_embed" in state and state["pos_embed"].shape[1] != 1 + grid_hw[0] * grid_hw[1]:
         state["pos_embed"] = resize_pos_embed(state["pos_embed"], grid_hw)
-    if world_size > 1 and fmt in ("global", "unknown"):
+    if world_size > 1 and fmt != "local":
         d0 = first_expert_dim0(state)
-        if d0 is not None and d0 % world_size == 0 and (expected_global_experts in (None, d0)):
+        if d0 is not None:
+            # shard a state that is KNOWN to be global: meta / shapes say so, or its expert count is the expected one.
+            # Anything else (e.g. a rank-local shard without meta or args) must not be sliced a second time.
+            known_global = fmt == "global" or (fmt == "unknown" and expected_global_experts is not None
+                                               and d0 == int(expected_global_experts))
+            if not known_global:
+                raise ValueError(f"cannot tell whether the checkpoint's {d0} experts per tensor are global or rank-local "
+                                 f"(format '{fmt}'): pass expected_global_experts or write meta.expert_format")
+            if d0 % world_size != 0:
+                raise ValueError(f"{d0} global experts do not divide over {world_size} ranks")
             state = shard_experts(state, rank, d0 // world_size)
     return state, fmt

@@ -50,6 +50,7 @@ struct GemmDev {
   char *pre_out; int64_t ld_pre;
   const char *gpre; int64_t ld_gpre;
   const float *residual; int64_t ld_res;
+  const float *row_scale; int32_t row_scale_div;   // value *= row_scale[crow / div] in front of the residual add
   int32_t act;
   int64_t M; int32_t N; int32_t K;
   int32_t G;
@@ -264,6 +265,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
 #pragma unroll
           for (int j = 0; j < 4; ++j) { v0[j] *= gelu_grad_f(p0[j]); v1[j] *= gelu_grad_f(p1[j]); }
         }
+        if (p.row_scale) {
+          const float sc = p.row_scale[crow / p.row_scale_div];
+          v0 *= sc; v1 *= sc;
+        }
         if (p.residual) {
           v0 += *(const f32x4 *)(p.residual + crow * p.ld_res + n);
           v1 += *(const f32x4 *)(p.residual + crow * p.ld_res + n + 4);
@@ -303,6 +308,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
         v[0] *= gelu_grad_f(pr[0]); v[1] *= gelu_grad_f(pr[1]);
         v[2] *= gelu_grad_f(pr[2]); v[3] *= gelu_grad_f(pr[3]);
       }
+      if (p.row_scale) v *= p.row_scale[crow / p.row_scale_div];
       if (p.residual) v += *(const f32x4 *)(p.residual + crow * p.ld_res + n);
       if (p.c_f32) *(f32x4 *)((float *)p.C + crow * p.ldc + n) = v;
       else Vec4<T>::store((T *)p.C + crow * p.ldc + n, v);
@@ -488,6 +494,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const Gemm
 #pragma unroll
           for (int j = 0; j < 4; ++j) { v0[j] *= gelu_grad_f(p0[j]); v1[j] *= gelu_grad_f(p1[j]); }
         }
+        if (p.row_scale) {
+          const float sc = p.row_scale[crow / p.row_scale_div];
+          v0 *= sc; v1 *= sc;
+        }
         if (p.residual) {
           v0 += *(const f32x4 *)(p.residual + crow * p.ld_res + n);
           v1 += *(const f32x4 *)(p.residual + crow * p.ld_res + n + 4);
@@ -531,6 +541,7 @@ extern "C" int m3_gemm_nt(const m3_gemm_args *a, void *stream) {
   M3_REQUIRE(!a->pre_out || a->ld_pre % 4 == 0, "m3_gemm_nt: ld_pre % 4");
   M3_REQUIRE(!a->gelu_grad_pre || a->ld_gpre % 4 == 0, "m3_gemm_nt: ld_gpre % 4");
   M3_REQUIRE(!a->residual || a->ld_res % 4 == 0, "m3_gemm_nt: ld_res % 4");
+  M3_REQUIRE(!a->row_scale || a->row_scale_div >= 1, "m3_gemm_nt: row_scale_div must be >= 1");
   if (a->M == 0) return M3_OK;
 
   GemmDev d;
@@ -543,6 +554,7 @@ extern "C" int m3_gemm_nt(const m3_gemm_args *a, void *stream) {
   d.pre_out = (char *)a->pre_out; d.ld_pre = a->ld_pre;
   d.gpre = (const char *)a->gelu_grad_pre; d.ld_gpre = a->ld_gpre;
   d.residual = a->residual; d.ld_res = a->ld_res;
+  d.row_scale = a->row_scale; d.row_scale_div = a->row_scale ? a->row_scale_div : 1;
   d.act = a->act;
   d.M = a->M; d.N = a->N; d.K = a->K; d.G = a->G;
   d.group_offsets = a->group_offsets; d.tile_starts = a->tile_starts;

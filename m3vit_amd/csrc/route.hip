@@ -110,10 +110,65 @@ __global__ __launch_bounds__(RT_THREADS) void route_assign_kernel(const int32_t 
       for (int w = 0; w < wave; ++w) s += wcnt[w][my];
       pos[i] = s;
       row_of_slot[s] = (int32_t)i;
+    } else if (i < n) {
+      // an id outside [0, E) is a caller error (Route.check() / offsets[E] != n reports it); it gets no slot.  Keep the
+      // metadata in range all the same: consumers gather through pos / row_of_slot with M = n rows.
+      pos[i] = 0;
     }
+    if (i < n && i >= offsets[E]) row_of_slot[i] = 0;       // slots past the last routed row (only with dropped ids)
     __syncthreads();
     for (int e = threadIdx.x; e < E; e += RT_THREADS) run[e] += wcnt[0][e] + wcnt[1][e] + wcnt[2][e] + wcnt[3][e];
     __syncthreads();
+  }
+}
+
+// ---- expert-parallel exchange plan (fastmoe expert_exchange / global_scatter bookkeeping behind
+// _fmoe_general_global_forward for world_size > 1, models/moe/ckpt/custom_moe_layer.py:263-265), on the device:
+// send[d * E_loc + e]: rows this rank routes to local expert e of rank d (its route_build counts, by global expert id);
+// recv[s * E_loc + e]: rows rank s routes to this rank's local expert e (the all-to-all of the former).
+// Rows arrive ordered (src, e); the local grouped GEMMs want (e, src): rg[i] = position in the received buffer of the
+// i-th row of the expert-major order.  Also: the a2a-v split sizes (the only values the host reads), the expert-major
+// group offsets and the 128-row tile prefix the grouped GEMMs take.
+constexpr int EP_MAX_BLOCKS = 64 * 64;       // W * E_loc (sources x local experts)
+__global__ __launch_bounds__(256) void ep_plan_kernel(const int64_t *send, const int64_t *recv, int W, int E_loc,
+                                                      int64_t *splits, int32_t *rg, int64_t rg_cap, int32_t *offsets,
+                                                      int32_t *tile_starts) {
+  __shared__ int32_t src_start[EP_MAX_BLOCKS];    // [s * E_loc + e]: first received row of block (s, e)
+  __shared__ int32_t em_start[EP_MAX_BLOCKS + 1]; // [e * W + s]: first expert-major slot of block (e, s)
+  const int nb = W * E_loc;
+  if (threadIdx.x == 0) {
+    int32_t o = 0;
+    for (int b = 0; b < nb; ++b) { src_start[b] = o; o += (int32_t)recv[b]; }
+    o = 0;
+    int32_t ts = 0;
+    for (int e = 0; e < E_loc; ++e) {
+      if (blockIdx.x == 0) { offsets[e] = o; tile_starts[e] = ts; }
+      const int32_t o0 = o;
+      for (int s = 0; s < W; ++s) { em_start[e * W + s] = o; o += (int32_t)recv[s * E_loc + e]; }
+      ts += (o - o0 + 127) / 128;
+    }
+    em_start[nb] = o;
+    if (blockIdx.x == 0) {
+      offsets[E_loc] = o;
+      tile_starts[E_loc] = ts;
+      for (int d = 0; d < W; ++d) {
+        int64_t a = 0, b = 0;
+        for (int e = 0; e < E_loc; ++e) { a += send[d * E_loc + e]; b += recv[d * E_loc + e]; }
+        splits[d] = a;            // rows this rank sends to rank d
+        splits[W + d] = b;        // rows this rank receives from rank d
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t n = em_start[nb] < rg_cap ? em_start[nb] : rg_cap;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int lo = 0, hi = nb - 1;                      // last block with em_start <= i
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (em_start[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    const int e = lo / W, s = lo - e * W;
+    rg[i] = src_start[s * E_loc + e] + (int32_t)(i - em_start[lo]);
   }
 }
 
@@ -144,4 +199,16 @@ extern "C" int m3_route_build(const int32_t *idx32, int64_t n, int E, int32_t *c
   hipLaunchKernelGGL(route_assign_kernel, dim3(nblk), dim3(RT_THREADS), 0, s, idx32, n, E, blk_base, offsets, pos,
                      row_of_slot);
   return check_launch("m3_route_build(assign)");
+}
+
+extern "C" int m3_ep_plan(const int64_t *send_counts, const int64_t *recv_counts, int W, int E_loc, int64_t *splits,
+                          int32_t *regroup, int64_t regroup_cap, int32_t *offsets, int32_t *tile_starts, void *stream) {
+  M3_REQUIRE(send_counts && recv_counts && splits && regroup && offsets && tile_starts, "m3_ep_plan: null operand");
+  M3_REQUIRE(W >= 1 && E_loc >= 1 && W * E_loc <= EP_MAX_BLOCKS, "m3_ep_plan: W * E_loc = %d outside [1, %d]", W * E_loc, EP_MAX_BLOCKS);
+  M3_REQUIRE(regroup_cap >= 0 && regroup_cap < ((int64_t)1 << 31), "m3_ep_plan: regroup capacity out of range");
+  const int64_t want = (regroup_cap + 255) / 256;
+  const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 512 ? 512 : want));
+  hipLaunchKernelGGL(ep_plan_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, send_counts, recv_counts, W, E_loc, splits,
+                     regroup, regroup_cap, offsets, tile_starts);
+  return check_launch("m3_ep_plan");
 }

@@ -255,6 +255,15 @@ __global__ void cast_f32_kernel(const float *__restrict__ src, int64_t n4, T *__
   Vec4<T>::store(dst + i * 4, *(const f32x4 *)(src + i * 4));
 }
 
+template <typename T>
+__global__ void scale_rows_cast_kernel(const float *__restrict__ src, int64_t n4, int cols4, const float *__restrict__ scale,
+                                       int div, T *__restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float sc = scale[(i / cols4) / div];
+  Vec4<T>::store(dst + i * 4, *(const f32x4 *)(src + i * 4) * sc);
+}
+
 // rows[(b*hp + py)*wp + px][c*P*P + iy*P + ix] = img[b][c][py*P+iy][px*P+ix]
 template <typename T>
 __global__ void im2row_kernel(const float *__restrict__ img, int B, int Cin, int H, int W, int P, T *__restrict__ rows) {
@@ -408,6 +417,19 @@ extern "C" int m3_cast_f32(const float *src, int64_t n, void *dst, int dst_dtype
   if (dst_dtype == M3_F16) hipLaunchKernelGGL(cast_f32_kernel<half_t>, grid, block, 0, s, src, n4, (half_t *)dst);
   else hipLaunchKernelGGL(cast_f32_kernel<float>, grid, block, 0, s, src, n4, (float *)dst);
   return check_launch("m3_cast_f32");
+}
+
+extern "C" int m3_scale_rows_cast(const float *src, int64_t rows, int cols, const float *row_scale, int div, void *dst,
+                                  int dst_dtype, void *stream) {
+  M3_REQUIRE(src && dst && row_scale && rows >= 0 && cols > 0 && cols % 4 == 0 && div >= 1, "m3_scale_rows_cast: bad args");
+  M3_REQUIRE(dst_dtype == M3_F32 || dst_dtype == M3_F16, "m3_scale_rows_cast: bad dtype");
+  if (rows == 0) return M3_OK;
+  const int64_t n4 = rows * cols / 4;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)((n4 + 255) / 256)), block(256);
+  if (dst_dtype == M3_F16) hipLaunchKernelGGL(scale_rows_cast_kernel<half_t>, grid, block, 0, s, src, n4, cols / 4, row_scale, div, (half_t *)dst);
+  else hipLaunchKernelGGL(scale_rows_cast_kernel<float>, grid, block, 0, s, src, n4, cols / 4, row_scale, div, (float *)dst);
+  return check_launch("m3_scale_rows_cast");
 }
 
 extern "C" int m3_im2row(const float *img, int B, int Cin, int H, int W, int P, void *rows, int dtype, void *stream) {

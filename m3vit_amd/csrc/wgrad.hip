@@ -408,6 +408,7 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   M3_REQUIRE(a->dtype == M3_F32 || a->dtype == M3_F16, "m3_wgrad_tn: bad dtype");
   const int es = dtype_size(a->dtype);
   M3_REQUIRE(a->N > 0 && a->K > 0 && a->M >= 0 && a->G >= 1 && a->splits >= 1, "m3_wgrad_tn: bad shape");
+  M3_REQUIRE(a->M < ((int64_t)1 << 31), "m3_wgrad_tn: M exceeds the 32-bit row indices");
   M3_REQUIRE((a->N * es) % 16 == 0 && (a->K * es) % 16 == 0, "m3_wgrad_tn: N*elem and K*elem must be multiples of 16 bytes");
   M3_REQUIRE((a->lddc * es) % 16 == 0 && (a->lda * es) % 16 == 0, "m3_wgrad_tn: rows must be 16-byte aligned");
   M3_REQUIRE(((uintptr_t)a->dC % 16) == 0 && ((uintptr_t)a->A % 16) == 0 && ((uintptr_t)a->ws % 16) == 0, "m3_wgrad_tn: alignment");

@@ -189,6 +189,12 @@ class BackboneEngine:
         self.s_dl_t = self._e(T, self.E)
         self.s_dl = self._e(T, self.E, dtype=f32)
         self.cv_acc = torch.zeros(1, dtype=f32, device=self.dev)
+        if self.ep_world > 1:
+            # expert-parallel exchange plans: one regroup index per MoE block (kept for the backward; a rank can
+            # receive at most what all ranks route) and the pinned landing buffer of the split sizes
+            self.ep_regroup = {i: torch.empty(self.ep_world * R, dtype=torch.int32, device=self.dev)
+                               for i in range(self.depth) if self.is_moe[i]}
+            self.ep_splits_host = torch.empty(2 * self.ep_world, dtype=torch.int64, pin_memory=True)
 
     def cfg_d_gate(self):
         g = self.cfg.gate_task_specific_dim
@@ -282,29 +288,39 @@ class BackboneEngine:
         tv = tsf.detach()
         return {i: tv @ p[self._gate_weight(i, task_id)][D:] for i in range(self.depth) if self.is_moe[i]}
 
-    def _task_feature_bwd(self):
-        """d(logit bias) of every MoE block -> w_gate[D:] rows, tsf, and the gate_task_represent parameters."""
+    def _task_feature_block_bwd(self, a, dl, st):
+        """One MoE block's share of the task-conditioned gate backward, written straight after the block's d logits
+        exist: w_gate[D:] += outer(tsf, colsum(d logits)) and d tsf += w_gate[D:] @ colsum(d logits).  It must be part of
+        backward_blocks(): a data-parallel step all-reduces a block's gradient slice as soon as backward_blocks() has
+        passed the block (step.py), so nothing may be added to it later."""
         p, gr, D = self.params, self.grads, self.D
+        tv = self._tsf["tsf"].detach()
+        dlb = ops.colsum(dl, torch.empty(self.E, device=self.dev), ws=self.ws_colsum)
+        gr[a["wname"]][D:].addr_(tv, dlb)
+        if st.get("d_tsf") is None:
+            st["d_tsf"] = torch.zeros_like(tv)
+        st["d_tsf"] += p[a["wname"]][D:] @ dlb
+
+    def _task_feature_bwd(self, d_tsf):
+        """d tsf -> the gate_task_represent parameters (block -1: the last gradient slice)."""
         t = self._tsf
-        tv = t["tsf"].detach()
-        d_tsf = torch.zeros_like(tv)
-        for i in range(self.depth):
-            if not self.is_moe[i]:
-                continue
-            a = self.act[i]
-            dlb = a.pop("d_logit_bias")
-            gr[a["wname"]][D:].addr_(tv, dlb)
-            d_tsf += p[a["wname"]][D:] @ dlb
-        for n, g in zip(t["names"], torch.autograd.grad(t["tsf"], t["leaves"], d_tsf)):
-            gr[n] += g
+        if d_tsf is not None:
+            for n, g in zip(t["names"], torch.autograd.grad(t["tsf"], t["leaves"], d_tsf)):
+                self.grads[n] += g
         self._tsf = None
 
-    def forward(self, images: torch.Tensor, task_id: Optional[int], tsf_bias=None, noises=None):
+    def forward(self, images: torch.Tensor, task_id: Optional[int], tsf_bias=None, noises=None, path_scales=None):
         """Returns (tokens fp32 [B,N,D], total_cv_loss).  noises: {block: [T,E]} caller-supplied N(0,1).
         Task-conditioned configs compute the per-block logit bias tsf @ w_gate[D:] here (tsf_bias overrides
-        it with a caller-supplied {block: [E]} and then no gradient flows to the task embedding)."""
+        it with a caller-supplied {block: [E]} and then no gradient flows to the task embedding).
+        path_scales: {block: (attn [B], mlp [B])} fp32 per-sample DropPath factors of the block's two residual
+        branches (stochastic depth, vision_transformer_moe.py:167-185: floor(keep + U) / keep, drawn by the caller -
+        pretrain/configs/deit_moe_small.yaml:51 trains with drop_path > 0); the factor rides on the epilogue of the
+        GEMM that closes the branch (proj, fc2) or on the combine scores (MoE), and on the gradient entering the
+        branch in backward."""
         P_, p = self.P, self.params
         B, T, D = self.B, self.T, self.D
+        N = self.N
         self._tsf = None
         if self.task_cond and tsf_bias is None and task_id is not None:
             tsf_bias = self._task_feature(task_id)
@@ -321,12 +337,17 @@ class BackboneEngine:
             ops.layernorm_fwd(x, p[b + "norm1.weight"], p[b + "norm1.bias"], a["h1"], a["mean1"], a["rstd1"])
             ops.gemm_nt(a["h1"], self.wc[b + "attn.qkv"], a["qkv"], bias=p[b + "attn.qkv.bias"])
             ops.attention_fwd(a["qkv"], B, self.N, self.heads, self.dh, a["o"], a["lse"])
-            ops.gemm_nt(a["o"], self.wc[b + "attn.proj"], a["x1"], bias=p[b + "attn.proj.bias"], residual=x)
+            ps = None if path_scales is None else path_scales.get(i)
+            a["ps"] = ps
+            sa, sm = (None, None) if ps is None else ps
+            ops.gemm_nt(a["o"], self.wc[b + "attn.proj"], a["x1"], bias=p[b + "attn.proj.bias"], residual=x,
+                        row_scale=sa, row_scale_div=N)
             ops.layernorm_fwd(a["x1"], p[b + "norm2.weight"], p[b + "norm2.bias"], a["h2"], a["mean2"], a["rstd2"])
             if not self.is_moe[i]:
                 ops.gemm_nt(a["h2"], self.wc[b + "mlp.fc1"], a["u"], bias=p[b + "mlp.fc1.bias"], act=M3_ACT_GELU,
                             pre_out=a["pre"])
-                ops.gemm_nt(a["u"], self.wc[b + "mlp.fc2"], a["x2"], bias=p[b + "mlp.fc2.bias"], residual=a["x1"])
+                ops.gemm_nt(a["u"], self.wc[b + "mlp.fc2"], a["x2"], bias=p[b + "mlp.fc2.bias"], residual=a["x1"],
+                            row_scale=sm, row_scale_div=N)
             else:
                 wname = self._gate_weight(i, task_id)
                 a["wname"] = wname
@@ -350,7 +371,10 @@ class BackboneEngine:
                     ops.gemm_nt(a["hid"], self.wc[b + "mlp.experts.h4toh"], a["y"], M=self.R,
                                 bias=p[b + "mlp.experts.h4toh.bias"], c_row_idx=r.row_of_slot,
                                 group_offsets=r.offsets, tile_starts=r.tile_starts)
-                ops.combine_fwd(a["y"], g["score"], a["x1"], a["x2"])
+                if sm is not None:                          # out = x1 + scale[sample] * sum_j score_j y_j
+                    a["sm_tok"] = sm.view(B, 1).expand(B, N).reshape(T, 1).contiguous()
+                    a["score_s"] = g["score"] * a["sm_tok"]
+                ops.combine_fwd(a["y"], a["score_s"] if sm is not None else g["score"], a["x1"], a["x2"])
             x = a["x2"]
         # total cv_loss = sum over MoE blocks of cv^2(importance) + cv^2(load)  (vision_transformer_moe.py:453-459,540)
         return x.view(B, self.N, D), self.cv_acc[0].clone()
@@ -369,7 +393,6 @@ class BackboneEngine:
         buffer is already grouped by destination rank; received rows are regrouped from (src, expert) to
         (expert, src) order for the local grouped GEMMs."""
         import torch.distributed as dist
-        from .ep import ExchangePlan
         b = f"blocks.{i}."
         p, k, D, dev = self.params, self.k, self.D, self.dev
         r = ops.route_build(g["idx32"], self.E, want_counts64=True)
@@ -378,15 +401,12 @@ class BackboneEngine:
         ops.gather_rows(a["h2"], r.row_of_slot, x_send, div=k)
         recv = torch.empty_like(r.counts64)
         dist.all_to_all_single(recv, r.counts64, group=self.ep_group)
-        plan = ExchangePlan(r.counts64.tolist(), recv.tolist(), self.ep_world, self.E_loc)   # host sync (sizes)
+        # the plan (regroup index, expert-major offsets, tile prefix) is built on the device; the host reads the
+        # 2 W split sizes the a2a-v API needs and nothing else
+        plan = ops.ep_plan(r.counts64, recv, self.ep_world, self.E_loc, self.ep_regroup[i], splits_host=self.ep_splits_host)
         n = plan.n_recv
         x_recv = self._a2a(x_send, plan.in_splits, plan.out_splits)
-        ep = dict(plan=plan, n=n)
-        ep["rg"] = torch.tensor(plan.regroup, dtype=torch.int32, device=dev)
-        cnt = torch.tensor(plan.fwd_expert_count, dtype=torch.int32, device=dev)
-        z = torch.zeros(1, dtype=torch.int32, device=dev)
-        ep["offsets"] = torch.cat((z, torch.cumsum(cnt, 0).to(torch.int32))).contiguous()
-        ep["tile_starts"] = torch.cat((z, torch.cumsum((cnt + 127) // 128, 0).to(torch.int32))).contiguous()
+        ep = dict(plan=plan, n=n, rg=plan.regroup, offsets=plan.offsets, tile_starts=plan.tile_starts)
         y_recv = self._e(n, D)
         ep["x_recv"] = x_recv
         if n > 0:
@@ -491,7 +511,7 @@ class BackboneEngine:
         self._ev_i = 0
         dx = self.s_dxa
         dx.copy_(d_tokens.reshape(self.T, self.D))
-        self._bw = dict(dx=dx, other=self.s_dxb, have_dx_t=False, cv_weight=cv_weight)
+        self._bw = dict(dx=dx, other=self.s_dxb, have_dx_t=False, cv_weight=cv_weight, d_tsf=None)
 
     def backward_blocks(self, hi: int, lo: int):
         """blocks hi, hi-1, ..., lo (inclusive); after it the gradients of every parameter of those blocks
@@ -503,8 +523,12 @@ class BackboneEngine:
         for i in range(hi, lo - 1, -1):
             a = self.act[i]
             b = f"blocks.{i}."
+            sa, sm = (None, None) if a.get("ps") is None else a["ps"]
             if not self.is_moe[i]:
-                if not have_dx_t:
+                if sm is not None:                          # DropPath: the gradient entering the branch is scale * d x
+                    self._before_write("dx_t")
+                    ops.scale_rows_cast(dx, sm, self.N, self.s_dx_t)
+                elif not have_dx_t:
                     self._before_write("dx_t")
                     ops.cast_f32(dx, self.s_dx_t)
                 dpre = self.s_dpre[: T * self.Hd].view(T, self.Hd)
@@ -517,7 +541,9 @@ class BackboneEngine:
             else:
                 g, r = a["gate"], a["route"]
                 self._before_write("dy")
-                ops.combine_bwd(dx, a["y"], g["score"], self.s_dy, self.s_dscore)
+                ops.combine_bwd(dx, a["y"], a["score_s"] if sm is not None else g["score"], self.s_dy, self.s_dscore)
+                if sm is not None:
+                    self.s_dscore.mul_(a["sm_tok"])         # d score = scale * d(scale * score)
                 if self.ep_world > 1:
                     self._experts_bwd_ep(i, a)
                 else:
@@ -540,7 +566,7 @@ class BackboneEngine:
                                          balance_scale=cv_weight, idx_next=g["idx_next"],
                                          d_load_prob=g["d_load_prob"] if bal else None, clean=g["clean"],
                                          top_logits=g["top_logits"], noise_std=g["noise_std"], out=self.s_dl)
-                # token rows of w_gate ([:D]; the task-conditioned rows [D:] are handled by _task_feature_bwd)
+                # token rows of w_gate ([:D]; the task-conditioned rows [D:]: _task_feature_block_bwd below)
                 wg, dwg = p[a["wname"]][:D], gr[a["wname"]][:D]
                 if self.gate_via_gemm:
                     # d w_gate += h2^T dl (TN GEMM) ; dh2 += dl w_gate^T (NT GEMM, K = E)
@@ -554,13 +580,15 @@ class BackboneEngine:
                     ops.gate_bwd_params(a["h2"], wg, dl, d_w_gate=dwg, beta_dw=1, dx=self.s_dh32,
                                         beta_dx=1, part_dw=self.ws_gate_dw)
                 if self._tsf is not None:
-                    a["d_logit_bias"] = ops.colsum(dl, torch.empty(self.E, device=self.dev), ws=self.ws_colsum)
+                    self._task_feature_block_bwd(a, dl, st)
                 dh2 = self.s_dh32
             self._before_write("dx_t")
             ops.layernorm_bwd(dh2, a["x1"], a["mean2"], a["rstd2"], p[b + "norm2.weight"], dx, other,
                               gr[b + "norm2.weight"], gr[b + "norm2.bias"], beta=1, ws=self.ws_ln,
-                              dx_act=self.s_dx_t)                        # also emits the activation-dtype copy
+                              dx_act=self.s_dx_t if sa is None else None)     # also emits the activation-dtype copy
             dx, other = other, dx                                        # dx = d x1
+            if sa is not None:
+                ops.scale_rows_cast(dx, sa, self.N, self.s_dx_t)         # DropPath of the attention branch
             self._wgrad(self.s_dx_t, a["o"], b + "attn.proj.weight", bias=b + "attn.proj.bias", reads=("dx_t",))
             ops.gemm_nt(self.s_dx_t, self.wt[b + "attn.proj"], self.s_do)
             self._before_write("dqkv")
@@ -568,7 +596,7 @@ class BackboneEngine:
                               dq_ws=self.ws_dq)
             self._wgrad(self.s_dqkv, a["h1"], b + "attn.qkv.weight", bias=b + "attn.qkv.bias", reads=("dqkv",))
             ops.gemm_nt(self.s_dqkv, self.wt[b + "attn.qkv"], self.s_dh)
-            nxt_dense = i > 0 and not self.is_moe[i - 1]                 # the block below consumes dx_t directly
+            nxt_dense = i > 0 and not self.is_moe[i - 1] and self.act[i - 1].get("ps") is None   # the block below consumes dx_t directly
             if nxt_dense:
                 self._before_write("dx_t")
             ops.layernorm_bwd(self.s_dh, a["x_in"], a["mean1"], a["rstd1"], p[b + "norm1.weight"], dx, other,
@@ -593,5 +621,5 @@ class BackboneEngine:
                                             db=gr["patch_embed.proj.bias"]))
         self._join_wgrad()
         if self._tsf is not None:
-            self._task_feature_bwd()
+            self._task_feature_bwd(self._bw.get("d_tsf"))
         return dx

@@ -9,8 +9,10 @@ the gate scores all E_tot = E_loc * W experts, and per MoE layer there is ONE ex
  -> inverse regroup, all-to-all-v back                   (fastmoe global_gather), MOEGather to token-major
 
 which is what _fmoe_general_global_forward does for world_size > 1 behind
-models/moe/ckpt/custom_moe_layer.py:263-265.  The counts are read on the host once per layer to size
-the variable all-to-all (torch.distributed's API takes python split lists; fastmoe syncs here as well).
+models/moe/ckpt/custom_moe_layer.py:263-265.  The exchange plan (regroup index, expert-major offsets, tile prefix) is
+built ON THE DEVICE from the two count vectors (m3_ep_plan; torch ops on CPU tensors for the gloo rehearsals); the
+host reads only the 2 * W split sizes per layer (torch.distributed's a2a-v takes python lists; fastmoe syncs here
+too) - no per-row host work.
 xGMI is a full point-to-point mesh, so the single large a2a-v per direction (one distinct peer per link)
 is the right collective; nothing is chunked into ring steps.
 
@@ -25,9 +27,55 @@ import torch
 import torch.distributed as dist
 
 
-# ------------------------------------------------------------------ pure host-side plan
+# ------------------------------------------------------------------ device-side plan
+class DevicePlan:
+    """in_splits / out_splits (python lists: the one host read), n_recv, and device tensors regroup (i32 [n_recv]:
+    expert-major slot -> received row), regroup_inv, fwd_expert_count (i64 [E_loc]), offsets / tile_starts (i32)."""
+    __slots__ = ("in_splits", "out_splits", "n_recv", "regroup", "regroup_inv", "fwd_expert_count", "offsets", "tile_starts")
+
+
+def device_plan(send_counts: torch.Tensor, recv_counts: torch.Tensor, world: int, e_loc: int, regroup_buf=None,
+                want_inverse: bool = True) -> DevicePlan:
+    """The exchange plan without per-row host work.  CUDA tensors: one m3_ep_plan launch; CPU tensors (gloo
+    rehearsals of the logic): the same arithmetic in vectorised torch ops."""
+    p = DevicePlan()
+    dev = send_counts.device
+    recv = recv_counts.view(world, e_loc)
+    p.fwd_expert_count = recv.sum(0)
+    if send_counts.is_cuda:
+        from . import ops
+        assert regroup_buf is not None, "device_plan on the GPU needs a regroup buffer of world * (rows routed per rank) int32"
+        dp = ops.ep_plan(send_counts, recv_counts, world, e_loc, regroup_buf)
+        p.in_splits, p.out_splits, p.n_recv = dp.in_splits, dp.out_splits, dp.n_recv
+        p.regroup, p.offsets, p.tile_starts = dp.regroup, dp.offsets, dp.tile_starts
+    else:
+        sp = torch.cat((send_counts.view(world, e_loc).sum(1), recv.sum(1))).tolist()        # the 2 W split sizes
+        p.in_splits, p.out_splits = sp[:world], sp[world:]
+        n = p.n_recv = sum(p.out_splits)
+        sizes_src = recv.reshape(-1)                                          # blocks in arrival order (s, e)
+        src_start = torch.cumsum(sizes_src, 0) - sizes_src
+        perm = torch.arange(world * e_loc).view(world, e_loc).t().reshape(-1)   # block ids in (e, s) order
+        sizes_em = sizes_src[perm]
+        em_start = torch.cumsum(sizes_em, 0) - sizes_em
+        blk = torch.repeat_interleave(torch.arange(world * e_loc), sizes_em, output_size=n)
+        p.regroup = (src_start[perm][blk] + (torch.arange(n) - em_start[blk])).to(torch.int32)
+        z = torch.zeros(1, dtype=torch.int64)
+        p.offsets = torch.cat((z, torch.cumsum(p.fwd_expert_count, 0))).to(torch.int32)
+        p.tile_starts = torch.cat((z, torch.cumsum((p.fwd_expert_count + 127) // 128, 0))).to(torch.int32)
+    if want_inverse:
+        inv = torch.empty_like(p.regroup)
+        inv[p.regroup.long()] = torch.arange(p.n_recv, dtype=torch.int32, device=dev)
+        p.regroup_inv = inv
+    else:
+        p.regroup_inv = None
+    return p
+
+
+# ------------------------------------------------------------------ pure host-side plan (the checker of device_plan)
 class ExchangePlan:
-    """Everything the exchange needs, derived from the two count vectors (host ints).
+    """Everything the exchange needs, derived from the two count vectors (host ints) with plain Python loops: the
+    readable statement of the plan, kept as the reference the device plan is tested against (tests/test_ep_gloo.py,
+    tests/test_hip_kernels.py); the product path uses device_plan.
 
     send_counts[d*E_loc + e]: rows this rank routes to local expert e of rank d.
     recv_counts[s*E_loc + e]: rows rank s routes to this rank's local expert e.
@@ -112,14 +160,14 @@ def general_global_forward_ep(inp, gate_idx, expert_fn, num_expert, world_size, 
     row_of_slot, pos, counts64 = route_fn(gate_idx, e_tot)
     send_counts = counts64.to(torch.int64)
     recv_counts = exchange_counts(send_counts, group)
-    plan = ExchangePlan(send_counts.tolist(), recv_counts.tolist(), world_size, num_expert)   # host sync (sizes)
-    dev = inp.device
+    # a rank can receive at most what all ranks route (every rank routes gate_idx.numel() rows)
+    buf = torch.empty(world_size * gate_idx.numel(), dtype=torch.int32, device=inp.device) if inp.is_cuda else None
+    plan = device_plan(send_counts, recv_counts, world_size, num_expert, regroup_buf=buf)   # host reads the 2 W split sizes only
     x_send = gather_fn(inp, row_of_slot, k, pos, k)                         # MOEScatter (local part)
     x_recv = _A2ARows.apply(x_send, plan.in_splits, plan.out_splits, group)  # global_scatter
-    rg = torch.tensor(plan.regroup, dtype=torch.int32, device=dev)
-    rgi = torch.tensor(plan.regroup_inv, dtype=torch.int32, device=dev)
+    rg, rgi = plan.regroup, plan.regroup_inv
     x_exp = gather_fn(x_recv, rg, 1, rgi, 1) if plan.n_recv else x_recv
-    cnt = torch.tensor(plan.fwd_expert_count, dtype=torch.int64, device=dev)
+    cnt = plan.fwd_expert_count
     if make_count is not None:
         cnt = make_count(cnt)
     y_exp = expert_fn(x_exp, cnt)

@@ -5,7 +5,11 @@ Same constructor arguments, parameter name (`w_gate [d_model, tot_expert]`, kaim
 ((idx, score), clean_logits, noisy_logits, noise_stddev, top_logits, gates) of :257-264.
 noise_stddev is a Python float (:92-93).  Noise is drawn with torch.randn (same distribution as
 randn_like at :168) and handed to the kernel; pass `noise=` to forward to pin it.
-The regu_sem / regu_subimage regularisers (:95-162) are OUT OF SCOPE and raise."""
+The regu_sem / regu_subimage regularisers (:95-162) are OUT OF SCOPE and raise.
+
+convention="origin": the API of models/moe/origin/noisy_gate_vmoe.py:168-297 - forward returns (idx, score) only,
+stores the block's balance loss cv^2(importance) + cv^2(load) (0 in eval) with set_loss() for
+utils/moe_utils.py::collect_noisy_gating_loss, and keeps the softmax probabilities as `activation`."""
 import math
 
 import torch
@@ -18,8 +22,10 @@ from .functional import GateFn
 class NoisyGate_VMoE(BaseGate):
     def __init__(self, d_model, num_expert, world_size, top_k=2, noise_std=1, no_noise=False,
                  return_decoupled_activation=False, regu_experts_fromtask=False, num_experts_pertask=-1, num_tasks=-1,
-                 regu_sem=False, sem_force=False, regu_subimage=False, group_size=4):
+                 regu_sem=False, sem_force=False, regu_subimage=False, group_size=4, convention="ckpt"):
         super().__init__(num_expert, world_size)
+        assert convention in ("ckpt", "origin")
+        self.convention = convention
         if regu_sem or regu_subimage or return_decoupled_activation:
             raise NotImplementedError("regu_sem / regu_subimage / decoupled activation are outside the hot path")
         self.w_gate = nn.Parameter(torch.zeros(d_model, self.tot_expert), requires_grad=True)
@@ -73,6 +79,15 @@ class NoisyGate_VMoE(BaseGate):
             x, w, min(self.top_k, E), noise if abs(noise_stddev) > 0 else None, float(noise_stddev), bias)
         self._last = dict(idx32=idx32, importance=imp, load=load)
         k = idx.shape[1]
+        if self.convention == "origin":                                   # origin/noisy_gate_vmoe.py:277-297
+            if self.training:
+                from .balance import block_balance_loss
+                loss = block_balance_loss(gates, clean, noisy, noise_stddev, top_logits, k)
+            else:
+                loss = 0
+            self.set_loss(loss)
+            self.activation = torch.softmax(noisy.detach(), dim=1).reshape(other + [-1]).contiguous()
+            return idx.reshape(other + [k]).contiguous(), score.reshape(other + [k]).contiguous()
         return ((idx.reshape(other + [k]), score.reshape(other + [k])), clean, noisy, noise_stddev, top_logits, gates)
 
     def get_activation(self, clear=True):

@@ -46,8 +46,10 @@ class FMoETransformerMLP(FMoE):
                  expert_dp_comm="none", expert_rank=0, gate=NaiveGate, world_size=1, top_k=2, vmoe_noisy_std=1,
                  gate_return_decoupled_activation=False, gate_task_specific_dim=-1, multi_gate=False,
                  regu_experts_fromtask=False, num_experts_pertask=-1, num_tasks=-1, regu_sem=False, sem_force=False,
-                 regu_subimage=False, expert_prune=False, prune_threshold=0.1, **kwargs):
+                 regu_subimage=False, expert_prune=False, prune_threshold=0.1, convention="ckpt", **kwargs):
         super().__init__(num_expert=num_expert, d_model=d_model, gate=gate, world_size=world_size, top_k=top_k, **kwargs)
+        assert convention in ("ckpt", "origin")
+        self.convention = convention       # "origin": forward returns the tensor only (origin/custom_moe_layer.py:161-181)
         if regu_sem or regu_subimage:
             raise NotImplementedError("regu_sem / regu_subimage are outside the hot path (SURVEY 8a a4)")
         self.sem_force = sem_force
@@ -79,7 +81,7 @@ class FMoETransformerMLP(FMoE):
         mk = lambda: gate(d_gate_in, num_expert, world_size, top_k,                      # noqa: E731
                           return_decoupled_activation=gate_return_decoupled_activation, noise_std=vmoe_noisy_std,
                           regu_experts_fromtask=regu_experts_fromtask, num_experts_pertask=num_experts_pertask,
-                          num_tasks=num_tasks, regu_sem=False, sem_force=False, regu_subimage=False)
+                          num_tasks=num_tasks, regu_sem=False, sem_force=False, regu_subimage=False, convention=convention)
         if self.multi_gate:
             self.gate = nn.ModuleList([mk() for _ in range(self.our_d_gate - self.our_d_model)])
         else:
@@ -102,6 +104,8 @@ class FMoETransformerMLP(FMoE):
             assert self.multi_gate is False
             tsf = task_specific_feature
         out, clean, noisy, std, top_logits, gates = self.forward_moe(gate_inp, inp, task_id=task_id, sem=sem, tsf=tsf)
+        if self.convention == "origin":
+            return out.reshape(original_shape)
         return out.reshape(original_shape), clean, noisy, std, top_logits, gates
 
     def _force_by_semantics(self, idx, score, sem):
@@ -120,15 +124,22 @@ class FMoETransformerMLP(FMoE):
         return idx3.reshape(-1, k), torch.full_like(score, 0.5)
 
     def forward_moe(self, gate_inp, moe_inp, task_id=None, sem=None, tsf=None):
+        clean = noisy = std = top_logits = gates = None
         if (task_id is not None) and self.multi_gate:
             g = self.gate[task_id]
-            (idx, score), clean, noisy, std, top_logits, gates = g(gate_inp, sem=sem)
-            unused = sum(p.sum() for i, gg in enumerate(self.gate) if i != task_id for p in gg.parameters())
-            clean = clean + 0.0 * unused                     # DDP keep-alive, :216-217
+            if self.convention == "origin":                 # origin/custom_moe_layer.py:213-215: a 2-tuple, no keep-alive
+                idx, score = g(gate_inp)
+            else:
+                (idx, score), clean, noisy, std, top_logits, gates = g(gate_inp, sem=sem)
+                unused = sum(p.sum() for i, gg in enumerate(self.gate) if i != task_id for p in gg.parameters())
+                clean = clean + 0.0 * unused                 # DDP keep-alive, :216-217
         else:
             g = self.gate
-            (idx, score), clean, noisy, std, top_logits, gates = g(gate_inp, task_id=task_id, sem=sem,
-                                                                   task_specific_feature=tsf)
+            if self.convention == "origin":
+                idx, score = g(gate_inp, task_id=task_id, sem=sem, task_specific_feature=tsf)
+            else:
+                (idx, score), clean, noisy, std, top_logits, gates = g(gate_inp, task_id=task_id, sem=sem,
+                                                                       task_specific_feature=tsf)
         if self.expert_prune:
             score = torch.where(score > self.prune_threshold, score, torch.zeros_like(score))
         idx32 = g._last["idx32"]

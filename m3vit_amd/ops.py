@@ -117,8 +117,16 @@ def gate_bwd_params(x, w_gate, d_logits, d_w_gate=None, beta_dw=0, dx=None, beta
 
 # ---------------------------------------------------------------------------- route
 class Route:
-    """Device-resident dispatch metadata (no host sync)."""
+    """Device-resident dispatch metadata (no host sync).  Expert ids outside [0, E) are a caller error: such entries
+    get no slot (their token-major output rows are never written) while pos / row_of_slot stay in range; check()
+    - a host sync, for tests and debugging - raises when any entry was dropped."""
     __slots__ = ("counts", "offsets", "pos", "row_of_slot", "tile_starts", "counts64", "n", "E", "k")
+
+    def check(self):
+        routed = int(self.offsets[-1])
+        if routed != self.n:
+            raise _lib.M3Error(f"route_build: {self.n - routed} of {self.n} expert ids lie outside [0, {self.E})")
+        return self
 
 
 def route_build(idx32: torch.Tensor, E: int, want_counts64=False) -> Route:
@@ -145,9 +153,40 @@ def route_build(idx32: torch.Tensor, E: int, want_counts64=False) -> Route:
     return r
 
 
+class EpPlan:
+    """Device-resident expert-parallel exchange plan (m3_ep_plan) + the two split lists the a2a-v API needs."""
+    __slots__ = ("splits", "regroup", "offsets", "tile_starts", "in_splits", "out_splits", "n_recv")
+
+
+def ep_plan(send_counts64, recv_counts64, world: int, e_loc: int, regroup_buf: torch.Tensor, splits_host=None) -> EpPlan:
+    """Plan of one expert-parallel exchange from the two count vectors, computed on the device; the host reads only the
+    2 * world split sizes (one small copy into pinned memory; torch.distributed's a2a-v takes python lists)."""
+    _req(send_counts64, torch.int64, "send_counts"); _req(recv_counts64, torch.int64, "recv_counts")
+    _req(regroup_buf, torch.int32, "regroup_buf")
+    dev = send_counts64.device
+    p = EpPlan()
+    p.splits = torch.empty(2 * world, dtype=torch.int64, device=dev)
+    p.offsets = torch.empty(e_loc + 1, dtype=torch.int32, device=dev)
+    p.tile_starts = torch.empty(e_loc + 1, dtype=torch.int32, device=dev)
+    check(lib().m3_ep_plan(_p(send_counts64), _p(recv_counts64), world, e_loc, _p(p.splits), _p(regroup_buf),
+                           regroup_buf.numel(), _p(p.offsets), _p(p.tile_starts), _stream()), "m3_ep_plan")
+    if splits_host is None:
+        splits_host = torch.empty(2 * world, dtype=torch.int64, pin_memory=True)
+    splits_host.copy_(p.splits, non_blocking=True)
+    torch.cuda.current_stream().synchronize()          # the one host read of the exchange: 2 * world integers
+    sp = splits_host.tolist()
+    p.in_splits, p.out_splits = sp[:world], sp[world:]
+    p.n_recv = sum(p.out_splits)
+    if p.n_recv > regroup_buf.numel():
+        raise _lib.M3Error(f"ep_plan: {p.n_recv} received rows exceed the regroup buffer ({regroup_buf.numel()})")
+    p.regroup = regroup_buf[: p.n_recv]
+    return p
+
+
 # ----------------------------------------------------------------------------- GEMM
 def gemm_nt(A, B, C, *, M=None, bias=None, act=M3_ACT_NONE, pre_out=None, gelu_grad_pre=None, residual=None,
-            a_row_idx=None, a_row_div=1, c_row_idx=None, group_offsets=None, tile_starts=None):
+            a_row_idx=None, a_row_div=1, c_row_idx=None, group_offsets=None, tile_starts=None, row_scale=None,
+            row_scale_div=1):
     """C[m,n] = epi(sum_k A[arow(m),k] B[g][n,k]).  A [rows,K]; B [N,K] or [G,N,K]; C [rows,N] (f32 or A.dtype)."""
     _req(A, name="A"); _req(B, A.dtype, "B"); _req(C, name="C")
     G = 1 if B.dim() == 2 else B.shape[0]
@@ -167,6 +206,10 @@ def gemm_nt(A, B, C, *, M=None, bias=None, act=M3_ACT_NONE, pre_out=None, gelu_g
     a.residual = residual.data_ptr() if residual is not None else None
     a.ld_res = residual.stride(0) if residual is not None else 0
     a.act = act
+    if row_scale is not None:
+        _req(row_scale, torch.float32, "row_scale")
+    a.row_scale = row_scale.data_ptr() if row_scale is not None else None
+    a.row_scale_div = row_scale_div
     if M is None:
         M = a_row_idx.numel() if a_row_idx is not None else A.shape[0]
     a.M = M; a.N = N; a.K = K; a.G = G
@@ -437,6 +480,16 @@ def add_f32(dst, src):
 
 def cast_f32(src, dst):
     check(lib().m3_cast_f32(_p(src), src.numel(), _p(dst), dt_code(dst.dtype), _stream()), "m3_cast_f32")
+    return dst
+
+
+def scale_rows_cast(src, row_scale, div, dst):
+    """dst[r, :] = row_scale[r // div] * src[r, :] (src fp32 [rows, cols], dst fp32 / f16)"""
+    _req(src, torch.float32, "src"); _req(row_scale, torch.float32, "row_scale"); _req(dst, name="dst")
+    rows, cols = src.shape
+    assert row_scale.numel() * div >= rows
+    check(lib().m3_scale_rows_cast(_p(src), rows, cols, _p(row_scale), div, _p(dst), dt_code(dst.dtype), _stream()),
+          "m3_scale_rows_cast")
     return dst
 
 

@@ -50,8 +50,20 @@ class MultiTaskStep:
         ends = [self.eng.grad_prefix(lo) for lo in cuts] + [self.flat.numel()]
         self.segments = list(zip([0] + ends[:-1], ends))
         self.two_parts = nparts > 1
-        self.want_graph = bool(graph) and not self.use_ep and not wg     # ROCm 7.2 crashes capturing the wgrad-stream pattern
+        # hipGraph capture: expert-parallel steps read split sizes on the host (eager).  Weight-gradient streams capture
+        # fine when forked from the capturing stream itself (tools/wgrad_capture_probe.py: capture + replay bit-exact),
+        # but forked from a stream that is ITSELF a fork of the capturing stream (task streams x wgrad streams: a nested
+        # fork) hipStreamEndCapture of ROCm 7.2 segfaults (profiles/r02_wgrad_capture_segv.txt) - that combination is
+        # refused here and runs eagerly.
+        self.capture_refused = None
+        if self.use_ep:
+            self.capture_refused = "expert-parallel steps read the exchange's split sizes on the host"
+        elif wg and self.par:
+            self.capture_refused = ("wgrad streams forked from forked task streams: hipStreamEndCapture (ROCm 7.2) "
+                                    "segfaults on the nested fork; use serial tasks or no wgrad streams to replay a graph")
+        self.want_graph = bool(graph) and self.capture_refused is None
         self.graphs = None
+        self.capture_error = None
         self.images = self.dtok = self.noises = self.logit_bias = None
 
     # ------------------------------------------------------------------ pieces
@@ -151,6 +163,7 @@ class MultiTaskStep:
     def capture(self) -> bool:
         """Capture the compute of a step into hipGraph(s).  Returns False (and stays eager) if capture is unavailable."""
         if not self.want_graph:
+            self.capture_error = self.capture_refused
             return False
         try:
             side = torch.cuda.Stream(device=self.dev)
@@ -169,7 +182,11 @@ class MultiTaskStep:
                 graphs.append(gj)
             self.graphs = graphs
             return True
-        except Exception:          # capture is an optimisation, never a requirement
+        except Exception as exc:   # capture is an optimisation, never a requirement - but say why it was lost
+            import sys
+            print(f"[m3vit_amd.step] hipGraph capture failed, running eagerly: {type(exc).__name__}: {exc}", file=sys.stderr,
+                  flush=True)
+            self.capture_error = f"{type(exc).__name__}: {exc}"
             self.graphs = None
             torch.cuda.synchronize()
             return False

@@ -17,6 +17,9 @@ Fixtures written to tests/golden/*.npz (small, a few hundred KB total):
   g5_moe_layer               whole layer out + dX/dW1/db1/dW2/db2/dw_gate
   g6_balance_noisy           x, w_gate, noise, std -> the gate's own balance loss in training mode
                              (cv^2(importance) + cv^2(_prob_in_top_k load)) and d loss / d(x, w_gate)
+  g7_checkpoint_formats      pretrain/utils/moe_checkpoint.py (f.4): to_mtl_backbone_state_dict, get_first_expert_dim0,
+                             infer_expert_format, build_mtl_meta over a table of cases, merge_moe_sharded_directory on a
+                             4-rank shard directory written the way train_fastmoe's ranks write it
 Inputs are resampled until the top-(k+2) probabilities of every token are
 separated by > 1e-4 relative, so torch.topk's unspecified tie order cannot matter.
 """
@@ -181,6 +184,69 @@ def g5(T=80, D=64, H=96, E=8, k=2):
     raise RuntimeError("no tie-free seed")
 
 
+def g7():
+    """EP checkpoint formats: run the reference's pretrain/utils/moe_checkpoint.py on small synthetic state dicts; the
+    case table (inputs) travels with the outputs so that the test replays exactly these calls."""
+    import json
+    import tempfile
+    from collections import OrderedDict
+    from pretrain.utils import moe_checkpoint as M
+    rng = np.random.RandomState(77)
+    E, W = 8, 4
+
+    def t(*shape):
+        return torch.from_numpy(rng.randn(*shape).astype(np.float32))
+    wrapped = OrderedDict([
+        ("module.encoder.pos_embed", t(1, 5, 4)),
+        ("module.encoder.blocks.0.attn.qkv.weight", t(12, 4)),
+        ("module.encoder.blocks.1.mlp.gate.w_gate", t(4, E)),
+        ("module.encoder.blocks.1.mlp.experts.htoh4.weight", t(E, 6, 4)),
+        ("module.encoder.blocks.1.mlp.experts.htoh4.bias", t(E, 6)),
+        ("module.encoder.blocks.1.mlp.experts.h4toh.weight", t(E, 4, 6)),
+        ("module.encoder.blocks.1.mlp.experts.h4toh.bias", t(E, 4)),
+        ("module.norm.weight", t(4)),
+        ("module.head.weight", t(5, 4)),
+        ("module.head.bias", t(5)),
+        ("blocks.0.norm1.weight", t(4)),                      # an already-backbone key passes through
+    ])
+    out, dropped = M.to_mtl_backbone_state_dict(wrapped)
+    glob = out                                                # backbone key space, E experts along dim 0
+    loc = OrderedDict((k, (v[2:4] if M.is_expert_key(k) else v)) for k, v in glob.items())
+    dense = OrderedDict((k, v) for k, v in glob.items() if not M.is_expert_key(k))
+    states = {"global": glob, "local": loc, "dense": dense}
+    infer_cases = []
+    for ck in ({}, {"meta": {"expert_format": "local"}}, {"meta": {"expert_format": "global"}}, {"meta": {"expert_format": "other"}},
+               {"args": {"moe_experts": 8, "world_size": 4}}, {"args": {"moe_experts": 8}}, {"args": {"moe_experts": 16, "world_size": 2}},
+               {"meta": "not a dict", "args": {"moe_experts": 2, "world_size": 4}}):
+        for sname in ("global", "local", "dense"):
+            for egx, ews in ((None, None), (8, None), (8, 4), (2, None), (16, 2), (None, 4), (8, 1)):
+                got = M.infer_expert_format(ck, states[sname], expected_global_experts=egx, expected_world_size=ews)
+                infer_cases.append(dict(checkpoint=ck, state=sname, expected_global_experts=egx, expected_world_size=ews, out=got))
+    meta_cases = []
+    for sname in ("global", "local", "dense"):
+        for kw in (dict(world_size=1), dict(world_size=4), dict(world_size=3), dict(world_size=4, moe_experts_global=16),
+                   dict(world_size=2, moe_experts_local=1), dict(world_size=4, moe_experts_global=32, moe_experts_local=8)):
+            meta_cases.append(dict(state=sname, kwargs=kw, out=M.build_mtl_meta(states[sname], "gen_golden", **kw)))
+    # a train_fastmoe-style shard directory (utils/moe_utils.py:164-175): rank 0 the whole state with ITS experts, the
+    # other ranks their expert tensors only
+    with tempfile.TemporaryDirectory() as d:
+        for r in range(W):
+            st = OrderedDict()
+            for k, v in glob.items():
+                if M.is_expert_key(k):
+                    st[k] = v[r * (E // W):(r + 1) * (E // W)].clone()
+                elif r == 0:
+                    st[k] = v
+            torch.save({"state_dict": st, "epoch": 7, "rank": r}, os.path.join(d, f"{r}.pth"))
+        base, merged, n = M.merge_moe_sharded_directory(d)
+    assert n == W and all(torch.equal(merged[k], glob[k]) for k in glob)
+    arrs = {"in/" + k: v for k, v in wrapped.items()}
+    arrs.update({"merged/" + k: v for k, v in merged.items()})
+    save("g7_checkpoint_formats", table=np.array(json.dumps(dict(
+        E=E, W=W, backbone_keys=list(out.keys()), dropped=dropped, first_dim0={k: M.get_first_expert_dim0(v) for k, v in states.items()},
+        infer=infer_cases, meta=meta_cases, merged_keys=list(merged.keys()), n_shards=n, base_epoch=base["epoch"]))), **arrs)
+
+
 if __name__ == "__main__":
     g1(16, "g1_gate_e16")
     g1(64, "g1_gate_e64")
@@ -190,3 +256,4 @@ if __name__ == "__main__":
     g3()
     g4()
     g5()
+    g7()

@@ -78,3 +78,53 @@ def test_pos_embed_resize():
     assert torch.allclose(C.resize_pos_embed(const, (7, 5)), torch.full((1, 36, 3), 2.5))
     with pytest.raises(ValueError):
         C.resize_pos_embed(torch.randn(1, 1 + 12, 4), (4, 4))
+
+
+def test_formats_match_the_reference_fixture(golden_dir, tmp_path):
+    """Pinned to the reference: tests/golden/g7_checkpoint_formats.npz holds the outputs of
+    pretrain/utils/moe_checkpoint.py (to_mtl_backbone_state_dict, get_first_expert_dim0, infer_expert_format over 168
+    argument combinations, build_mtl_meta, merge_moe_sharded_directory) made by tests/gen_golden.py::g7 in the build
+    container, together with the inputs; the same calls through m3vit_amd.checkpoint must give the same results."""
+    import json
+    from collections import OrderedDict
+
+    import numpy as np
+    z = np.load(os.path.join(golden_dir, "g7_checkpoint_formats.npz"))
+    tab = json.loads(str(z["table"]))
+    wrapped = OrderedDict((k[3:], torch.from_numpy(z[k])) for k in z.files if k.startswith("in/"))
+    out, dropped = C.to_mtl_backbone_state_dict(wrapped)
+    assert list(out.keys()) == tab["backbone_keys"] and dropped == tab["dropped"]
+    E, W = tab["E"], tab["W"]
+    glob = out
+    loc = OrderedDict((k, (v[2:4] if C.is_expert_key(k) else v)) for k, v in glob.items())
+    dense = OrderedDict((k, v) for k, v in glob.items() if not C.is_expert_key(k))
+    states = {"global": glob, "local": loc, "dense": dense}
+    assert {k: C.first_expert_dim0(v) for k, v in states.items()} == tab["first_dim0"]
+    assert len(tab["infer"]) == 168
+    for c in tab["infer"]:
+        got = C.infer_expert_format(c["checkpoint"], states[c["state"]], expected_global_experts=c["expected_global_experts"],
+                                    expected_world_size=c["expected_world_size"])
+        assert got == c["out"], c
+    for c in tab["meta"]:
+        assert C.build_mtl_meta(states[c["state"]], "gen_golden", **c["kwargs"]) == c["out"], c
+    # the shard directory the generator wrote (rank 0: everything with its experts; ranks > 0: expert tensors only)
+    d = str(tmp_path / "shards")
+    for r in range(W):
+        C.save_rank_shard({"state_dict": C.shard_experts(glob, r, E // W), "epoch": 7, "rank": r}, d, r)
+    base, merged, n = C.merge_rank_shards(d)
+    assert n == tab["n_shards"] and base["epoch"] == tab["base_epoch"] and list(merged.keys()) == tab["merged_keys"]
+    for k in merged:
+        assert torch.equal(merged[k], torch.from_numpy(z["merged/" + k])), k
+
+
+def test_a_local_shard_without_meta_is_not_sliced_again():
+    cfg, P = _state()
+    loc = C.shard_experts(P, 1, 2)                                   # 2 of 8 experts, no meta, no args
+    with pytest.raises(ValueError, match="global or rank-local"):
+        C.to_backbone_state({"state_dict": loc}, rank=1, world_size=2)
+    st, fmt = C.to_backbone_state({"state_dict": loc}, rank=1, world_size=4, expected_global_experts=8)
+    assert fmt == "local" and st["blocks.1.mlp.experts.htoh4.weight"].shape[0] == 2
+    st, fmt = C.to_backbone_state({"state_dict": P}, rank=1, world_size=4, expected_global_experts=8)
+    assert fmt == "global" and st["blocks.1.mlp.experts.htoh4.weight"].shape[0] == 2
+    with pytest.raises(ValueError, match="do not divide"):
+        C.to_backbone_state({"state_dict": P, "meta": {"expert_format": "global"}}, rank=0, world_size=3)

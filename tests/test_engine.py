@@ -11,6 +11,15 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+GRAD_FACTOR = 3     # parameter gradients: relative L2 per tensor <= GRAD_FACTOR * the token bound (see F16_TOL)
+# fp16 activations: every stored activation / activation gradient is rounded to 11 bits (2^-11 = 4.9e-4 relative);
+# the residual stream, the statistics and all accumulations stay fp32.  Tokens after a whole backbone come out at
+# 3-5e-4 relative L2 (the BENCHMARKED size: tests/test_full_size.py, bound 1e-3 = north_star); gradients see the
+# rounding of both the forward activations and the backward chain plus the bias / norm parameters' long column sums
+# of rounded terms: measured worst tensors 1.0-1.4e-3 at full size, bound 3e-3.
+F16_TOL = 1e-3
+
+
 def _check_backbone(cfg, dtype, tol, tasks, B=3, seed=5, follow_routing=False, noisy=False):
     """follow_routing (fp16 runs with many experts, where a 1e-3 perturbation of the gate input flips
     near-tied experts): the engine's indices must be EXACTLY the oracle gate's top-k on the engine's own
@@ -53,25 +62,29 @@ def _check_backbone(cfg, dtype, tol, tasks, B=3, seed=5, follow_routing=False, n
             # identical routing in every MoE block, then values
             for i in moe_blocks:
                 assert torch.equal(eng.act[i]["gate"]["idx"].cpu(), aux[i]["idx"]), f"routing differs in block {i}"
-        assert rel(tok, tok_ref) < tol
+        tok_err = rel(tok, tok_ref)
+        assert tok_err < tol
         assert abs(float(cv) - float(cv_ref.detach())) < 1e-3 * max(1.0, abs(float(cv_ref.detach())))
         eng.backward(dtok.cuda(), cv_weight=cvw)
         tot = tot + (tok_ref * dtok.double()).sum() + cvw * cv_ref
     tot.backward()
-    bad = []
+    bad, worst = [], ("", 0.0)
     for name, g in eng.grads.items():
         ref = Pr[name].grad
         if ref is None:
             assert float(g.abs().max()) == 0.0, name
             continue
         e = rel(g, ref)
-        if e > tol * 5:
+        if e > worst[1]:
+            worst = (name, e)
+        if e > tol * GRAD_FACTOR:
             bad.append((name, e))
+    print(f"[{dtype}] tokens rel {tok_err:.2e} (bound {tol:.0e}); worst gradient {worst[0]} {worst[1]:.2e} (bound {tol * GRAD_FACTOR:.0e})")
     assert not bad, bad
     return eng
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float16, 4e-3)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float16, F16_TOL)])
 def test_backbone_fwd_bwd_matches_oracle(dtype, tol):
     """BASELINE configs[1] structure (multi-gate, one w_gate per task) at a small size."""
     if not torch.cuda.is_available():
@@ -94,7 +107,7 @@ def test_backbone_noisy_training_matches_oracle():
     _check_backbone(cfg, torch.float32, 2e-4, tasks=(0, 1), noisy=True)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float16, 4e-3)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float16, F16_TOL)])
 def test_backbone_task_conditioned_matches_oracle(dtype, tol):
     """BASELINE configs[2] structure: ONE shared gate per block fed cat(token, tsf) with
     tsf = gate_task_represent(one_hot(task)) (5 PASCAL tasks, custom_moe_layer.py:161-181,
@@ -110,7 +123,7 @@ def test_backbone_task_conditioned_matches_oracle(dtype, tol):
     assert float(eng.grads["blocks.1.mlp.gate.w_gate"][64:].abs().max()) > 0.0
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float16, 4e-3)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float16, F16_TOL)])
 def test_config3_vit_base_64_experts(dtype, tol):
     """BASELINE configs[3] shapes on one GPU: ViT-Base width (D=768, 12 heads of 64), E=64, k=4,
     moe_mlp_ratio 1, 2 tasks; depth cut to 2 and 64x64 images so the float64 oracle finishes in seconds
@@ -132,7 +145,52 @@ def test_config4_vit_base_ratio4_nyud_resolution_f16():
     cfg = R.BackboneCfg(img_size=(480, 640), embed_dim=768, depth=2, num_heads=12, mlp_ratio=4.0, moe_mlp_ratio=4.0,
                         moe_experts=16, moe_top_k=4, gate_dim=770, multi_gate=True)
     assert cfg.num_tokens == 1201
-    _check_backbone(cfg, torch.float16, 4e-3, tasks=(1,), B=1, seed=9, follow_routing=True)
+    _check_backbone(cfg, torch.float16, F16_TOL, tasks=(1,), B=1, seed=9, follow_routing=True)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float16, F16_TOL)])
+def test_engine_drop_path_matches_oracle(dtype, tol):
+    """Stochastic depth in the fused executor (vision_transformer_moe.py:167-185,441,450; the AMP trainer's config has
+    drop_path 0.1, pretrain/configs/deit_moe_small.yaml:51): the caller draws the per-sample factors floor(keep + U) / keep
+    of both residual branches of every block; they ride on the proj / fc2 GEMM epilogues, on the combine scores of the
+    MoE branch and on the gradients entering the branches.  Forward and every gradient against the oracle with the
+    same factors; some samples drop a branch entirely (factor 0), some keep it (1 / keep)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from m3vit_amd.engine import BackboneEngine
+    from oracle import ref_torch as R
+    cfg = R.BackboneCfg(img_size=(32, 48), embed_dim=64, depth=4, num_heads=2, mlp_ratio=4.0, moe_mlp_ratio=1.0,
+                        moe_experts=4, moe_top_k=2, gate_dim=66, multi_gate=True)
+    B = 5
+    P = R.init_backbone_params(cfg, seed=5)
+    torch.manual_seed(1)
+    img = torch.randn(B, 3, *cfg.img_size)
+    dtok = torch.randn(B, cfg.num_tokens, 64) * 0.1
+    rates = [0.5 * i / (cfg.depth - 1) for i in range(cfg.depth)]           # linspace(0, rate, depth), :632
+    g = torch.Generator().manual_seed(2)
+    ps = {}
+    for i, r in enumerate(rates):
+        if r > 0:
+            keep = 1.0 - r
+            ps[i] = tuple(torch.floor(keep + torch.rand(B, generator=g)) / keep for _ in range(2))
+    assert any(float(v.min()) == 0.0 for pair in ps.values() for v in pair) and any(float(v.max()) > 1.0 for pair in ps.values() for v in pair)
+    eng = BackboneEngine(cfg, P, batch=B, dtype=dtype)
+    eng.zero_grad()
+    Pr = {k: v.clone().double().requires_grad_() for k, v in P.items()}
+    task = 1
+    tok, cv = eng.forward(img.cuda(), task, path_scales={i: tuple(v.cuda() for v in pair) for i, pair in ps.items()})
+    tok = tok.clone()                                  # (a view of the engine's last activation buffer)
+    ovr = {i: eng.act[i]["gate"]["idx"].cpu() for i in range(cfg.depth) if cfg.is_moe(i)} if dtype == torch.float16 else None
+    tok_ref, cv_ref, _ = R.backbone_forward(Pr, cfg, img.double(), task, path_scales=ps, route_override=ovr)
+    assert rel(tok, tok_ref) < tol
+    assert abs(float(cv) - float(cv_ref)) < 1e-3 * max(1.0, abs(float(cv_ref)))
+    eng.backward(dtok.cuda(), cv_weight=0.01)
+    ((tok_ref * dtok.double()).sum() + 0.01 * cv_ref).backward()
+    bad = [(n, rel(gr, Pr[n].grad)) for n, gr in eng.grads.items() if Pr[n].grad is not None and rel(gr, Pr[n].grad) > tol * GRAD_FACTOR]
+    assert not bad, bad
+    # without factors the engine is unchanged, and the factors do change the result
+    tok0, _ = eng.forward(img.cuda(), task)
+    assert rel(tok0, tok) > 1e-2
 
 
 def test_config0_dense_vit_tiny_plumbing():
@@ -319,17 +377,61 @@ def test_multitask_step_runner_graph_and_streams_match_serial():
     assert rel(run2.flat, want2) < 1e-5
 
 
-def test_multitask_step_data_parallel_parts():
+def test_wgrad_streams_are_captured_into_the_graph():
+    """BackboneEngine(wgrad_stream=True) forks the weight-gradient GEMMs onto a second stream by an event recorded on
+    the capturing stream and joins them back with wait_stream: that pattern captures into a hipGraph and replays
+    bit-exactly (also tools/wgrad_capture_probe.py).  Forked from a stream that is itself a fork of the capturing
+    stream (task streams x wgrad streams) hipStreamEndCapture of ROCm 7.2 segfaults (profiles/r02_wgrad_capture_segv.txt):
+    MultiTaskStep refuses to capture that combination, says why, and runs it eagerly."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from m3vit_amd.step import MultiTaskStep
+    from oracle import ref_torch as R
+    cfg = R.BackboneCfg(img_size=(64, 64), embed_dim=64, depth=4, num_heads=2, mlp_ratio=4.0, moe_mlp_ratio=1.0,
+                        moe_experts=8, moe_top_k=2, gate_dim=66, multi_gate=True)
+    P = R.init_backbone_params(cfg, seed=4)
+    torch.manual_seed(9)
+    img = torch.randn(4, 3, 64, 64).cuda()
+    dtok = (torch.randn(4, cfg.num_tokens, 64) * 0.1).cuda()
+    run = MultiTaskStep(cfg, P, batch=4, dtype=torch.float16, cv_weight=0.01, wgrad_streams=True, parallel_tasks=False)
+    assert run.eng.wg_stream is not None and len(run.engs) == 1 and run.want_graph
+    run.bind(img, dtok)
+    run.serial_step()
+    torch.cuda.synchronize()
+    want = run.flat.clone()
+    assert run.capture(), run.capture_error
+    for _ in range(3):
+        run.flat.fill_(7.0)
+        run.step()
+        torch.cuda.synchronize()
+        assert rel(run.flat, want) < 1e-5
+    nested = MultiTaskStep(cfg, P, batch=4, dtype=torch.float16, cv_weight=0.01, wgrad_streams=True)
+    assert len(nested.engs) == 2 and not nested.want_graph and "nested fork" in nested.capture_refused
+    nested.bind(img, dtok)
+    assert not nested.capture() and nested.capture_error == nested.capture_refused and nested.launch == "eager"
+    nested.step()                                    # eager: four streams
+    torch.cuda.synchronize()
+    assert rel(nested.flat, want) < 1e-5
+
+
+@pytest.mark.parametrize("task_cond", [False, True])
+def test_multitask_step_data_parallel_parts(task_cond):
     """The data-parallel form of the step: cut into parts with an asynchronous all-reduce of the gradient slice each part
     completed.  One-rank gloo group standing in for the collective (all-reduce = identity), `world=2` for the mean:
-    every slicing must give serial gradients / 2, eagerly and as replayed graphs."""
+    every slicing must give serial gradients / 2, eagerly and as replayed graphs.  task_cond: the task-conditioned
+    gate (configs[2] structure), whose w_gate[D:] rows must be final inside their block's slice too; the slice of a
+    part is checked to be FINAL when the part returns (nothing may be added to it by a later part)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import torch.distributed as dist
     from m3vit_amd.step import MultiTaskStep
     from oracle import ref_torch as R
-    cfg = R.BackboneCfg(img_size=(64, 64), embed_dim=64, depth=4, num_heads=2, mlp_ratio=4.0, moe_mlp_ratio=1.0,
-                        moe_experts=8, moe_top_k=2, gate_dim=66, multi_gate=True)
+    if task_cond:
+        cfg = R.BackboneCfg(img_size=(64, 64), embed_dim=64, depth=4, num_heads=2, mlp_ratio=4.0, moe_mlp_ratio=1.0,
+                            moe_experts=8, moe_top_k=2, gate_dim=67, multi_gate=False, gate_task_specific_dim=16)
+    else:
+        cfg = R.BackboneCfg(img_size=(64, 64), embed_dim=64, depth=4, num_heads=2, mlp_ratio=4.0, moe_mlp_ratio=1.0,
+                            moe_experts=8, moe_top_k=2, gate_dim=66, multi_gate=True)
     P = R.init_backbone_params(cfg, seed=5)
     torch.manual_seed(10)
     img = torch.randn(4, 3, 64, 64).cuda()
@@ -354,6 +456,17 @@ def test_multitask_step_data_parallel_parts():
             torch.cuda.synchronize()
             for n, gview in run.eng.grads.items():
                 assert rel(gview, ref.eng.grads[n] / 2) < 1e-5, (parts, n)
+            # every part's slice is final when the part returns: run the parts by hand and compare slice by slice
+            snap = []
+            for j in range(parts):
+                run.part(j)
+                torch.cuda.synchronize()
+                lo, hi = run.segments[j]
+                snap.append(run.flat[lo:hi].clone())
+            for j, (lo, hi) in enumerate(run.segments):
+                assert torch.equal(run.flat[lo:hi], snap[j]), (parts, j, "slice changed after its part returned")
+            for n, gview in run.eng.grads.items():
+                assert rel(gview, ref.eng.grads[n]) < 1e-5, (parts, n, "by hand")
             assert run.capture() and run.launch == "hipGraph replay" and len(run.graphs) == parts
             run.flat.fill_(3.0)
             run.step()

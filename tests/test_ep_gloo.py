@@ -131,3 +131,33 @@ def test_expert_parallel_exchange_world2_gloo():
 
 def test_dgdp_allreduce_params_world2_gloo():
     _run(_dgdp_worker)
+
+
+def test_device_plan_matches_the_host_plan_on_cpu():
+    """ep.device_plan (vectorised torch ops on CPU tensors; m3_ep_plan on the GPU - tests/test_hip_kernels.py) against
+    the plain-loop ExchangePlan for random count matrices incl. empty blocks, empty experts and empty sources."""
+    import torch
+    from m3vit_amd.ep import ExchangePlan, device_plan
+    g = torch.Generator().manual_seed(5)
+    for world, e_loc in [(1, 4), (2, 2), (4, 4), (8, 2), (8, 8), (3, 5)]:
+        for trial in range(3):
+            send = torch.randint(0, 40, (world * e_loc,), generator=g)
+            recv = torch.randint(0, 40, (world * e_loc,), generator=g)
+            if trial == 1:
+                recv.view(world, e_loc)[:, 0] = 0            # an expert nobody routes to
+                recv.view(world, e_loc)[world - 1] = 0       # a source that sends nothing
+            if trial == 2:
+                recv.zero_()
+            want = ExchangePlan(send.tolist(), recv.tolist(), world, e_loc)
+            got = device_plan(send, recv, world, e_loc)
+            assert got.in_splits == want.in_splits and got.out_splits == want.out_splits and got.n_recv == want.n_recv
+            assert got.regroup.tolist() == want.regroup and got.regroup_inv.tolist() == want.regroup_inv
+            assert got.fwd_expert_count.tolist() == want.fwd_expert_count
+            off = [0]
+            for c in want.fwd_expert_count:
+                off.append(off[-1] + c)
+            assert got.offsets.tolist() == off
+            ts = [0]
+            for c in want.fwd_expert_count:
+                ts.append(ts[-1] + (c + 127) // 128)
+            assert got.tile_starts.tolist() == ts

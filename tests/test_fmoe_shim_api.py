@@ -75,3 +75,75 @@ def test_pre_routed_layer_signature_and_keys():
     assert keys == {"experts.htoh4.weight", "experts.htoh4.bias", "experts.h4toh.weight", "experts.h4toh.bias"}
     assert layer.our_d_model == 32 and layer.num_expert == 4 and layer.top_k == 2
     assert all(getattr(p, "dp_comm") == "none" for p in layer.experts.parameters())
+
+
+def test_reference_layer_and_gate_construct_against_the_shim():
+    """Build container only (skipped where /root/reference is absent, e.g. on the GPU box): the reference's OWN
+    models/moe/ckpt/custom_moe_layer.py and noisy_gate_vmoe.py import and construct against install_fmoe_shim() - the
+    drop-in boundary of SURVEY.md 8(b) from the reference's side.  `tree` (dm-tree, third party, not installed here)
+    is given a two-function stand-in for the import line only; nothing of it runs at construction."""
+    import os
+    import sys
+    import types
+
+    import pytest
+    if not os.path.isdir("/root/reference/models/moe/ckpt"):
+        pytest.skip("reference checkout not present")
+    import m3vit_amd
+    m3vit_amd.install_fmoe_shim()
+    added = []
+    if "tree" not in sys.modules:
+        t = types.ModuleType("tree")
+        t.map_structure = lambda fn, *s: fn(*s)            # single-tensor structures: all the reference ever passes
+        t.flatten = lambda x: [x]
+        sys.modules["tree"] = t
+        added.append("tree")
+    sys.path.insert(0, "/root/reference")
+    try:
+        from models.moe.ckpt.custom_moe_layer import FMoETransformerMLP as RefLayer
+        from models.moe.ckpt.noisy_gate_vmoe import NoisyGate_VMoE as RefGate
+        from fmoe.gates.base_gate import BaseGate
+        from fmoe.layers import FMoE
+        assert issubclass(RefLayer, FMoE) and issubclass(RefGate, BaseGate)            # the shim's classes are the bases
+        act = torch.nn.Sequential(torch.nn.GELU(), torch.nn.Dropout(0.))
+        layer = RefLayer(num_expert=4, d_model=32, d_gate=34, d_hidden=48, gate=RefGate, top_k=2, multi_gate=True,
+                         activation=act, vmoe_noisy_std=0)
+        assert set(layer.state_dict().keys()) == {"experts.htoh4.weight", "experts.htoh4.bias", "experts.h4toh.weight",
+                                                  "experts.h4toh.bias", "gate.0.w_gate", "gate.1.w_gate"}
+        assert tuple(layer.experts.htoh4.weight.shape) == (4, 48, 32) and tuple(layer.experts.h4toh.bias.shape) == (4, 32)
+        assert all(getattr(p, "dp_comm") == "none" for p in layer.experts.parameters())      # mark_parallel_comm, :159
+        assert all(getattr(p, "dp_comm") == "gate" for g in layer.gate for p in g.parameters())
+        assert layer.d_model == 32 and layer.top_k == 2 and layer.world_size == 1 and layer.num_expert == 4
+        assert layer.gate_hook is None and layer.mask is None and layer.slice_size == 1 and layer.moe_group is None
+        assert callable(layer.expert_fn)
+        tc = RefLayer(num_expert=4, d_model=32, d_gate=37, d_hidden=32, gate=RefGate, top_k=2, gate_task_specific_dim=8,
+                      activation=act)
+        assert tuple(tc.gate.w_gate.shape) == (40, 4) and tc.gate.tot_expert == 4 and tc.gate.loss is None
+        # the mirror exposes the same keys / shapes, so a state_dict moves between the two
+        from m3vit_amd.gate import NoisyGate_VMoE
+        from m3vit_amd.moe_layer import FMoETransformerMLP
+        mine = FMoETransformerMLP(num_expert=4, d_model=32, d_gate=34, d_hidden=48, gate=NoisyGate_VMoE, top_k=2,
+                                  multi_gate=True, activation=act, vmoe_noisy_std=0)
+        mine.load_state_dict(layer.state_dict())
+        layer.load_state_dict(mine.state_dict())
+    finally:
+        sys.path.remove("/root/reference")
+        for m in added:
+            sys.modules.pop(m, None)
+        for m in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+            sys.modules.pop(m, None)
+
+
+def test_origin_convention_signatures():
+    """convention="origin" mirrors models/moe/origin/*: same ctor arguments, tensor / 2-tuple returns (checked on the
+    GPU in tests/test_modules_gpu.py); here: flags are plumbed from the backbone down to every gate."""
+    from m3vit_amd.gate import NoisyGate_VMoE
+    from m3vit_amd.vit import VisionTransformerMoE
+    vit = VisionTransformerMoE(img_size=(32, 32), embed_dim=64, depth=4, num_heads=2, moe_mlp_ratio=1, moe_experts=4,
+                               moe_top_k=2, gate_dim=66, multi_gate=True, convention="origin")
+    gates = [m for m in vit.modules() if isinstance(m, NoisyGate_VMoE)]
+    assert len(gates) == 4 and all(g.convention == "origin" for g in gates)
+    assert all(b.convention == "origin" for b in vit.blocks) and vit.blocks[1].mlp.convention == "origin"
+    ck = VisionTransformerMoE(img_size=(32, 32), embed_dim=64, depth=2, num_heads=2, moe_mlp_ratio=1, moe_experts=4,
+                              moe_top_k=2, gate_dim=66, multi_gate=True)
+    assert set(ck.state_dict().keys()) == {k for k in vit.state_dict().keys() if not k.startswith(("blocks.2", "blocks.3"))}

@@ -89,6 +89,59 @@ def test_full_size_fp32_matches_oracle_on_two_images():
     assert torch.equal(eng.flat_grads, g1)
 
 
+def test_full_size_fp16_matches_oracle_on_two_images():
+    """The BENCHMARKED dtype at the BENCHMARKED size against the float64 oracle (same structure as the fp32 test).
+    fp16 storage perturbs the gate input by ~1e-3, which flips a few near-tied experts, so - as in
+    tests/test_engine.py::_check_backbone(follow_routing=True) - the engine's indices must be EXACTLY the oracle gate's
+    top-k of the engine's own gate input, may differ from the float64 run's for a small fraction of tokens, and the values
+    are compared with the oracle following the engine's routing.
+    Bounds: tokens 1e-3 relative L2 (north_star).  Gradients: 12 blocks of fp16-stored activations AND fp16-stored
+    activation gradients (each rounding 2^-11 = 4.9e-4 relative, accumulated over the backward chain and the
+    T = 25 216-row contractions): measured worst tensors 1.1-1.4e-3 (norm biases, w_gate, cls_token); bound 3e-3
+    relative L2 per parameter tensor."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import ref_torch as R
+    cfg, P, img, eng = _setup(torch.float16)
+    pick = [3, 101]
+    task = 1
+    N, D, k = cfg.num_tokens, cfg.embed_dim, cfg.moe_top_k
+    tok, cv = eng.forward(img.cuda(), task)
+    ocfg = R.BackboneCfg(**{kk: getattr(cfg, kk) for kk in ("img_size", "embed_dim", "depth", "num_heads", "mlp_ratio",
+                                                             "moe_mlp_ratio", "moe_experts", "moe_top_k", "gate_dim",
+                                                             "multi_gate")})
+    moe_blocks = [i for i in range(cfg.depth) if i % 2 == 1]
+    ovr = {i: eng.act[i]["gate"]["idx"].view(128, N, k)[pick].reshape(-1, k).cpu() for i in moe_blocks}
+    Pr = {kk: v.clone().double().requires_grad_() for kk, v in P.items()}
+    tok_ref, _, aux = R.backbone_forward(Pr, ocfg, img[pick].double(), task, route_override=ovr)
+    with torch.no_grad():
+        free = R.backbone_forward(Pr, ocfg, img[pick].double(), task)[2]
+    for i in moe_blocks:
+        h2 = eng.act[i]["h2"].view(128, N, D)[pick].reshape(-1, D).double().cpu()
+        (own, _), *_ = R.gate_vmoe(h2, aux[i]["w_gate"].detach(), k)
+        assert torch.equal(ovr[i], own), f"block {i}: indices are not the top-k of the engine's own gate input"
+        flipped = float((ovr[i] != free[i]["idx"]).any(1).float().mean())
+        assert flipped < 0.1, f"block {i}: {flipped:.2%} of the tokens routed differently from the float64 run"
+    e_tok = rel(tok[pick], tok_ref)
+    assert e_tok < 1e-3, e_tok
+    dsel = torch.randn(2, N, D, generator=torch.Generator().manual_seed(6)) * 0.1
+    dtok = torch.zeros(128, N, D)
+    dtok[pick] = dsel
+    eng.zero_grad()
+    eng.backward(dtok.cuda(), cv_weight=0.0)
+    (tok_ref * dsel.double()).sum().backward()
+    errs = {}
+    for name, gr in eng.grads.items():
+        ref = Pr[name].grad
+        if ref is None:           # the other task's gate
+            assert float(gr.abs().max()) == 0.0, name
+            continue
+        errs[name] = rel(gr, ref)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print(f"fp16 full size: tokens rel {e_tok:.2e}; worst gradients {[(n, f'{e:.2e}') for n, e in worst]}")
+    assert worst[0][1] < 3e-3, worst
+
+
 def test_full_size_fp16_rows_do_not_depend_on_batch_position():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")

@@ -246,6 +246,55 @@ def test_route_edge_cases(ops):
         assert np.array_equal(r.row_of_slot.cpu().numpy(), cr)
 
 
+def test_ep_plan_kernel_matches_the_host_plan(ops):
+    """m3_ep_plan (device-side expert-parallel exchange plan) against the plain-loop ExchangePlan: split sizes,
+    regroup index, expert-major offsets and tile prefix, bit-exact, incl. empty blocks / experts / sources and the
+    configs[1] (W = 8, 2 experts per rank, 100 864 rows per rank) and configs[3] (W = 8, 8 per rank) sizes."""
+    from m3vit_amd.ep import ExchangePlan
+    g = torch.Generator().manual_seed(5)
+    cases = [(1, 4, 40), (2, 2, 40), (4, 4, 300), (8, 8, 200), (3, 5, 17), (8, 2, 12608), (8, 8, 1576), (64, 1, 50)]
+    for world, e_loc, hi in cases:
+        for trial in range(3):
+            send = torch.randint(0, hi, (world * e_loc,), generator=g)
+            recv = torch.randint(0, hi, (world * e_loc,), generator=g)
+            if trial == 1:
+                recv.view(world, e_loc)[:, 0] = 0
+                recv.view(world, e_loc)[world - 1] = 0
+            if trial == 2:
+                recv.zero_()
+            want = ExchangePlan(send.tolist(), recv.tolist(), world, e_loc)
+            buf = torch.full((int(recv.sum()) + 7,), -1, dtype=torch.int32, device=dev())
+            got = ops.ep_plan(send.to(dev()), recv.to(dev()), world, e_loc, buf)
+            assert got.in_splits == want.in_splits and got.out_splits == want.out_splits and got.n_recv == want.n_recv
+            assert got.regroup.cpu().tolist() == want.regroup
+            assert buf[got.n_recv:].cpu().tolist() == [-1] * 7                      # nothing written past the plan
+            off = np.concatenate([[0], np.cumsum(want.fwd_expert_count)])
+            assert np.array_equal(got.offsets.cpu().numpy(), off)
+            ts = np.concatenate([[0], np.cumsum((np.asarray(want.fwd_expert_count) + 127) // 128)])
+            assert np.array_equal(got.tile_starts.cpu().numpy(), ts)
+
+
+def test_route_out_of_range_ids_are_reported_and_stay_in_range(ops):
+    """expert ids outside [0, E) (a caller error: a wrong E, or offsets applied twice) get no slot; the metadata
+    stays inside [0, n) so that consumers gathering through it cannot fault, and Route.check() reports them."""
+    from m3vit_amd._lib import M3Error
+    n, E = 3000, 8
+    idx = torch.randint(0, E, (n,), generator=torch.Generator().manual_seed(3)).to(torch.int32)
+    ops.route_build(idx.to(dev()), E).check()                      # all in range: fine
+    bad = idx.clone()
+    bad[::7] = E + 3
+    bad[5::11] = -2
+    nbad = int(((bad < 0) | (bad >= E)).sum())
+    r = ops.route_build(bad.to(dev()), E)
+    assert int(r.offsets[-1]) == n - nbad and int(r.counts.sum()) == n - nbad
+    pos, ros = r.pos.cpu(), r.row_of_slot.cpu()
+    assert int(pos.min()) >= 0 and int(pos.max()) < n and int(ros.min()) >= 0 and int(ros.max()) < n
+    good = (bad >= 0) & (bad < E)
+    assert torch.equal(ros[pos[good].long()], torch.arange(n, dtype=torch.int32)[good])      # routed entries: a bijection
+    with pytest.raises(M3Error, match="outside"):
+        r.check()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gate_backward(ops, dtype):
     T, D, E, k = 1000, 384, 16, 4

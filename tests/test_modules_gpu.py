@@ -340,3 +340,150 @@ def test_sem_force_routing_override():
                            e.h4toh.bias.detach().double().cpu())
     ref = 0.5 * y.view(-1, k, D).sum(1)
     assert rel(out.reshape(-1, D), ref) < 2e-5
+
+
+def _layer_and_refs(**kw):
+    from m3vit_amd.gate import NoisyGate_VMoE
+    from m3vit_amd.moe_layer import FMoETransformerMLP
+    layer = FMoETransformerMLP(gate=NoisyGate_VMoE, vmoe_noisy_std=0,
+                               activation=torch.nn.Sequential(torch.nn.GELU(), torch.nn.Dropout(0.)), **kw).cuda()
+    e = layer.experts
+    refs = {n: p.detach().double().cpu().requires_grad_() for n, p in
+            (("w1", e.htoh4.weight), ("b1", e.htoh4.bias), ("w2", e.h4toh.weight), ("b2", e.h4toh.bias))}
+    return layer, refs
+
+
+def test_expert_prune_matches_reference_lines():
+    """expert_prune (custom_moe_layer.py:221-224): gate_score = where(gate_score > prune_threshold, gate_score, 0) in
+    front of the dispatch.  Forward and every gradient against a literal transcription on the oracle's gate / dispatch
+    (float64 autograd): pruned slots contribute nothing and pass no gradient to the gate."""
+    _need_gpu()
+    from oracle import ref_torch as R
+    torch.manual_seed(21)
+    E, D, k, T = 8, 64, 4, 96
+    thr = 0.16                                     # between the typical 2nd and 3rd softmax scores at E = 8
+    layer, refs = _layer_and_refs(num_expert=E, d_model=D, d_gate=D, d_hidden=D, top_k=k, expert_prune=True, prune_threshold=thr)
+    with torch.no_grad():
+        layer.gate.w_gate.mul_(4.0)                # spread the softmax so that some of the k scores fall under the threshold
+    x = torch.randn(T, D, device="cuda", requires_grad=True)
+    dout = torch.randn(T, D, device="cuda") * 0.1
+    seen = {}
+    layer.gate_hook = lambda idx, score, _: seen.update(idx=idx.clone(), score=score.detach().clone())
+    out, *_ = layer(x)
+    out.backward(dout)
+    # --- reference lines
+    xr = x.detach().double().cpu().requires_grad_()
+    wg = layer.gate.w_gate.detach().double().cpu().requires_grad_()
+    (idx, score), *_ = R.gate_vmoe(xr, wg, k)
+    score = torch.where(score > thr, score, torch.zeros_like(score))                       # :222
+    frac = float((score == 0).float().mean())
+    assert 0.05 < frac < 0.95, f"the test must prune some, not all, slots (pruned {frac:.0%})"
+    y = R.moe_dispatch_ffn(xr, idx, refs["w1"], refs["b1"], refs["w2"], refs["b2"])         # :263-265
+    ref = torch.bmm(score.view(T, 1, k), y.view(T, k, D)).reshape(T, D)                    # :291-305
+    ref.backward(dout.double().cpu())
+    assert torch.equal(seen["idx"].cpu(), idx) and torch.equal(seen["score"].cpu() == 0, score == 0)
+    assert rel(out, ref) < 2e-5
+    e = layer.experts
+    for name, got, want in (("x", x.grad, xr.grad), ("w_gate", layer.gate.w_gate.grad, wg.grad),
+                            ("w1", e.htoh4.weight.grad, refs["w1"].grad), ("b1", e.htoh4.bias.grad, refs["b1"].grad),
+                            ("w2", e.h4toh.weight.grad, refs["w2"].grad), ("b2", e.h4toh.bias.grad, refs["b2"].grad)):
+        assert rel(got, want) < 1e-4, name
+
+
+@pytest.mark.parametrize("task", [0, 1, 2])
+def test_regu_experts_fromtask_matches_reference_lines(task):
+    """regu_experts_fromtask (noisy_gate_vmoe.py:87-89, custom_moe_layer.py:244-246): the gate scores only the
+    num_experts_pertask columns of w_gate that start at start_experts_id[task] (ctor :106-112 / gate :40-46: a running
+    sum), and the layer shifts the chosen indices by that start.  Forward and every gradient against a literal
+    transcription; w_gate columns outside the task's slice get exactly zero gradient."""
+    _need_gpu()
+    from oracle import ref_torch as R
+    torch.manual_seed(22)
+    E, D, k, T, npt, ntask = 16, 64, 2, 80, 6, 3
+    layer, refs = _layer_and_refs(num_expert=E, d_model=D, d_gate=D, d_hidden=D, top_k=k, regu_experts_fromtask=True,
+                                  num_experts_pertask=npt, num_tasks=ntask)
+    # the reference's start ids (running sum, both ctors)
+    starts, s = [], 0
+    for i in range(ntask):
+        s = s + int(i * (E - npt) / (ntask - 1))
+        starts.append(s)
+    assert layer.start_experts_id == starts and layer.gate.start_experts_id == starts
+    if starts[task] + npt > E:
+        pytest.skip("the reference's running-sum start ids leave the expert range for this task")
+    x = torch.randn(T, D, device="cuda", requires_grad=True)
+    dout = torch.randn(T, D, device="cuda") * 0.1
+    seen = {}
+    layer.gate_hook = lambda idx, score, _: seen.update(idx=idx.clone())
+    out, *_ = layer(x, task_id=task)
+    out.backward(dout)
+    xr = x.detach().double().cpu().requires_grad_()
+    wg = layer.gate.w_gate.detach().double().cpu().requires_grad_()
+    (idx, score), *_ = R.gate_vmoe(xr, wg[:, starts[task]:starts[task] + npt], k)          # noisy_gate_vmoe.py:87-88
+    idx = idx + starts[task]                                                               # custom_moe_layer.py:246
+    y = R.moe_dispatch_ffn(xr, idx, refs["w1"], refs["b1"], refs["w2"], refs["b2"])
+    ref = torch.bmm(score.view(T, 1, k), y.view(T, k, D)).reshape(T, D)
+    ref.backward(dout.double().cpu())
+    assert torch.equal(seen["idx"].cpu(), idx)
+    assert int(idx.min()) >= starts[task] and int(idx.max()) < starts[task] + npt
+    assert rel(out, ref) < 2e-5
+    e = layer.experts
+    gw = layer.gate.w_gate.grad
+    outside = torch.ones(E, dtype=torch.bool)
+    outside[starts[task]:starts[task] + npt] = False
+    assert float(gw[:, outside.cuda()].abs().max()) == 0.0
+    for name, got, want in (("x", x.grad, xr.grad), ("w_gate", gw, wg.grad),
+                            ("w1", e.htoh4.weight.grad, refs["w1"].grad), ("b1", e.htoh4.bias.grad, refs["b1"].grad),
+                            ("w2", e.h4toh.weight.grad, refs["w2"].grad), ("b2", e.h4toh.bias.grad, refs["b2"].grad)):
+        assert rel(got, want) < 1e-4, name
+
+
+@pytest.mark.parametrize("std", [0.0, 1.0])
+def test_origin_convention_matches_ckpt_convention(std):
+    """convention="origin" (models/moe/origin/*: gate -> (idx, score) + self.loss, layer -> tensor, backbone -> tokens,
+    loss gathered by utils/moe_utils.py::collect_noisy_gating_loss) against the ckpt-convention model with the same
+    parameters (itself pinned to the oracle by test_vit_mirror_matches_oracle_fwd_bwd): identical tokens, the collected
+    loss = weight * the ckpt backbone's cv loss, identical gradients of tokens . d + loss; eval mode stores loss 0."""
+    _need_gpu()
+    from m3vit_amd.moe_utils import collect_noisy_gating_loss
+    from m3vit_amd.vit import VisionTransformerMoE
+    kw = dict(img_size=(32, 48), embed_dim=64, depth=4, num_heads=2, moe_experts=8, moe_top_k=2, gate_dim=66,
+              multi_gate=True, mlp_ratio=4.0, moe_mlp_ratio=1, vmoe_noisy_std=std)
+    torch.manual_seed(3)
+    a = VisionTransformerMoE(**kw).cuda()
+    b = VisionTransformerMoE(convention="origin", **kw).cuda()
+    b.load_state_dict(a.state_dict())
+    a.train(); b.train()
+    img = torch.randn(3, 3, 32, 48).cuda()
+    dtok = (torch.randn(3, a.num_patches + 1, 64) * 0.1).cuda()
+    w = 0.01
+    for task in (0, 1):
+        torch.manual_seed(70 + task)                       # the gates draw their noise with torch.randn
+        tok_a, cv_a = a(img, task_id=task)
+        torch.manual_seed(70 + task)
+        out_b = b(img, task_id=task)
+        assert torch.is_tensor(out_b) and out_b.shape == tok_a.shape          # tokens only
+        assert torch.equal(out_b, tok_a)
+        loss_b = collect_noisy_gating_loss(b, w)
+        assert abs(float(loss_b) - w * float(cv_a)) <= 1e-6 * max(1.0, abs(w * float(cv_a)))
+        assert not any(m.has_loss for m in b.modules() if hasattr(m, "has_loss"))      # get_loss() cleared them
+        ((tok_a * dtok).sum() + w * cv_a).backward()
+        ((out_b * dtok).sum() + loss_b).backward()
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if pa.grad is None:
+            assert pb.grad is None or float(pb.grad.abs().max()) == 0.0, n
+            continue
+        if pb.grad is None:                                # ckpt: 0.0 * sum(other gates) keep-alive gives zeros, origin: None
+            assert float(pa.grad.abs().max()) == 0.0, n
+            continue
+        assert rel(pb.grad, pa.grad) < 1e-5, n
+    # the layer / gate level returns
+    blk = b.blocks[1]
+    x = torch.randn(2, 7, 64, device="cuda")
+    y = blk.mlp(x, None, 0, None, None)
+    assert torch.is_tensor(y) and y.shape == x.shape
+    g_out = blk.mlp.gate[0](x)
+    assert isinstance(g_out, tuple) and len(g_out) == 2 and g_out[0].shape == (2, 7, 2) and g_out[0].dtype == torch.int64
+    assert blk.mlp.gate[0].has_activation and blk.mlp.gate[0].get_activation().shape == (2, 7, 8)
+    b.eval()
+    b(img, task_id=0)
+    assert float(collect_noisy_gating_loss(b, 1.0)) == 0.0
