@@ -223,7 +223,7 @@ typedef struct {
                                       same pass (one extra MFMA row); reduced by m3_wgrad_reduce (same launch as
                                       the weight slabs) or m3_wgrad_bias_reduce */
   int32_t chunk_rows;              /* 0: every group is cut into `splits` equal parts.  > 0 (grouped calls, a
-                                      multiple of 32): balanced mode - a work unit is chunk_rows rows of one group,
+                                      multiple of 64): balanced mode - a work unit is chunk_rows rows of one group,
                                       group g gets ceil(rows_g / chunk_rows) consecutive units of equal size (taken from the
                                       device-resident offsets: a hot expert gets proportionally more workgroups), ws is
                                       [units][N][K] (bias_ws [units][N]) and m3_wgrad_reduce_grouped sums each

@@ -82,15 +82,31 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_res_kernel(const 
       if (qrow < N) qfs[i][ch] = *(const f16x8 *)(qbase + (int64_t)qrow * ld + ch * 32 + 8 * lg);
     }
   }
-  for (int q = tid; q < NP * CPR; q += AR_THREADS) {
-    const int row = q / CPR, c = q % CPR;
-    u32x4 kv = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
-    if (row < N) {
-      kv = *(const u32x4 *)((const char *)(kbase + (int64_t)row * ld) + c * 16);
-      vv = *(const u32x4 *)((const char *)(vbase + (int64_t)row * ld) + c * 16);
+  // K / V images: ALL loads of the thread are issued before the first LDS store (a rolled loop waits for each
+  // iteration's loads in turn: in-kernel stamps showed a third of a workgroup's life in this phase)
+  {
+    constexpr int SIT = AR_MAXN * CPR / AR_THREADS, SB = SIT < 4 ? SIT : 4;      // batches of <= 4 iterations (registers)
+#pragma unroll
+    for (int it0 = 0; it0 < SIT; it0 += SB) {
+      u32x4 kv[SB], vv[SB];
+#pragma unroll
+      for (int it = 0; it < SB; ++it) {
+        const int q = (it0 + it) * AR_THREADS + tid, row = q / CPR, c = q % CPR;
+        kv[it] = u32x4{0u, 0u, 0u, 0u}; vv[it] = kv[it];
+        if (row < N) {
+          kv[it] = *(const u32x4 *)((const char *)(kbase + (int64_t)row * ld) + c * 16);
+          vv[it] = *(const u32x4 *)((const char *)(vbase + (int64_t)row * ld) + c * 16);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < SB; ++it) {
+        const int q = (it0 + it) * AR_THREADS + tid, row = q / CPR, c = q % CPR;
+        if (row < NP) {
+          *(u32x4 *)(sK + swo<DH>(row, c * 16)) = kv[it];
+          *(u32x4 *)(sV + swo<DH>(row, c * 16)) = vv[it];
+        }
+      }
     }
-    *(u32x4 *)(sK + swo<DH>(row, c * 16)) = kv;
-    *(u32x4 *)(sV + swo<DH>(row, c * 16)) = vv;
   }
   __syncthreads();
 
@@ -159,6 +175,19 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_res_kernel(const 
   }
 }
 
+// Diagnostic build only (-DM3_ATTN_STAMPS, tools/attn_stamps.py): lane 0 of wave 0 of every workgroup of the
+// short-sequence backward records s_memtime at its phase boundaries; no stamp executes in the shipped kernel.
+#ifdef M3_ATTN_STAMPS
+constexpr int ASTAMP_WGS = 2048, ASTAMP_N = 40;
+__device__ unsigned long long g_attn_stamps[ASTAMP_WGS][ASTAMP_N];
+#define ATTN_STAMP(i)                                                                              \
+  do {                                                                                             \
+    if (threadIdx.x == 0 && blockIdx.x < ASTAMP_WGS && (i) < ASTAMP_N) g_attn_stamps[blockIdx.x][(i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define ATTN_STAMP(i) do { } while (0)
+#endif
+
 // ----------------------------------------------------------------------------- backward
 // NW waves; wave owns key tiles {w, w + NW, ...} (KTW = 16 / NW of them); dQ pieces (2 query tiles x NDT d tiles) = NW
 template <int DH>
@@ -186,29 +215,46 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
   const half_t *dobase = d_o + (int64_t)b * N * C + h * DH;
   half_t *dqbase = dqkv + (int64_t)b * N * ld + h * DH;
   const float *lbase = lse + ((int64_t)b * heads + h) * N;
+  ATTN_STAMP(0);
 
-  // ---- stage Q, dO, K; delta[q] = sum_d dO O (CPR chunk-threads per row)
-  for (int q = tid; q < NP * CPR; q += NT) {
-    const int row = q / CPR, c = q % CPR;
-    u32x4 qv = u32x4{0u, 0u, 0u, 0u}, dv = qv, kv = qv, ov = qv;
-    if (row < N) {
-      qv = *(const u32x4 *)((const char *)(qbase + (int64_t)row * ld) + c * 16);
-      kv = *(const u32x4 *)((const char *)(kbase + (int64_t)row * ld) + c * 16);
-      dv = *(const u32x4 *)((const char *)(dobase + (int64_t)row * C) + c * 16);
-      ov = *(const u32x4 *)((const char *)(obase + (int64_t)row * C) + c * 16);
+  // ---- stage Q, dO, K; delta[q] = sum_d dO O (CPR chunk-threads per row).  ALL loads of the thread are issued before
+  // the first LDS store (stamps: the rolled loop, which waits for each iteration's four loads in turn, was 34 % of
+  // a workgroup's life)
+  {
+    constexpr int SIT = AR_MAXN * CPR / NT;
+    u32x4 qv[SIT], dv[SIT], kv[SIT], ov[SIT];
+    float lv[SIT];
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+      const int q = it * NT + tid, row = q / CPR, c = q % CPR;
+      qv[it] = u32x4{0u, 0u, 0u, 0u}; dv[it] = qv[it]; kv[it] = qv[it]; ov[it] = qv[it];
+      lv[it] = 1e30f;                                              // padded query rows: P = exp2(-huge) = 0
+      if (row < N) {
+        qv[it] = *(const u32x4 *)((const char *)(qbase + (int64_t)row * ld) + c * 16);
+        kv[it] = *(const u32x4 *)((const char *)(kbase + (int64_t)row * ld) + c * 16);
+        dv[it] = *(const u32x4 *)((const char *)(dobase + (int64_t)row * C) + c * 16);
+        ov[it] = *(const u32x4 *)((const char *)(obase + (int64_t)row * C) + c * 16);
+        if (c == 0) lv[it] = lbase[row] * AR_LOG2E;
+      }
     }
-    *(u32x4 *)(sQ + swo<DH>(row, c * 16)) = qv;
-    *(u32x4 *)(sdO + swo<DH>(row, c * 16)) = dv;
-    *(u32x4 *)(sK + swo<DH>(row, c * 16)) = kv;
-    const f16x8 dh8 = __builtin_bit_cast(f16x8, dv), oh8 = __builtin_bit_cast(f16x8, ov);
-    float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s += (float)dh8[j] * (float)oh8[j];
+    for (int it = 0; it < SIT; ++it) {
+      const int q = it * NT + tid, row = q / CPR, c = q % CPR;
+      const f16x8 dh8 = __builtin_bit_cast(f16x8, dv[it]), oh8 = __builtin_bit_cast(f16x8, ov[it]);
+      float sd = 0.f;
 #pragma unroll
-    for (int m = 1; m < CPR; m <<= 1) s += __shfl_xor(s, m, 64);
-    if (c == 0) {
-      sDelta[row] = s;
-      sLse[row] = (row < N) ? lbase[row] * AR_LOG2E : 1e30f;     // padded query rows: P = exp2(-huge) = 0
+      for (int j = 0; j < 8; ++j) sd += (float)dh8[j] * (float)oh8[j];
+#pragma unroll
+      for (int m = 1; m < CPR; m <<= 1) sd += __shfl_xor(sd, m, 64);
+      if (row < NP) {
+        *(u32x4 *)(sQ + swo<DH>(row, c * 16)) = qv[it];
+        *(u32x4 *)(sdO + swo<DH>(row, c * 16)) = dv[it];
+        *(u32x4 *)(sK + swo<DH>(row, c * 16)) = kv[it];
+        if (c == 0) {
+          sDelta[row] = sd;
+          sLse[row] = lv[it];
+        }
+      }
     }
   }
   // rows of the dS^T images that no wave writes (key tiles past the last valid one) must read as zero
@@ -235,7 +281,9 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
   for (int a = 0; a < NDT; ++a)
 #pragma unroll
     for (int c = 0; c < KTW; ++c) { dkt[a][c] = zero4; dvt[a][c] = zero4; }
+  ATTN_STAMP(1);                                   // loads issued, LDS stores queued
   __syncthreads();
+  ATTN_STAMP(2);                                   // operands staged
 
   const float c1 = scale * AR_LOG2E;
   const int nkc = NP >> 5;                       // 32-key chunks of the dQ contraction
@@ -279,6 +327,7 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
         }
       }
     }
+    ATTN_STAMP(3 + 4 * st);                          // S, dP, P, dS of the step
     // ---- dV^T += dO^T P ; dK^T += Q^T dS   (contraction over the 32 queries of the step)
     {
       f16x8 aq[NDT], ado[NDT];
@@ -307,16 +356,28 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
         }
       }
     }
+    ATTN_STAMP(4 + 4 * st);                          // dV, dK accumulated, dS^T stored
     __syncthreads();      // the other dS^T buffer is rewritten only after the NEXT barrier
+    ATTN_STAMP(5 + 4 * st);                          // barrier passed
     // ---- dQ^T[d = 16*dt + 4*lg + r][q = 16*qt + li] = K^T dS^T, one (qt, dt) piece per wave
     {
       const int qt = wave / NDT, dt = wave - qt * NDT;
+      // all fragment reads first (clamped chunk index: always inside the images), then the dependent MFMA chain
+      f16x8 ka[AR_MAXN / 32], da[AR_MAXN / 32];
+#pragma unroll
+      for (int c = 0; c < AR_MAXN / 32; ++c) {
+        const int cc = c < nkc ? c : nkc - 1;
+        ka[c] = tr_frag<DH>(sK, cc * 32, dt * 16, li, lg);
+        da[c] = tr_frag<32>(dsb, cc * 32, qt * 16, li, lg);
+      }
       f32x4 acc = zero4;
-      for (int c = 0; c < nkc; ++c)
-        acc = mma16(tr_frag<DH>(sK, c * 32, dt * 16, li, lg), tr_frag<32>(dsb, c * 32, qt * 16, li, lg), acc);
+#pragma unroll
+      for (int c = 0; c < AR_MAXN / 32; ++c)
+        if (c < nkc) acc = mma16(ka[c], da[c], acc);
       const int qr = qs + qt * 16 + li;
       if (qr < N) Vec4<half_t>::store(dqbase + (int64_t)qr * ld + dt * 16 + 4 * lg, acc * scale);
     }
+    ATTN_STAMP(6 + 4 * st);                          // dQ piece of the step stored
   }
 
   // ---- dK, dV rows of this wave's keys
@@ -331,6 +392,11 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
       }
     }
   }
+  ATTN_STAMP(36);                                  // dK / dV stores issued
+#ifdef M3_ATTN_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATTN_STAMP(37);                                  // stores acknowledged
+#endif
 }
 
 // -------------------------------------------------------------------- forward, long sequences
@@ -625,6 +691,7 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
         }
       }
     }
+    ATTN_STAMP(3 + 4 * st);                          // S, dP, P, dS of the step
     // ---- dV^T += dO^T P ; dK^T += Q^T dS   (contraction over the 32 queries of the step)
     {
       f16x8 aq[NDT], ado[NDT];
@@ -657,9 +724,18 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
     // ---- dQ^T[d][q] contribution of this key block, one (qt, dt) piece per wave -> fp32 slab
     {
       const int qt = wave / NDT, dt = wave - qt * NDT;
+      // all fragment reads first (clamped chunk index: always inside the images), then the dependent MFMA chain
+      f16x8 ka[AR_MAXN / 32], da[AR_MAXN / 32];
+#pragma unroll
+      for (int c = 0; c < AR_MAXN / 32; ++c) {
+        const int cc = c < nkc ? c : nkc - 1;
+        ka[c] = tr_frag<DH>(sK, cc * 32, dt * 16, li, lg);
+        da[c] = tr_frag<32>(dsb, cc * 32, qt * 16, li, lg);
+      }
       f32x4 acc = zero4;
-      for (int c = 0; c < nkc; ++c)
-        acc = mma16(tr_frag<DH>(sK, c * 32, dt * 16, li, lg), tr_frag<32>(dsb, c * 32, qt * 16, li, lg), acc);
+#pragma unroll
+      for (int c = 0; c < AR_MAXN / 32; ++c)
+        if (c < nkc) acc = mma16(ka[c], da[c], acc);
       const int qr = qs + qt * 16 + li;
       if (qr < N) *(f32x4 *)(dqw + (int64_t)qr * DH + dt * 16 + 4 * lg) = acc * scale;
     }
@@ -749,3 +825,10 @@ int launch_attention_bwd_res(const void *qkv, const void *o, const void *d_o, co
 }
 
 }  // namespace m3
+
+#ifdef M3_ATTN_STAMPS
+extern "C" int m3_debug_attn_stamps(unsigned long long *dst, int wgs) {
+  if (wgs > m3::ASTAMP_WGS) wgs = m3::ASTAMP_WGS;
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(m3::g_attn_stamps), (size_t)wgs * m3::ASTAMP_N * sizeof(unsigned long long)) == hipSuccess ? M3_OK : M3_ERR_LAUNCH;
+}
+#endif

@@ -34,7 +34,6 @@
 
 namespace m3 {
 
-constexpr int FFN_THREADS = 256;
 constexpr int FFN_SLICE = 16384;                 // bytes per weight slice: 128 image rows x 128 B
 constexpr int FFN_NSLOT = 3;
 constexpr int FFN_RING = FFN_NSLOT * FFN_SLICE;  // 48 KiB
@@ -73,16 +72,23 @@ __device__ unsigned long long g_ffn_stamps[FSTAMP_WGS][FSTAMP_N];
 #define FFN_STAMP(i) do { } while (0)
 #endif
 
-// D: model width (contraction of FC1, output width of FC2), MT: 16-row tiles per wave
+// D: model width (contraction of FC1, output width of FC2), MT: 16-row tiles per wave, NW: waves per workgroup
+// (4: one wave per SIMD, up to 512 registers; 8: two per SIMD, 256 registers - the partner wave covers the issue time
+// of memory instructions, LDS latency and the GELU's VALU work, at twice the LDS fragment reads per MFMA when MT = 1)
 // ABL (diagnostic builds only, M3_FFN_ABL): bit 0 no GELU, bit 1 no weight loads inside the loop, bit 2 no MFMAs
-template <int D, int MT, bool OUT_F32, int ABL = 0>
-__global__ __launch_bounds__(FFN_THREADS, 1) void ffn_fwd_kernel(const FfnDev p) {
+template <int D, int MT, int NW, bool OUT_F32, int ABL = 0>
+__global__ __launch_bounds__(NW * 64, NW / 4) void ffn_fwd_kernel(const FfnDev p) {
   typedef Mma<half_t> MM;
   typedef MM::frag frag;
   constexpr int KS = D / 32;              // k steps of FC1
   constexpr int DT = D / 16;              // output tiles
-  constexpr int ROWS = 64 * MT;           // rows per workgroup
   constexpr int WROWS = 16 * MT;          // rows per wave
+  constexpr int ROWS = NW * WROWS;        // rows per workgroup
+  constexpr int RU = ROWS / 64;           // row-index registers per lane (rows lane, lane + 64, ..)
+  constexpr int NT = NW * 64;             // threads
+  constexpr int PPW = 16 / NW;            // 1-KiB pieces of a weight slice per wave
+  constexpr bool FA2 = NW == 4;           // double-buffered fragment registers (one wave per SIMD only: 256 registers do not hold a second set)
+  static_assert(ROWS % 64 == 0 && RU <= 2 && 16 % NW == 0, "geometry");
   constexpr int XROWB = D * 2;            // bytes of an X row
   constexpr int XCH = XROWB / 16;         // 16-byte chunks per X row (multiple of 16)
   constexpr int NP = D / 128;             // slices per phase per hidden chunk
@@ -137,38 +143,38 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void ffn_fwd_kernel(const FfnDev p)
   // slot lane % 8, which receives source chunk (lane % 8) ^ swz(row), swz(row) = (row >> 1) & 7 (lane-linear image).
   // Phase-1 slice j of chunk hc: image row r = lcl * 64 + hl  <-  W1[hc*64 + hl][k bytes (2j + lcl) * 128 ..]
   // Phase-2 slice j of chunk hc: image row r (= d - 128 j)     <-  W2p[128 j + r][h bytes hc * 128 ..]
-  uint32_t off1[4], off2[4];
+  uint32_t off1[PPW], off2[PPW];
 #pragma unroll
-  for (int pc = 0; pc < 4; ++pc) {
-    const int r = (4 * wave + pc) * 8 + (lane >> 3);
+  for (int pc = 0; pc < PPW; ++pc) {
+    const int r = (PPW * wave + pc) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     off1[pc] = (uint32_t)((r & 63) * XROWB + (r >> 6) * 128 + c * 16);
     off2[pc] = (uint32_t)(r * H * 2 + c * 16);
   }
-  u32x4 wq[2][4];                               // two slices in flight in registers
-  auto load_slice = [&](int sl, u32x4(&q)[4]) {
+  u32x4 wq[2][PPW];                             // two slices in flight in registers
+  auto load_slice = [&](int sl, u32x4(&q)[PPW]) {
     const int hc = sl / SPC, j = sl - hc * SPC;
     if (j < NP) {
       const char *src = w1g + (int64_t)hc * (FFN_HC * XROWB) + j * 256;
 #pragma unroll
-      for (int pc = 0; pc < 4; ++pc) q[pc] = *(const u32x4 *)(src + off1[pc]);
+      for (int pc = 0; pc < PPW; ++pc) q[pc] = *(const u32x4 *)(src + off1[pc]);
     } else {
       const char *src = w2g + (int64_t)(j - NP) * (128 * 2) * H + hc * 128;
 #pragma unroll
-      for (int pc = 0; pc < 4; ++pc) q[pc] = *(const u32x4 *)(src + off2[pc]);
+      for (int pc = 0; pc < PPW; ++pc) q[pc] = *(const u32x4 *)(src + off2[pc]);
     }
   };
   auto slot_of = [&](int sl) { return ring + (sl % FFN_NSLOT) * FFN_SLICE; };
-  auto write_slice = [&](int sl, const u32x4(&q)[4]) {
-    char *dst = slot_of(sl) + wave * 4096 + lane * 16;
+  auto write_slice = [&](int sl, const u32x4(&q)[PPW]) {
+    char *dst = slot_of(sl) + wave * (PPW * 1024) + lane * 16;
 #pragma unroll
-    for (int pc = 0; pc < 4; ++pc) *(u32x4 *)(dst + pc * 1024) = q[pc];
+    for (int pc = 0; pc < PPW; ++pc) *(u32x4 *)(dst + pc * 1024) = q[pc];
   };
 
   // ---- row indices of the tile: lane holds rows `lane` (and `lane + 64`); everything else gets them by shuffle
-  int32_t xrow[MT], yrow[MT];
+  int32_t xrow[RU], yrow[RU];
 #pragma unroll
-  for (int u = 0; u < MT; ++u) {
+  for (int u = 0; u < RU; ++u) {
     int64_t m = m_begin + u * 64 + lane;
     if (m >= m_end) m = m_end - 1;              // clamp: valid memory, never stored
     xrow[u] = p.x_row_idx ? p.x_row_idx[m] / p.x_row_div : (int32_t)m;
@@ -181,14 +187,14 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void ffn_fwd_kernel(const FfnDev p)
   // ---- X image by LDS-DMA (once per tile): row r at xreg + r * XROWB, chunk c of the row stored at position
   // (c & ~15) | ((c & 15) ^ (r & 15))  (conflict-free ds_read_b128 of 16 rows at one k chunk).
   // Instruction q (wave w: q = w * XI + jj) fills flat positions 64 q .. 64 q + 63.
-  constexpr int XI = ROWS * XCH / 64 / 4;       // X DMA instructions per wave
+  constexpr int XI = ROWS * XCH / 64 / NW;      // X DMA instructions per wave
 #pragma unroll
   for (int jj = 0; jj < XI; ++jj) {
     const int f = (wave * XI + jj) * 64 + lane;
     const int r = f / XCH, cp = f - r * XCH;
     const int c = (cp & ~15) | ((cp & 15) ^ (r & 15));
     int src = __shfl(xrow[0], r & 63, 64);
-    if (MT > 1) { const int s1 = __shfl(xrow[MT - 1], r & 63, 64); if (r >= 64) src = s1; }
+    if (RU > 1) { const int s1 = __shfl(xrow[RU - 1], r & 63, 64); if (r >= 64) src = s1; }
     glds16(p.X + (int64_t)src * p.ldx_b + c * 16, xreg + (wave * XI + jj) * 1024);
   }
   FFN_STAMP(1);                                  // loads issued
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void ffn_fwd_kernel(const FfnDev p)
   float *const b2s = b1s + H;
   {
     const int nb = H + D;
-    for (int i0 = wave * 64; i0 < nb; i0 += 256) {
+    for (int i0 = wave * 64; i0 < nb; i0 += NT) {
       const int i = i0 + lane;
       if (i < nb) {
         const float *src = (i < H) ? (p.b1 ? p.b1 + (int64_t)g * H + i : nullptr) : (p.b2 ? p.b2 + (int64_t)g * D + (i - H) : nullptr);
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void ffn_fwd_kernel(const FfnDev p)
   for (int mt = 0; mt < MT; ++mt) {
     const int r = wave * WROWS + mt * 16 + li;
     int v = __shfl(yrow[0], r & 63, 64);
-    if (MT > 1) { const int v1 = __shfl(yrow[MT - 1], r & 63, 64); if (r >= 64) v = v1; }
+    if (RU > 1) { const int v1 = __shfl(yrow[RU - 1], r & 63, 64); if (r >= 64) v = v1; }
     crow[mt] = v;
     rok[mt] = m_begin + r < m_end;
   }
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void ffn_fwd_kernel(const FfnDev p)
   //   b. barrier: slice n is readable (and every wave is done with the first half of slice n - 1);
   //   c. the loads of slice n + 2 are issued into the register set that step a freed.
   // The compiler counts these plain loads (and the optional pre / act stores) itself: no hand-written vmcnt.
-  auto sync_next = [&](int sl, u32x4(&q)[4]) {   // called between the halves of slice sl; q = register set of sl + 1
+  auto sync_next = [&](int sl, u32x4(&q)[PPW]) {   // called between the halves of slice sl; q = register set of sl + 1
     const int nx = sl + 1;
     if (nx >= NSL) return;
     write_slice(nx, q);
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void ffn_fwd_kernel(const FfnDev p)
   // slice are already in flight into fa[cur ^ 1] (one wave per SIMD: nobody else hides the LDS latency).  A half slice is
   // 8 fragments: f = kc * 4 + ht (phase 1: k step 2 * half + kc, hidden tile ht) or f = ks2 * 4 + d4 (phase 2: output
   // tile 4 * half + d4) - consecutive MFMAs go to different accumulators.
-  frag fa[2][8];
+  frag fa[FA2 ? 2 : 1][8];
   auto load1 = [&](frag(&f)[8], const char *sb, int half) {
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc)
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void ffn_fwd_kernel(const FfnDev p)
       for (int d4 = 0; d4 < 4; ++d4) f[ks2 * 4 + d4] = *(const frag *)(sb + rd2[ks2] + (half * 4 + d4) * 16 * 128);
   };
 
-  load1(fa[0], slot_of(0), 0);
+  if (FA2) load1(fa[0], slot_of(0), 0);
   for (int hc = 0; hc < NC; ++hc) {
     const int sl0 = hc * SPC;
     f32x4 acc1[4][MT];
@@ -300,24 +306,29 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void ffn_fwd_kernel(const FfnDev p)
       const int sl = sl0 + j;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        if (half == 0) {
-          load1(fa[1], slot_of(sl), 1);
+        if (FA2) {
+          if (half == 0) {
+            load1(fa[1], slot_of(sl), 1);
+          } else {
+            sync_next(sl, wq[(j + 1) & 1]);
+            if (j + 1 < NP) load1(fa[0], slot_of(sl + 1), 0); else load2(fa[0], slot_of(sl + 1), 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         } else {
-          sync_next(sl, wq[(j + 1) & 1]);
-          if (j + 1 < NP) load1(fa[0], slot_of(sl + 1), 0); else load2(fa[0], slot_of(sl + 1), 0);
+          if (half == 1) sync_next(sl, wq[(j + 1) & 1]);
+          load1(fa[0], slot_of(sl), half);
         }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
           for (int ht = 0; ht < 4; ++ht)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-              const frag a = fa[half][kc * 4 + ht];
+              const frag a = fa[FA2 ? half : 0][kc * 4 + ht];
               if (ABL & 4) { asm volatile("" :: "v"(a)); acc1[ht][mt][0] += 1.f; }
               else acc1[ht][mt] = MM::mma(a, xf[mt][4 * j + 2 * half + kc], acc1[ht][mt]);
             }
-        __builtin_amdgcn_sched_barrier(0);
+        if (FA2) __builtin_amdgcn_sched_barrier(0);
       }
     }
     // ---- optional outputs for a backward that keeps the hidden activations: pre = x W1^T + b1, act = GELU(pre),
@@ -350,13 +361,18 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void ffn_fwd_kernel(const FfnDev p)
       const int sl = sl0 + NP + j;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        if (half == 0) {
-          load2(fa[1], slot_of(sl), 1);
+        if (FA2) {
+          if (half == 0) {
+            load2(fa[1], slot_of(sl), 1);
+          } else {
+            sync_next(sl, wq[(NP + j + 1) & 1]);
+            if (j + 1 < NP) load2(fa[0], slot_of(sl + 1), 0); else load1(fa[0], slot_of(sl + 1), 0);   // (past the end: unused)
+          }
+          __builtin_amdgcn_sched_barrier(0);
         } else {
-          sync_next(sl, wq[(NP + j + 1) & 1]);
-          if (j + 1 < NP) load2(fa[0], slot_of(sl + 1), 0); else load1(fa[0], slot_of(sl + 1), 0);   // (past the end: unused)
+          if (half == 1) sync_next(sl, wq[(NP + j + 1) & 1]);
+          load2(fa[0], slot_of(sl), half);
         }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2)
 #pragma unroll
@@ -364,11 +380,11 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void ffn_fwd_kernel(const FfnDev p)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               const int dt = 8 * j + 4 * half + d4;
-              const frag a = fa[half][ks2 * 4 + d4];
+              const frag a = fa[FA2 ? half : 0][ks2 * 4 + d4];
               if (ABL & 4) { asm volatile("" :: "v"(a), "v"(hf[mt][ks2])); yacc[dt][mt][0] += 1.f; }
               else yacc[dt][mt] = MM::mma(a, hf[mt][ks2], yacc[dt][mt]);
             }
-        __builtin_amdgcn_sched_barrier(0);
+        if (FA2) __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -434,36 +450,41 @@ extern "C" int m3_ffn_fwd(const m3_ffn_args *a, void *stream) {
   d.M = a->M; d.H = a->H; d.G = a->G;
   d.group_offsets = a->group_offsets;
   hipStream_t s = (hipStream_t)stream;
-  const int mt = a->D == 384 ? 2 : 1;
-  const int rows = 64 * mt;
+  // geometry: D = 384: 128-row tiles, as 8 waves x 16 rows (two waves per SIMD; default) or 4 waves x 32 rows
+  // (M3_FFN_WAVES=4); D = 768: 64-row tiles of 4 waves x 16 rows
+  static int nw_env = -1, abl = -1;
+  if (nw_env < 0) { const char *e = getenv("M3_FFN_WAVES"); nw_env = e ? atoi(e) : 8; }
+  if (abl < 0) { const char *e = getenv("M3_FFN_ABL"); abl = e ? atoi(e) : 0; }
+  const int nw = (a->D == 384 && nw_env != 4) ? 8 : 4;
+  const int mt = (a->D == 384 && nw == 4) ? 2 : 1;
+  const int rows = nw * 16 * mt;
   const int64_t tiles = (a->M + rows - 1) / rows + (a->group_offsets ? a->G : 0);
   M3_REQUIRE(tiles < ((int64_t)1 << 30), "m3_ffn_fwd: grid too large");
   const size_t lds = FFN_RING + (size_t)rows * a->D * 2 + (size_t)(a->H + a->D) * 4;
   M3_REQUIRE(lds <= 163840, "m3_ffn_fwd: H too large for the bias image");
-  const dim3 grid((unsigned)tiles), block(FFN_THREADS);
-#define M3_FFN_LAUNCH(DD, MTT, F32, AB)                                                                               \
+  const dim3 grid((unsigned)tiles), block(nw * 64);
+#define M3_FFN_LAUNCH(DD, MTT, NWW, F32, AB)                                                                          \
   do {                                                                                                                \
     static bool attr_set = false;                                                                                     \
     if (!attr_set) {                                                                                                  \
-      (void)hipFuncSetAttribute((const void *)ffn_fwd_kernel<DD, MTT, F32, AB>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+      (void)hipFuncSetAttribute((const void *)ffn_fwd_kernel<DD, MTT, NWW, F32, AB>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
       attr_set = true;                                                                                                \
     }                                                                                                                 \
-    hipLaunchKernelGGL((ffn_fwd_kernel<DD, MTT, F32, AB>), grid, block, lds, s, d);                                   \
+    hipLaunchKernelGGL((ffn_fwd_kernel<DD, MTT, NWW, F32, AB>), grid, block, lds, s, d);                              \
   } while (0)
-  static int abl = -1;
-  if (abl < 0) { const char *e = getenv("M3_FFN_ABL"); abl = e ? atoi(e) : 0; }
-  if (a->D == 384) {
+  if (a->D == 384 && nw == 8) {
 #ifdef M3_FFN_ABLATIONS
-    if (abl == 1 && !d.y_f32) M3_FFN_LAUNCH(384, 2, false, 1);
-    else if (abl == 2 && !d.y_f32) M3_FFN_LAUNCH(384, 2, false, 2);
-    else if (abl == 4 && !d.y_f32) M3_FFN_LAUNCH(384, 2, false, 4);
-    else if (abl == 3 && !d.y_f32) M3_FFN_LAUNCH(384, 2, false, 3);
-    else if (abl == 7 && !d.y_f32) M3_FFN_LAUNCH(384, 2, false, 7);
+    if (abl == 1 && !d.y_f32) M3_FFN_LAUNCH(384, 1, 8, false, 1);
+    else if (abl == 2 && !d.y_f32) M3_FFN_LAUNCH(384, 1, 8, false, 2);
+    else if (abl == 4 && !d.y_f32) M3_FFN_LAUNCH(384, 1, 8, false, 4);
+    else if (abl == 7 && !d.y_f32) M3_FFN_LAUNCH(384, 1, 8, false, 7);
     else
 #endif
-    if (d.y_f32) M3_FFN_LAUNCH(384, 2, true, 0); else M3_FFN_LAUNCH(384, 2, false, 0);
+    if (d.y_f32) M3_FFN_LAUNCH(384, 1, 8, true, 0); else M3_FFN_LAUNCH(384, 1, 8, false, 0);
+  } else if (a->D == 384) {
+    if (d.y_f32) M3_FFN_LAUNCH(384, 2, 4, true, 0); else M3_FFN_LAUNCH(384, 2, 4, false, 0);
   } else {
-    if (d.y_f32) M3_FFN_LAUNCH(768, 1, true, 0); else M3_FFN_LAUNCH(768, 1, false, 0);
+    if (d.y_f32) M3_FFN_LAUNCH(768, 1, 4, true, 0); else M3_FFN_LAUNCH(768, 1, 4, false, 0);
   }
 #undef M3_FFN_LAUNCH
   return check_launch("m3_ffn_fwd");

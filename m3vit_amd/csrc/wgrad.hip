@@ -22,7 +22,7 @@
 namespace m3 {
 
 constexpr int WG_T = 128;        // tile edge (n and k)
-constexpr int WG_ROWS = 32;      // contraction rows per step
+constexpr int WG_ROWS = 64;      // granule of the row splits (= the largest per-dtype step below)
 constexpr int WG_THREADS = 256;
 
 struct WgradDev {
@@ -75,8 +75,14 @@ __device__ __forceinline__ bool wgrad_unit(const int32_t *off, int G, int chunk,
 }
 
 template <typename T> struct WgLds;
-template <> struct WgLds<half_t> { static constexpr int STRIDE = 288; };
-template <> struct WgLds<float> { static constexpr int STRIDE = 528; };
+// ROWS: contraction rows per barrier step.  (fp16 with 64 rows - 32 MFMAs per wave per barrier instead of 16 - was
+// built in round 2: the second pair of staging registers spills, 256 VGPRs + 172 B scratch, and the step got 1-2 %
+// slower; -DM3_WGRAD_F16_ROWS=64 rebuilds it.)
+#ifndef M3_WGRAD_F16_ROWS
+#define M3_WGRAD_F16_ROWS 32
+#endif
+template <> struct WgLds<half_t> { static constexpr int STRIDE = 288; static constexpr int ROWS = M3_WGRAD_F16_ROWS; };
+template <> struct WgLds<float> { static constexpr int STRIDE = 528; static constexpr int ROWS = 32; };
 
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
@@ -116,11 +122,12 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
   constexpr int ES = (int)sizeof(T);
   constexpr int EPC = 16 / ES;
   constexpr int STRIDE = WgLds<T>::STRIDE;
+  constexpr int ROWS = WgLds<T>::ROWS;                      // contraction rows per step
   constexpr int CPR = WG_T * ES / 16;                       // 16-byte chunks per tile row
-  constexpr int NLD = WG_ROWS * CPR / WG_THREADS;           // chunks per thread per operand
+  constexpr int NLD = ROWS * CPR / WG_THREADS;           // chunks per thread per operand
   constexpr int RSTEP = WG_THREADS / CPR;                   // tile rows between a thread's chunks
-  constexpr int OPB = WG_ROWS * STRIDE;                     // bytes per operand image
-  constexpr int KCH = WG_ROWS / MM::KC;                     // fragment chunks per step
+  constexpr int OPB = ROWS * STRIDE;                     // bytes per operand image
+  constexpr int KCH = ROWS / MM::KC;                     // fragment chunks per step
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -139,14 +146,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
   if (p.chunk_rows) {                          // gs = work unit; its slab is ws[gs]
     if (!wgrad_unit(p.group_offsets, p.G, p.chunk_rows, lin, tiles, lane, tile, gs, g, r0, r1)) return;
     sp = gs; s_begin = 0;
-    nst = (int)((r1 - r0 + WG_ROWS - 1) / WG_ROWS);
+    nst = (int)((r1 - r0 + ROWS - 1) / ROWS);
   } else {
     const int log_id = xcd_remap(lin, tiles * gridDim.y * gridDim.z);
     tile = log_id % tiles; gs = log_id / tiles;
     g = gs % (int)gridDim.y; sp = gs / (int)gridDim.y;
     if (p.group_offsets) { r0 = p.group_offsets[g]; r1 = p.group_offsets[g + 1]; }
     else { r0 = 0; r1 = p.M; }
-    const int64_t nsteps_all = (r1 - r0 + WG_ROWS - 1) / WG_ROWS;
+    const int64_t nsteps_all = (r1 - r0 + ROWS - 1) / ROWS;
     const int64_t per = (nsteps_all + p.splits - 1) / p.splits;
     s_begin = (int64_t)sp * per;
     int64_t s_end = s_begin + per;
@@ -175,10 +182,10 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
   const char *c_base = p.dC + (int64_t)ncol * ES;
   const char *a_base = p.A + (int64_t)kcol * ES;
   const int st_off = srow * STRIDE + c * 16;                // + i*RSTEP*STRIDE
-  const int64_t rbase = r0 + s_begin * WG_ROWS + srow;      // row of chunk 0 in local step 0
+  const int64_t rbase = r0 + s_begin * ROWS + srow;      // row of chunk 0 in local step 0
 
   auto row_of = [&](int step, int i) -> int64_t {           // clamped slot row
-    int64_t m = rbase + (int64_t)step * WG_ROWS + i * RSTEP;
+    int64_t m = rbase + (int64_t)step * ROWS + i * RSTEP;
     return m < r1 ? m : r1 - 1;
   };
   auto load_index = [&](int step, int32_t(&ic)[NLD], int32_t(&ia)[NLD]) {
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
     char *base = smem + buf * (2 * OPB) + st_off;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const bool ok = rbase + (int64_t)step * WG_ROWS + i * RSTEP < r1;
+      const bool ok = rbase + (int64_t)step * ROWS + i * RSTEP < r1;
       *(u32x4 *)(base + i * RSTEP * STRIDE) = ok ? rc[i] : u32x4{0u, 0u, 0u, 0u};
       *(u32x4 *)(base + i * RSTEP * STRIDE + OPB) = ok ? ra[i] : u32x4{0u, 0u, 0u, 0u};
     }
@@ -428,7 +435,7 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   M3_REQUIRE(a->N * es >= 16 && a->K * es >= 16, "m3_wgrad_tn: N, K too small");
   const bool gc = a->c_row_idx != nullptr, ga = a->a_row_idx != nullptr;
-  const size_t lds16 = 4 * WG_ROWS * WgLds<half_t>::STRIDE, lds32 = 4 * WG_ROWS * WgLds<float>::STRIDE;
+  const size_t lds16 = 4 * WgLds<half_t>::ROWS * WgLds<half_t>::STRIDE, lds32 = 4 * WgLds<float>::ROWS * WgLds<float>::STRIDE;
 #define M3_WG(TT, LDS)                                                                               \
   do {                                                                                               \
     if (gc && ga) hipLaunchKernelGGL((wgrad_tn_kernel<TT, true, true>), grid, block, LDS, s, d);     \
@@ -436,19 +443,20 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
     else if (ga) hipLaunchKernelGGL((wgrad_tn_kernel<TT, false, true>), grid, block, LDS, s, d);     \
     else hipLaunchKernelGGL((wgrad_tn_kernel<TT, false, false>), grid, block, LDS, s, d);            \
   } while (0)
-  if (a->dtype == M3_F16) {
-    M3_WG(half_t, lds16);
-  } else {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<float, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
-      (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<float, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
-      (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<float, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
-      (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<float, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
-      attr_set = true;
-    }
-    M3_WG(float, lds32);
+  static bool attr_set = false;
+  if (!attr_set) {                               // both images exceed the 64 KiB a launch gets without asking
+    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<float, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
+    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<float, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
+    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<float, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
+    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<float, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
+    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<half_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<half_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<half_t, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<half_t, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+    attr_set = true;
   }
+  if (a->dtype == M3_F16) M3_WG(half_t, lds16);
+  else M3_WG(float, lds32);
 #undef M3_WG
   return check_launch("m3_wgrad_tn");
 }

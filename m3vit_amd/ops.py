@@ -330,7 +330,7 @@ def wgrad_plan(M, G, splits, grouped):
     is the average number of units per group and the chunk sits 1/8 above the mean part, so that groups near the mean keep
     `splits` units.  chunk 0: every group in `splits` equal parts."""
     if grouped and 1 < G <= 64 and M > 0:
-        chunk = max(32, (-(-M * 9 // (8 * splits * G)) + 31) // 32 * 32)
+        chunk = max(64, (-(-M * 9 // (8 * splits * G)) + 63) // 64 * 64)
         return chunk, M // chunk + G
     return 0, splits * G
 
