@@ -8,7 +8,11 @@ are outside the MoE / attention path this repository hand-writes, and SURVEY pla
 `MultiTaskModel` mirrors the backbone/decoder plumbing of models/models.py:215-342 for the two gate layouts the
 path supports: one backbone pass shared by all heads (single / task-conditioned gate called without a task), or
 one pass per task with that task's gate (multi-gate, :299-320), every head output resized to the input size.
-TAM feature aggregation, multi-level outputs and the sem regulariser are out of scope."""
+Also mirrored, as plain torch modules behind the path (convolutions = MIOpen): the heads' multi-level outputs
+(`output_level_0..2`, vit_up_head.py:128-131,184-214), their three TAM feature taps (:190-206) and `TamModule`
+(models/models.py:11-134: a sigmoid gate B from the stacked task features, a 2x down / 2x up modulation M, one
+3x3 + 1x1 head per task on cat_t(feature_t * (1 + M))), wired into `MultiTaskModel` as `tam_level0/1/2` (:246-279).
+The sem regulariser is out of scope."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -19,8 +23,9 @@ from .functional import LayerNormFn
 class VisionTransformerUpHead(nn.Module):
     def __init__(self, img_size=(480, 640), patch_size=16, embed_dim=384, num_classes=40, num_conv=4,
                  num_upsampe_layer=4, conv3x3_conv1x1=True, align_corners=False, sync_bn=False,
-                 act_dtype=torch.float32, channels=256):
+                 act_dtype=torch.float32, channels=256, multi_level=False, tam=False):
         super().__init__()
+        self.multi_level, self.tam = bool(multi_level), bool(tam)       # p['multi_level'], p['model_kwargs']['tam'] (:96-105)
         if (num_conv, num_upsampe_layer) not in ((4, 4), (2, 2), (2, 1)):
             raise NotImplementedError("supported stacks: num_conv / num_upsampe_layer = 4/4, 2/2, 2/1")
         self.img_size = tuple(img_size) if isinstance(img_size, (tuple, list)) else (img_size, img_size)
@@ -42,6 +47,9 @@ class VisionTransformerUpHead(nn.Module):
             self.conv_4 = nn.Conv2d(channels, num_classes, 1, 1)
             for i in range(4):
                 setattr(self, f"syncbn_fc_{i}", bn(channels))
+        if self.multi_level:                                           # :128-131
+            for i in range(3):
+                setattr(self, f"output_level_{i}", nn.Conv2d(channels, num_classes, 1, 1))
 
     def _up(self, x, factor=None, size=None):
         if size is None:
@@ -61,38 +69,114 @@ class VisionTransformerUpHead(nn.Module):
             if self.num_upsampe_layer == 2:
                 x = self._up(x, size=x.shape[-1] * 4)          # :171 (square size, as the reference writes it)
             return self._up(self.conv_1(x), size=self.img_size)
+        out, taps = {}, []
         for i in range(4):
             x = F.relu(getattr(self, f"syncbn_fc_{i}")(getattr(self, f"conv_{i}")(x)))
+            if i >= 1:
+                taps.append(x)                                           # tam_feature0..2: after conv_1..3 (:190-206)
             if i < 3:
                 x = self._up(x, 2)
-        return self._up(self.conv_4(x), 2)
+                if self.multi_level:
+                    out[f"level{i + 1}"] = getattr(self, f"output_level_{i}")(x)     # :184-200
+        x = self._up(self.conv_4(x), 2)
+        if self.multi_level:
+            out["final"] = x
+            return out
+        if self.tam and self.training:
+            return x, taps[0], taps[1], taps[2]
+        return x
+
+
+class TamModule(nn.Module):
+    """models/models.py:11-134 with the reference's module names (layers0..2, encoder0/1, decoder0/1, layers3/4[task]).
+    norm: the layer build_norm_layer(norm_cfg) would give (BatchNorm2d / SyncBatchNorm).  The reference's activation
+    checkpointing around the blocks changes memory only."""
+
+    def __init__(self, tasks, input_channels, num_output, norm=nn.BatchNorm2d):
+        super().__init__()
+        self.tasks = list(tasks)
+        if not 2 <= len(self.tasks) <= 5:
+            raise ValueError("TamModule is defined for 2..5 tasks (models/models.py:87-95)")
+        nt, c = len(self.tasks), input_channels
+        self.layers0 = nn.Sequential(nn.Conv2d(nt * c, c, 3, 1, 1), norm(c))
+        self.layers1 = nn.Sequential(nn.Conv2d(c, c, 3, 1, 1), norm(c))
+        self.layers2 = nn.Sequential(nn.Conv2d(nt * c, c, 3, 1, 1), norm(c))
+        self.encoder0 = nn.Sequential(nn.Conv2d(c, c, 3, 2, 1), norm(c))
+        self.encoder1 = nn.Sequential(nn.Conv2d(c, c, 3, 2, 1), norm(c))
+        self.decoder0 = nn.Sequential(nn.ConvTranspose2d(c, c, 3, 2, 1, output_padding=1), norm(c))
+        self.decoder1 = nn.Sequential(nn.ConvTranspose2d(c, c, 3, 2, 1, output_padding=1), norm(c))
+        self.layers3 = nn.ModuleDict({t: nn.Sequential(nn.Conv2d(nt * c, 256, 3, 1, 1), norm(256)) for t in self.tasks})
+        self.layers4 = nn.ModuleDict({t: nn.Sequential(nn.Conv2d(256, num_output[t], 1, 1)) for t in self.tasks})
+
+    @staticmethod
+    def gate_weights(n_tasks, B):
+        """the per-task factors of the gated concat (:87-95): B and 1 - B shared out over the first / last tasks"""
+        return {2: [B, 1 - B], 3: [B, (1 - B) / 2, (1 - B) / 2], 4: [B / 2, B / 2, (1 - B) / 2, (1 - B) / 2],
+                5: [B / 2, B / 2, (1 - B) / 3, (1 - B) / 3, (1 - B) / 3]}[n_tasks]
+
+    def forward(self, deepfeature):
+        feats = [deepfeature[t] for t in self.tasks]
+        batch, c, H, W = feats[0].shape
+        stacked = torch.stack(feats, dim=1).reshape(batch, len(feats) * c, H, W)
+        B = torch.sigmoid(self.layers1(F.relu(self.layers0(stacked))))                       # _block0
+        Fb = torch.cat([f * w for f, w in zip(feats, self.gate_weights(len(feats), B))], dim=1)
+        Fb = F.relu(self.layers2(Fb))                                                        # _block2
+        Fb = F.relu(self.encoder1(F.relu(self.encoder0(Fb))))                                # _encoder_block
+        M = torch.sigmoid(self.decoder1(F.relu(self.decoder0(Fb))))                          # _decoder_block
+        Ftam = torch.cat([f * (1 + M) for f in feats], dim=1)
+        return {t: self.layers4[t](F.relu(self.layers3[t](Ftam))) for t in self.tasks}
 
 
 class MultiTaskModel(nn.Module):
-    """backbone(x[, task_id]) -> (tokens, cv_loss); decoders: {task: head}; tasks_id: {task: gate index}."""
+    """backbone(x[, task_id]) -> (tokens, cv_loss); decoders: {task: head}; tasks_id: {task: gate index}.
+    tam_models: {0 / 1 / 2: TamModule} for the heads' feature taps (the reference's tam_level0/1/2, training only):
+    their per-task outputs are added to the result as 'tam_level{l}_{task}' (models/models.py:246-279,313-327)."""
 
-    def __init__(self, backbone: nn.Module, decoders: nn.ModuleDict, tasks, multi_gate: bool = False):
+    def __init__(self, backbone: nn.Module, decoders: nn.ModuleDict, tasks, multi_gate: bool = False, tam_models=None):
         super().__init__()
         assert set(decoders.keys()) == set(tasks)
         self.backbone, self.decoders = backbone, decoders
         self.tasks = list(tasks)
         self.tasks_id = {t: i for i, t in enumerate(self.tasks)}          # models/models.py ctor: enumerate(tasks)
         self.multi_gate = multi_gate
+        self.tam = bool(tam_models)
+        self.tam_models = nn.ModuleDict({str(k): m for k, m in (tam_models or {}).items()})
 
-    def _head(self, task, tokens, out_size):
-        return F.interpolate(self.decoders[task](tokens), out_size, mode="bilinear")
+    def _head(self, task, tokens, out_size, feats=None):
+        y = self.decoders[task](tokens)
+        if self.tam and self.training:                                    # head returns (out, tap0, tap1, tap2)
+            y, *taps = y
+            for lvl in self.tam_models:
+                feats[lvl][task] = taps[int(lvl)]
+        return F.interpolate(y, out_size, mode="bilinear")
+
+    def _tam_outputs(self, out, feats, out_size):
+        for lvl, model in self.tam_models.items():
+            y = model(feats[lvl])
+            for t in self.tasks:
+                out[f"tam_level{lvl}_{t}"] = F.interpolate(y[t], out_size, mode="bilinear", align_corners=False)
 
     def forward(self, x, single_task=None, task_id=None):
         if task_id is not None:
             assert self.tasks_id[single_task] == task_id                  # :216-217
         out_size = x.shape[2:]
+        use_tam = self.tam and self.training
+        feats = {lvl: {} for lvl in self.tam_models} if use_tam else None
         if not self.multi_gate:
             tokens, cv = self.backbone(x) if task_id is None else self.backbone(x, task_id=task_id)
-            names = [single_task] if single_task is not None else self.tasks
-            return {t: self._head(t, tokens, out_size) for t in names}, cv
+            if single_task is not None:                                   # :251-256 (no TAM on the single-task call)
+                y = self.decoders[single_task](tokens)
+                y = y[0] if isinstance(y, tuple) else y
+                return {single_task: F.interpolate(y, out_size, mode="bilinear")}, cv
+            out = {t: self._head(t, tokens, out_size, feats) for t in self.tasks}
+            if use_tam:
+                self._tam_outputs(out, feats, out_size)
+            return out, cv
         out, total = {}, None
         for t in self.tasks:                                              # :299-320: one pass per task's gate
             tokens, cv = self.backbone(x, task_id=self.tasks_id[t])
             total = cv if total is None else total + cv
-            out[t] = self._head(t, tokens, out_size)
+            out[t] = self._head(t, tokens, out_size, feats)
+        if use_tam:
+            self._tam_outputs(out, feats, out_size)
         return out, total

@@ -487,3 +487,69 @@ def test_origin_convention_matches_ckpt_convention(std):
     b.eval()
     b(img, task_id=0)
     assert float(collect_noisy_gating_loss(b, 1.0)) == 0.0
+
+
+def test_head_multi_level_outputs_and_tam_wiring():
+    """vit_up_head.py:128-131,184-214 (multi_level: a 1x1 classifier after every upsampling) and :190-206 + models/models.py:
+    246-279,313-327 (tam: the heads hand their three intermediate features to one TamModule per level, whose per-task
+    outputs are added as 'tam_level{l}_{task}', training only) against a functional transcription of those lines."""
+    _need_gpu()
+    import torch.nn.functional as F
+    from m3vit_amd.heads import MultiTaskModel, TamModule, VisionTransformerUpHead
+    from m3vit_amd.vit import VisionTransformerMoE
+    torch.manual_seed(11)
+    tok = torch.randn(2, 1 + 6, 64, device="cuda")                       # cls + 2 x 3 patches
+
+    def stack(h, x, stop=4):
+        """conv / BN / ReLU / x2 stages of the 4-conv head (:181-214) in plain functional ops; returns per-stage tensors"""
+        z = F.layer_norm(x[:, 1:], (64,), h.norm.weight, h.norm.bias, 1e-6).transpose(1, 2).reshape(2, 64, 2, 3)
+        post_relu, post_up = [], []
+        for i in range(4):
+            conv, bn = getattr(h, f"conv_{i}"), getattr(h, f"syncbn_fc_{i}")
+            z = F.conv2d(z, conv.weight, conv.bias, padding=1)
+            z = F.relu(F.batch_norm(z, bn.running_mean, bn.running_var, bn.weight, bn.bias, training=False, eps=bn.eps))
+            post_relu.append(z)
+            if i < 3:
+                z = F.interpolate(z, scale_factor=2, mode="bilinear", align_corners=False)
+                post_up.append(z)
+        final = F.interpolate(F.conv2d(z, h.conv_4.weight, h.conv_4.bias), scale_factor=2, mode="bilinear", align_corners=False)
+        return post_relu, post_up, final
+
+    ml = VisionTransformerUpHead((32, 48), 16, 64, num_classes=5, multi_level=True).cuda().eval()
+    assert {"output_level_0.weight", "output_level_2.bias"} <= set(ml.state_dict())
+    out = ml(tok)
+    assert list(out) == ["level1", "level2", "level3", "final"]
+    _, post_up, final = stack(ml, tok)
+    for i in range(3):
+        lv = getattr(ml, f"output_level_{i}")
+        assert rel(out[f"level{i + 1}"], F.conv2d(post_up[i], lv.weight, lv.bias)) < 1e-5
+    assert rel(out["final"], final) < 1e-5 and out["final"].shape == (2, 5, 32, 48)
+
+    # TAM: eval BN statistics inside the heads (so the transcription can use running stats), wrapper in training mode
+    kw = dict(img_size=(32, 48), embed_dim=64, depth=2, num_heads=2, moe_experts=4, moe_top_k=2, gate_dim=66, multi_gate=True)
+    bb = VisionTransformerMoE(mlp_ratio=4.0, moe_mlp_ratio=1, vmoe_noisy_std=0, **kw)
+    tasks = ["semseg", "depth"]
+    nout = {"semseg": 5, "depth": 1}
+    heads = torch.nn.ModuleDict({t: VisionTransformerUpHead((32, 48), 16, 64, num_classes=nout[t], tam=True) for t in tasks})
+    tams = {0: TamModule(tasks, 256, nout), 2: TamModule(tasks, 256, nout)}
+    m = MultiTaskModel(bb, heads, tasks, multi_gate=True, tam_models=tams).cuda()
+    m.train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.eval()
+    x = torch.randn(2, 3, 32, 48, device="cuda")
+    out, cv = m(x)
+    assert set(out) == {"semseg", "depth", "tam_level0_semseg", "tam_level0_depth", "tam_level2_semseg", "tam_level2_depth"}
+    feats = {0: {}, 2: {}}
+    for i, t in enumerate(tasks):
+        tokens, _ = bb(x, task_id=i)
+        post_relu, _, final = stack(heads[t], tokens.float())
+        feats[0][t], feats[2][t] = post_relu[1], post_relu[3]            # tam_feature0 / 2: after conv_1 / conv_3
+        assert rel(out[t], F.interpolate(final, (32, 48), mode="bilinear")) < 1e-4
+    for lvl in (0, 2):
+        y = tams[lvl](feats[lvl])
+        for t in tasks:
+            assert rel(out[f"tam_level{lvl}_{t}"], F.interpolate(y[t], (32, 48), mode="bilinear", align_corners=False)) < 1e-4
+    m.eval()                                                             # inference: no TAM outputs, heads return tensors
+    out_e, _ = m(x)
+    assert set(out_e) == set(tasks)
