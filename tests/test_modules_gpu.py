@@ -531,7 +531,8 @@ def test_head_multi_level_outputs_and_tam_wiring():
     tasks = ["semseg", "depth"]
     nout = {"semseg": 5, "depth": 1}
     heads = torch.nn.ModuleDict({t: VisionTransformerUpHead((32, 48), 16, 64, num_classes=nout[t], tam=True) for t in tasks})
-    tams = {0: TamModule(tasks, 256, nout), 2: TamModule(tasks, 256, nout)}
+    # (the 2x-down / 2x-up modulation path needs feature maps divisible by 4: levels 1 and 2 are 8 x 12 and 16 x 24 here)
+    tams = {1: TamModule(tasks, 256, nout), 2: TamModule(tasks, 256, nout)}
     m = MultiTaskModel(bb, heads, tasks, multi_gate=True, tam_models=tams).cuda()
     m.train()
     for mod in m.modules():
@@ -539,14 +540,14 @@ def test_head_multi_level_outputs_and_tam_wiring():
             mod.eval()
     x = torch.randn(2, 3, 32, 48, device="cuda")
     out, cv = m(x)
-    assert set(out) == {"semseg", "depth", "tam_level0_semseg", "tam_level0_depth", "tam_level2_semseg", "tam_level2_depth"}
-    feats = {0: {}, 2: {}}
+    assert set(out) == {"semseg", "depth", "tam_level1_semseg", "tam_level1_depth", "tam_level2_semseg", "tam_level2_depth"}
+    feats = {1: {}, 2: {}}
     for i, t in enumerate(tasks):
         tokens, _ = bb(x, task_id=i)
         post_relu, _, final = stack(heads[t], tokens.float())
-        feats[0][t], feats[2][t] = post_relu[1], post_relu[3]            # tam_feature0 / 2: after conv_1 / conv_3
+        feats[1][t], feats[2][t] = post_relu[2], post_relu[3]            # tam_feature1 / 2: after conv_2 / conv_3
         assert rel(out[t], F.interpolate(final, (32, 48), mode="bilinear")) < 1e-4
-    for lvl in (0, 2):
+    for lvl in (1, 2):
         y = tams[lvl](feats[lvl])
         for t in tasks:
             assert rel(out[f"tam_level{lvl}_{t}"], F.interpolate(y[t], (32, 48), mode="bilinear", align_corners=False)) < 1e-4
