@@ -40,6 +40,7 @@ ap.add_argument("fetch_db")
 ap.add_argument("write_db")
 ap.add_argument("--dtype", default="f16")
 ap.add_argument("--note", default="")
+ap.add_argument("--head", default="", help="commit the passes were taken at (bench.py prints it in roofline.traffic_source)")
 ap.add_argument("--merge", action="append", default=[], help="NEW=a,b : launch-weighted average of kernels a and b")
 a = ap.parse_args()
 fe, wr = per_kernel(a.fetch_db, "FETCH_SIZE"), per_kernel(a.write_db, "WRITE_SIZE")
@@ -69,4 +70,4 @@ for spec in a.merge:
 print(json.dumps({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only); counter unit KB; "
                           "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads; other "
                           "widths uncalibrated); Infinity-Cache hits are included. " + a.note,
-                  "dtype": a.dtype, "kernels": kernels}, indent=1))
+                  "dtype": a.dtype, "head": a.head, "kernels": kernels}, indent=1))
