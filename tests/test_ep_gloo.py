@@ -104,6 +104,23 @@ def _dgdp_worker(rank, world, port, q):
         assert torch.allclose(m["dense"].weight.grad, torch.full_like(m["dense"].weight, 1.5))   # mean of 1, 2
         assert torch.allclose(m["experts"].weight.grad, torch.full_like(m["experts"].weight, float(rank + 1)))  # untouched
         assert list(w.state_dict().keys())[0].startswith("module.")
+        # the dense gradients now alias ONE flat buffer: a second step that accumulates in place (as autograd does
+        # into an existing .grad) needs no gather / scatter passes ...
+        flat = w._flat[("dp", torch.float32, m["dense"].weight.device)][1]
+        assert m["dense"].weight.grad.data_ptr() == flat.data_ptr() and flat.numel() == 4 * 3 + 3
+        ptr = m["dense"].weight.grad.data_ptr()
+        for p in m["dense"].parameters():
+            p.grad.zero_(); p.grad.add_(float(2 * rank + 1))                 # 1 on rank 0, 3 on rank 1
+        w.allreduce_params()
+        assert m["dense"].weight.grad.data_ptr() == ptr and torch.allclose(m["dense"].bias.grad, torch.full((3,), 2.0))
+        # ... and a .grad the trainer re-created (zero_grad(set_to_none=True) + backward) is taken back into the buffer
+        x = torch.ones(2, 4) * (rank + 1)
+        for p in m["dense"].parameters():
+            p.grad = None
+        m["dense"](x).sum().backward()
+        w.allreduce_params()
+        assert m["dense"].weight.grad.data_ptr() == ptr
+        assert torch.allclose(m["dense"].weight.grad, torch.full((3, 4), 3.0))    # mean of 2 rows x (1 | 2) = (2 + 4) / 2
         q.put((rank, "ok"))
     except Exception:                                # pragma: no cover
         import traceback
