@@ -175,6 +175,12 @@ typedef struct {
   int32_t row_scale_div;
 } m3_gemm_args;
 int m3_gemm_nt(const m3_gemm_args *args, void *stream);
+/* Tuning knob, no reference counterpart: which calls of m3_gemm_nt may take the weight-stationary persistent kernel
+ * (fp16, K = 384, N % 128 == 0, M >= 1024; csrc/gemm.hip).  ws_mask bits: 0 plain epilogue, 1 GELU + pre-activation
+ * output, 2 GELU'(pre) multiply, 3 fp32 residual, 4 grouped calls as well.  Default 0 (the tiled kernels take every
+ * call: measured faster inside the training step); -1 re-reads M3_GEMM_WS from the environment.  Results are the same
+ * up to fp32 summation order either way. */
+int m3_gemm_set_variant(int ws_mask);
 
 /* Fused FFN forward (fp16 activations):
  *   Y[crow(m), :] = (residual[crow(m), :] +) GELU(X[arow(m), :] W1[g]^T + b1[g]) W2[g]^T + b2[g]

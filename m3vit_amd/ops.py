@@ -226,6 +226,11 @@ def gemm_nt(A, B, C, *, M=None, bias=None, act=M3_ACT_NONE, pre_out=None, gelu_g
     return C
 
 
+def gemm_set_variant(ws_mask: int):
+    """which gemm_nt calls may take the weight-stationary kernel (include/m3vit_hip.h: m3_gemm_set_variant); 0 = none"""
+    check(lib().m3_gemm_set_variant(int(ws_mask)), "m3_gemm_set_variant")
+
+
 def ffn_supported(D: int, H: int, dtype: torch.dtype, G: int = 1) -> bool:
     """shapes the fused FFN kernels take (anything else runs the unfused m3_gemm_nt pair)"""
     return dtype == torch.float16 and D in (384, 768) and H % 64 == 0 and 64 <= H <= 8192 and G <= 64 and \

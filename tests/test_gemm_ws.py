@@ -1,0 +1,168 @@
+"""GPU: the weight-stationary, wave-specialised persistent GEMM (gemm_nt_ws_kernel in csrc/gemm.hip: fp16, K = 384,
+N % 128 == 0, M >= 1024 - qkv, proj, fc1, the expert FC1 and the GELU'-fused input-gradient GEMMs at the BASELINE sizes;
+opt-in through m3_gemm_set_variant) against torch fp64 on the same fp16-rounded operands: its four epilogues (bias,
+GELU + pre-activation output, GELU' of a stored pre-activation, fp32 residual in / out), expert gather with ragged and
+empty groups, partial last tiles, runs that cross column-tile and expert boundaries - and the argument combinations it
+hands back to the tiled kernels (DropPath row factor, token-major scatter, fp32 output without residual)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from m3vit_amd import ops as _ops
+    _ops.gemm_set_variant(31)         # the kernel is opt-in: all four epilogues + grouped calls for this module
+    yield _ops
+    _ops.gemm_set_variant(0)
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a = a.double().flatten().cpu(); b = b.double().flatten().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=torch.float16):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def gelu64(x):
+    return 0.5 * x * (1 + torch.erf(x / 2 ** 0.5))
+
+
+def gelu_grad64(x):
+    return 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * np.pi) ** 0.5
+
+
+@pytest.mark.parametrize("M,N", [(1024, 384), (1500, 1152), (5000, 1536), (25216, 384), (1100, 128)])
+def test_ws_dense_plain_and_bias(ops, M, N):
+    K = 384
+    A, B, bias = rnd(M, K, seed=1), rnd(N, K, scale=0.05, seed=2), rnd(N, seed=3, dtype=torch.float32)
+    for c_dtype in (torch.float16, torch.float32):
+        C = torch.full((M, N), float("nan"), dtype=c_dtype, device=dev())
+        ops.gemm_nt(A.to(dev()), B.to(dev()), C, bias=bias.to(dev()))
+        ref = A.double() @ B.double().t() + bias.double()
+        assert torch.isfinite(C).all()
+        assert rel(C, ref) < TOL
+
+
+def test_ws_fc1_epilogue_gelu_and_pre(ops):
+    M, N, K = 2100, 1536, 384
+    A, B, bias = rnd(M, K, seed=4), rnd(N, K, scale=0.05, seed=5), rnd(N, scale=0.1, seed=6, dtype=torch.float32)
+    C = torch.empty(M, N, dtype=torch.float16, device=dev())
+    pre = torch.empty(M, N, dtype=torch.float16, device=dev())
+    ops.gemm_nt(A.to(dev()), B.to(dev()), C, bias=bias.to(dev()), act=ops.M3_ACT_GELU, pre_out=pre)
+    p64 = A.double() @ B.double().t() + bias.double()
+    assert rel(pre, p64) < TOL and rel(C, gelu64(p64)) < TOL
+
+
+def test_ws_dgrad_epilogue_gelu_grad_residual_and_row_scale(ops):
+    M, N, K, div = 1970, 384, 384, 197
+    A, B = rnd(M, K, seed=7), rnd(N, K, scale=0.05, seed=8)
+    gp = rnd(M, N, seed=9)
+    res = rnd(M, N, seed=10, dtype=torch.float32)
+    sc = torch.tensor([0.0, 2.0, 1.0, 0.0, 2.0, 2.0, 1.0, 0.5, 0.0, 1.5])
+    C = torch.empty(M, N, dtype=torch.float32, device=dev())
+    ops.gemm_nt(A.to(dev()), B.to(dev()), C, gelu_grad_pre=gp.to(dev()), residual=res.to(dev()), row_scale=sc.to(dev()),
+                row_scale_div=div)
+    ref = (A.double() @ B.double().t()) * gelu_grad64(gp.double())
+    ref = ref * sc.double().repeat_interleave(div)[:, None] + res.double()
+    assert rel(C, ref) < TOL
+
+
+def test_ws_dgrad_epilogue_gelu_grad_only(ops):
+    """d pre = (dy W2) * GELU'(pre): the dense FC2 input-gradient form (N = 1536), partial last tile"""
+    M, N, K = 3001, 1536, 384
+    A, B, gp = rnd(M, K, seed=17), rnd(N, K, scale=0.05, seed=18), rnd(M, N, seed=19)
+    C = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev())
+    ops.gemm_nt(A.to(dev()), B.to(dev()), C, gelu_grad_pre=gp.to(dev()))
+    ref = (A.double() @ B.double().t()) * gelu_grad64(gp.double())
+    assert torch.isfinite(C).all() and rel(C, ref) < TOL
+
+
+def test_ws_proj_epilogue_fp32_residual(ops):
+    """x1 = x + o Wp + b: fp32 residual stream in and out (in place, as the engine calls it, and out of place)"""
+    M, N, K = 2600, 384, 384
+    A, B, bias = rnd(M, K, seed=20), rnd(N, K, scale=0.05, seed=21), rnd(N, scale=0.1, seed=22, dtype=torch.float32)
+    res = rnd(M, N, seed=23, dtype=torch.float32)
+    ref = A.double() @ B.double().t() + bias.double() + res.double()
+    C = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev())
+    ops.gemm_nt(A.to(dev()), B.to(dev()), C, bias=bias.to(dev()), residual=res.to(dev()))
+    assert rel(C, ref) < TOL
+    C2 = res.to(dev()).clone()
+    ops.gemm_nt(A.to(dev()), B.to(dev()), C2, bias=bias.to(dev()), residual=C2)
+    assert rel(C2, ref) < TOL
+
+
+@pytest.mark.parametrize("E,k,T,H", [(16, 4, 1576, 1536), (4, 2, 3000, 384)])
+def test_ws_grouped_dgrad_gather_gelu_grad(ops, E, k, T, H):
+    """expert FC2 input gradient: rows of d y gathered by row_of_slot, per-expert transposed weights, GELU' of the
+    stored hidden pre-activation; ragged groups, an empty expert, runs that cross expert and column boundaries"""
+    D = 384
+    g = torch.Generator().manual_seed(24)
+    dy = rnd(T * k, D, seed=25)
+    choices = torch.tensor([e for e in range(E) if e != 2])
+    idx = torch.stack([choices[torch.randperm(E - 1, generator=g)[:k]] for _ in range(T)])
+    wt = rnd(E, H, D, scale=0.05, seed=26)
+    r = ops.route_build(idx.to(torch.int32).to(dev()), E)
+    R = T * k
+    hp = rnd(R, H, seed=27)
+    out = torch.full((R, H), float("nan"), dtype=torch.float16, device=dev())
+    ops.gemm_nt(dy.to(dev()), wt.to(dev()), out, M=R, gelu_grad_pre=hp.to(dev()), a_row_idx=r.row_of_slot, a_row_div=1,
+                group_offsets=r.offsets, tile_starts=r.tile_starts)
+    ros = r.row_of_slot.cpu().long()
+    off = r.offsets.cpu().tolist()
+    e_of_slot = torch.zeros(R, dtype=torch.long)
+    for e in range(E):
+        e_of_slot[off[e]:off[e + 1]] = e
+    ref = torch.empty(R, H, dtype=torch.float64)
+    for e in range(E):
+        sl = slice(off[e], off[e + 1])
+        ref[sl] = dy.double()[ros[sl]] @ wt.double()[e].t()
+    ref = ref * gelu_grad64(hp.double())
+    assert torch.isfinite(out).all() and rel(out, ref) < TOL
+
+
+@pytest.mark.parametrize("E,k,T", [(16, 4, 1576), (4, 2, 3000), (8, 4, 512)])
+def test_ws_grouped_gather_scatter(ops, E, k, T):
+    """expert FC1 form (gather by row_of_slot / k, bias, GELU, pre) and FC2 form (scatter to token-major) with ragged
+    groups and an EMPTY expert"""
+    D = 384
+    g = torch.Generator().manual_seed(11)
+    x = rnd(T, D, seed=12)
+    choices = torch.tensor([e for e in range(E) if e != 1])
+    idx = torch.stack([choices[torch.randperm(E - 1, generator=g)[:k]] for _ in range(T)])
+    H = 1536 if E == 16 else D                     # the BASELINE experts' hidden width on the 16-expert case
+    w1, b1 = rnd(E, H, D, scale=0.05, seed=13), rnd(E, H, scale=0.1, seed=14, dtype=torch.float32)
+    w2, b2 = rnd(E, D, H, scale=0.05, seed=15), rnd(E, D, scale=0.1, seed=16, dtype=torch.float32)
+    r = ops.route_build(idx.to(torch.int32).to(dev()), E)
+    R = T * k
+    hid = torch.full((R, H), float("nan"), dtype=torch.float16, device=dev())
+    pre = torch.full((R, H), float("nan"), dtype=torch.float16, device=dev())
+    ops.gemm_nt(x.to(dev()), w1.to(dev()), hid, M=R, bias=b1.to(dev()), act=ops.M3_ACT_GELU, pre_out=pre,
+                a_row_idx=r.row_of_slot, a_row_div=k, group_offsets=r.offsets, tile_starts=r.tile_starts)
+    y = torch.full((R, D), float("nan"), dtype=torch.float16, device=dev())
+    ops.gemm_nt(hid, w2.to(dev()), y, M=R, bias=b2.to(dev()), c_row_idx=r.row_of_slot, group_offsets=r.offsets,
+                tile_starts=r.tile_starts)
+    ros = r.row_of_slot.cpu().long()
+    off = r.offsets.cpu().tolist()
+    e_of_slot = torch.zeros(R, dtype=torch.long)
+    for e in range(E):
+        e_of_slot[off[e]:off[e + 1]] = e
+    xs = x.double()[ros // k]
+    p64 = torch.einsum("rd,rhd->rh", xs, w1.double()[e_of_slot]) + b1.double()[e_of_slot]
+    assert rel(pre, p64) < TOL and rel(hid, gelu64(p64)) < TOL
+    y64 = torch.einsum("rh,rdh->rd", hid.double().cpu(), w2.double()[e_of_slot]) + b2.double()[e_of_slot]
+    want = torch.empty(R, D, dtype=torch.float64)
+    want[ros] = y64
+    assert torch.isfinite(y).all() and rel(y, want) < TOL

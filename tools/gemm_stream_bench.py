@@ -35,15 +35,17 @@ def timeit(fn):
 
 
 for name, N, K, two_out in (("qkv", 1152, 384, False), ("proj", 384, 384, False), ("fc1+gelu+pre", 1536, 384, True),
-                            ("fc2", 384, 1536, False)):
+                            ("dpre (gelu')", 1536, 384, "gpre"), ("fc2", 384, 1536, False)):
     if a.only and name != a.only:
         continue
     As = [torch.randn(M, K, device=dev).half() for _ in range(a.ring)]
     B = (torch.randn(N, K, device=dev) * 0.05).half()
     Cs = [torch.empty(M, N, dtype=torch.float16, device=dev) for _ in range(a.ring)]
-    Ps = [torch.empty(M, N, dtype=torch.float16, device=dev) for _ in range(a.ring)] if two_out else None
+    Ps = [torch.randn(M, N, device=dev).half() for _ in range(a.ring)] if two_out else None
     bias = torch.zeros(N, device=dev)
-    if two_out:
+    if two_out == "gpre":           # d pre = (d y W2) * GELU'(pre): reads a second [M, N] fp16 operand instead of writing one
+        fn = lambda i: ops.gemm_nt(As[i % a.ring], B, Cs[i % a.ring], gelu_grad_pre=Ps[i % a.ring])  # noqa: E731
+    elif two_out:
         fn = lambda i: ops.gemm_nt(As[i % a.ring], B, Cs[i % a.ring], bias=bias, act=ops.M3_ACT_GELU, pre_out=Ps[i % a.ring])  # noqa: E731
     else:
         fn = lambda i: ops.gemm_nt(As[i % a.ring], B, Cs[i % a.ring])  # noqa: E731
