@@ -238,6 +238,15 @@ typedef struct {
                                       (M / chunk_rows + G always suffices) */
 } m3_wgrad_args;
 int m3_wgrad_tn(const m3_wgrad_args *args, void *stream);
+/* The output tile (n x k) m3_wgrad_tn uses for a shape - 128 x 128, or, with the wide tiles switched on, for fp16
+ * 128 x 384 (K = 384, N >= 768 a multiple of 128) / 384 x 128 (N = 384, K >= 768 a multiple of 128) with one
+ * 512-thread workgroup per CU.  Callers that pick `splits` / `units` themselves size them (and the slab workspace
+ * splits * G * N * K) for ceil(N / tn) * ceil(K / tk) tiles per group.
+ * m3_wgrad_set_wide: tuning knob, no reference counterpart: 1 = wide tiles where they apply, 0 = 128 x 128 everywhere
+ * (default: measured no faster inside the training step), -1 = re-read M3_WGRAD_WIDE from the environment.  Switch it
+ * before sizing any workspace. */
+int m3_wgrad_set_wide(int on);
+int m3_wgrad_tile(int N, int K, int dtype, int *tn, int *tk);
 /* balanced mode: dW[g] (+)= sum over group g's units of ws[u] (elems = N*K per group), unit order; optionally the
  * same for the bias slabs (bias_elems = N per group) */
 int m3_wgrad_reduce_grouped(const float *ws, const int32_t *group_offsets, int G, int chunk_rows, int64_t elems,

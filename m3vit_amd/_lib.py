@@ -121,6 +121,8 @@ SIGNATURES = {
     "m3_gemm_set_variant": (c_int, [_I]),
     "m3_ffn_fwd": (c_int, [POINTER(FfnArgs), _V]),
     "m3_wgrad_tn": (c_int, [POINTER(WgradArgs), _V]),
+    "m3_wgrad_tile": (c_int, [_I, _I, _I, POINTER(c_int), POINTER(c_int)]),
+    "m3_wgrad_set_wide": (c_int, [_I]),
     "m3_wgrad_reduce": (c_int, [_V, _I, _L, _V, _I, _V, _L, _V, _I, _V]),
     "m3_wgrad_reduce_grouped": (c_int, [_V, _V, _I, _I, _L, _V, _I, _V, _L, _V, _I, _V]),
     "m3_wgrad_bias_reduce": (c_int, [_V, _I, _L, _V, _I, _V]),

@@ -81,6 +81,9 @@ template <typename T> struct WgLds;
 #ifndef M3_WGRAD_F16_ROWS
 #define M3_WGRAD_F16_ROWS 32
 #endif
+#ifndef M3_WGRAD_WIDE_ROWS
+#define M3_WGRAD_WIDE_ROWS 32        // contraction rows per barrier step of the wide-tile kernel
+#endif
 template <> struct WgLds<half_t> { static constexpr int STRIDE = 288; static constexpr int ROWS = M3_WGRAD_F16_ROWS; };
 template <> struct WgLds<float> { static constexpr int STRIDE = 528; static constexpr int ROWS = 32; };
 
@@ -319,6 +322,254 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide tiles (fp16): 128(n) x 384(k) for the K = 384 weights (qkv, fc1, expert FC1) and 384(n) x 128(k) for the
+// N = 384 ones (fc2, expert FC2, patch embedding), eight waves per workgroup, one workgroup per CU.
+// A 128 x 128 tile moves 16 KiB through global loads, ds_write and transposed ds_reads per MFLOP; every one of
+// those paths is within 1.5x of the MFMA time, and with four waves per workgroup the phases of a 32-row step
+// (loads, LDS stores, barrier, transposed reads, 16 MFMAs) largely serialise: 20 % of the MFMA peak.  The wide tile
+// has 1.5x the FLOP per staged byte (96 instead of 64), covers the whole 384-wide side (that operand is read from
+// memory once per column tile instead of three times) and gives a wave 24 MFMAs per barrier with a second wave on
+// its SIMD to run under its LDS phases.
+// Staging: one wave loads one contraction row - lanes 0..CPR_C-1 the 16-byte chunks of the dC row, the others the
+// chunks of the A row (64 chunks either way) - so a wave's load instruction reads two contiguous runs and the
+// gather index of a row is one broadcast load.
+template <bool WIDE_K> struct WwCfg {
+  static constexpr int TN = WIDE_K ? 128 : 384, TK = WIDE_K ? 384 : 128;
+  static constexpr int NWR = WIDE_K ? 4 : 2, NWC = 8 / NWR;            // waves along k, along n
+  static constexpr int KI = TK / 16 / NWR, NI = TN / 16 / NWC;         // 16 x 16 tiles per wave: 6 x 4 or 4 x 6
+  static constexpr int SC = TN * 2 + 32, SA = TK * 2 + 32;             // LDS row strides: 32 B past a multiple of 256 B
+  static constexpr int CPR_C = TN / 8;                                 // 16-byte chunks of a dC row; the A row has 64 - CPR_C
+};
+constexpr int WW_THREADS = 512;
+
+__device__ __forceinline__ f16x8 read_tr_frag16(const char *base, int stride, int rb, int col, int li, int lg) {
+  const char *p0 = base + (rb + 4 * lg + (li >> 2)) * stride + (col + 4 * (li & 3)) * 2;
+  const char *p1 = p0 + 16 * stride;
+  fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t *)p0);
+  fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t *)p1);
+  f16x8 f;
+  f[0] = (half_t)lo[0]; f[1] = (half_t)lo[1]; f[2] = (half_t)lo[2]; f[3] = (half_t)lo[3];
+  f[4] = (half_t)hi[0]; f[5] = (half_t)hi[1]; f[6] = (half_t)hi[2]; f[7] = (half_t)hi[3];
+  return f;
+}
+
+// Diagnostic build (-DM3_WGRAD_CLOCK, tools/wgrad_clock.py): workgroup 0 records how many shader cycles (s_memtime) and
+// how many 100 MHz reference ticks (s_memrealtime) its life took - their ratio is the clock the kernel really ran at.
+#ifdef M3_WGRAD_CLOCK
+__device__ unsigned long long g_wgrad_clock[4];
+#endif
+
+template <bool GC, bool GA, bool WIDE_K, int ROWS>
+__global__ __launch_bounds__(WW_THREADS, 2) void wgrad_wide_kernel(const WgradDev p) {
+#ifdef M3_WGRAD_CLOCK
+  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  typedef Mma<half_t> MM;
+  typedef MM::frag frag;
+  typedef WwCfg<WIDE_K> C;
+  constexpr int KI = C::KI, NI = C::NI, SC = C::SC, SA = C::SA;
+  constexpr int NLD = ROWS / 8;                             // rows (= chunks) per thread per step
+  constexpr int OPC = ROWS * SC, BUF = ROWS * (SC + SA);    // dC image, whole buffer
+  constexpr int KCH = ROWS / 32;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int wr = wave / C::NWC, wc = wave - wr * C::NWC;
+
+  const int tiles = gridDim.x;
+  const int lin = blockIdx.x + tiles * (blockIdx.y + gridDim.y * blockIdx.z);
+  int tile, gs, g, sp, nst;
+  int64_t r0, r1, s_begin;
+  if (p.chunk_rows) {                          // gs = work unit; its slab is ws[gs]
+    if (!wgrad_unit(p.group_offsets, p.G, p.chunk_rows, lin, tiles, lane, tile, gs, g, r0, r1)) return;
+    sp = gs; s_begin = 0;
+    nst = (int)((r1 - r0 + ROWS - 1) / ROWS);
+  } else {
+    const int log_id = xcd_remap(lin, tiles * gridDim.y * gridDim.z);
+    tile = log_id % tiles; gs = log_id / tiles;
+    g = gs % (int)gridDim.y; sp = gs / (int)gridDim.y;
+    if (p.group_offsets) { r0 = p.group_offsets[g]; r1 = p.group_offsets[g + 1]; }
+    else { r0 = 0; r1 = p.M; }
+    const int64_t nsteps_all = (r1 - r0 + ROWS - 1) / ROWS;
+    const int64_t per = (nsteps_all + p.splits - 1) / p.splits;
+    s_begin = (int64_t)sp * per;
+    int64_t s_end = s_begin + per;
+    if (s_end > nsteps_all) s_end = nsteps_all;
+    nst = (int)(s_end > s_begin ? s_end - s_begin : 0);
+  }
+  const int tn = tile / p.tiles_k, tk = tile - tn * p.tiles_k;
+  const int n0 = tn * C::TN, k0 = tk * C::TK;
+  const int64_t slab_id = p.chunk_rows ? (int64_t)sp : (int64_t)sp * p.G + g;
+
+  f32x4 acc[KI][NI];   // MFMA rows = k, cols = n
+#pragma unroll
+  for (int a = 0; a < KI; ++a)
+#pragma unroll
+    for (int b = 0; b < NI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging: wave w loads rows w, w + 8, ... of a step; lane j the j-th 16-byte chunk of (dC row | A row)
+  const bool is_c = lane < C::CPR_C;
+  const char *g_base = is_c ? p.dC + (int64_t)n0 * 2 + lane * 16 : p.A + (int64_t)k0 * 2 + (lane - C::CPR_C) * 16;
+  const int64_t g_stride = is_c ? p.lddc_b : p.lda_b;
+  // gather: every lane reads an index table (its own side's, or - value unused - the other side's), so the index
+  // load is unconditional and the compiler's vmcnt counts stay exact; a_row_div is a power of two here (host check)
+  const int32_t *g_idx = (is_c ? GC : GA) ? (is_c ? p.c_row_idx : p.a_row_idx) : (GC ? p.c_row_idx : p.a_row_idx);
+  const int32_t g_mask = (is_c ? GC : GA) ? -1 : 0;        // (a mask, not a branch: the compiler would sink the load into it)
+  const int g_sh = is_c ? 0 : __builtin_ctz((unsigned)p.a_row_div);
+  const int st_off = is_c ? wave * SC + lane * 16 : OPC + wave * SA + (lane - C::CPR_C) * 16;      // + 8 i * stride
+  const int st_step = 8 * (is_c ? SC : SA);
+  const int64_t rbase = r0 + s_begin * ROWS + wave;        // row of chunk 0 in local step 0
+
+  auto row_of = [&](int step, int i) -> int64_t {           // clamped row
+    const int64_t m = rbase + (int64_t)step * ROWS + i * 8;
+    return m < r1 ? m : r1 - 1;
+  };
+  auto load_index = [&](int step, int32_t(&ix)[NLD]) {
+    if (!(GC || GA)) return;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int64_t m = row_of(step, i);
+      const int32_t v = g_idx[m] >> g_sh;
+      ix[i] = (int32_t)m ^ ((v ^ (int32_t)m) & g_mask);
+    }
+  };
+  auto load_global = [&](int step, const int32_t(&ix)[NLD], u32x4(&rq)[NLD]) {
+#ifdef WW_ABL_NOLOAD                               // diagnostic builds (profiles/README.md): one phase of the step removed
+    if (step > 1) return;
+#endif
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int64_t row = (GC || GA) ? (int64_t)ix[i] : row_of(step, i);
+      rq[i] = *(const u32x4 *)(g_base + row * g_stride);
+    }
+  };
+  auto store_lds = [&](int buf, int step, const u32x4(&rq)[NLD]) {
+    char *base = smem + buf * BUF + st_off;
+#ifdef WW_ABL_NOLDSW
+    if (step > 1) return;
+#endif
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const bool ok = rbase + (int64_t)step * ROWS + i * 8 < r1;       // rows past the group's end add zeros
+      *(u32x4 *)(base + i * st_step) = ok ? rq[i] : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  const bool do_bias = p.bias_ws && tk == 0 && wr == 0;    // column sums of dC as one extra MFMA row of ones
+  f32x4 acc_b[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) acc_b[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  frag ones;
+#pragma unroll
+  for (int j = 0; j < MM::EPL; ++j) ones[j] = (half_t)1.0f;
+
+  auto compute = [&](int buf) {
+    const char *sC = smem + buf * BUF, *sA = sC + OPC;
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc) {
+      // the n fragments stay for the whole chunk; the k fragments are read two ahead of their MFMA row (sched_barriers
+      // keep the compiler from hoisting all ten reads to the top: with them all live the kernel spills)
+      frag fn[NI], fk[KI];
+#ifdef WW_ABL_NOTR
+#define read_tr_frag16(a_, b_, c_, d_, e_, f_) ones
+#endif
+#pragma unroll
+      for (int i = 0; i < NI; ++i) fn[i] = read_tr_frag16(sC, SC, kc * 32, (wc * NI + i) * 16, li, lg);
+      fk[0] = read_tr_frag16(sA, SA, kc * 32, (wr * KI + 0) * 16, li, lg);
+      fk[1] = read_tr_frag16(sA, SA, kc * 32, (wr * KI + 1) * 16, li, lg);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ki = 0; ki < KI; ++ki) {
+        if (ki + 2 < KI) fk[ki + 2] = read_tr_frag16(sA, SA, kc * 32, (wr * KI + ki + 2) * 16, li, lg);
+#pragma unroll
+#ifdef WW_ABL_NOMFMA
+        for (int ni = 0; ni < NI; ++ni) acc[ki][ni][0] += fk[ki][0] * fn[ni][0];
+#else
+        for (int ni = 0; ni < NI; ++ni) acc[ki][ni] = MM::mma(fk[ki], fn[ni], acc[ki][ni]);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#ifdef WW_ABL_NOTR
+#undef read_tr_frag16
+#endif
+      if (do_bias) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc_b[ni] = MM::mma(ones, fn[ni], acc_b[ni]);
+      }
+    }
+  };
+
+  if (nst > 0) {
+    // Ping-pong: waves 0-3 and waves 4-7 (one of each on every SIMD) run half a step apart.  In the first half of
+    // step t the first group multiplies buffer t while the second group requests the rows of step t + 2 and writes
+    // its share of step t + 1 into the other buffer; in the second half they swap.  So one group's transposed reads
+    // and MFMAs always run against the other group's address arithmetic, global loads and LDS stores, instead of all
+    // eight waves reading, multiplying and storing in lockstep (measured on the lockstep version: the skeleton
+    // without MFMAs, loads and slab stores still took 0.67 us per 32-row step).
+    // Steps past the end re-load the last step (clamped) and are never multiplied, so the loop body is unconditional.
+    const int last = nst - 1;
+    auto cl = [&](int s_) { return s_ < last ? s_ : last; };
+    const bool first_grp = wave < 4;
+    // two register sets, each written to LDS and then re-used at once for the rows two steps further on: a load has
+    // two whole steps to arrive (one step was not enough for rows coming from the Infinity Cache / HBM)
+    u32x4 qa[NLD], qb[NLD];
+    int32_t ip[NLD], iq[NLD];                     // gather indices, two sets: a refill requests the next refill's rows'
+    load_index(0, ip);                             // indices BEFORE it issues its own data loads, so that using them a
+    load_global(0, ip, qb);                        // step later does not wait for those data loads (vmcnt is in-order)
+    load_index(cl(1), iq);
+    load_global(cl(1), iq, qa);
+    store_lds(0, 0, qb);
+    load_index(cl(2), ip);
+    load_global(cl(2), ip, qb);
+    load_index(cl(3), ip);
+    __syncthreads();
+    // entry of even local step t: buf0 = step t, qa = step t + 1, qb = step t + 2, ip = indices of step t + 3
+    auto refill_a = [&](int t) { store_lds(1, t + 1, qa); load_index(cl(t + 4), iq); load_global(cl(t + 3), ip, qa); };
+    auto refill_b = [&](int t) { store_lds(0, t + 2, qb); load_index(cl(t + 5), ip); load_global(cl(t + 4), iq, qb); };
+    for (int t = 0; t < nst; t += 2) {
+      if (first_grp) compute(0); else refill_a(t);
+      __syncthreads();
+      if (first_grp) refill_a(t); else compute(0);
+      __syncthreads();
+      const bool odd = t + 1 < nst;
+      if (first_grp) { if (odd) compute(1); } else refill_b(t);
+      __syncthreads();
+      if (first_grp) refill_b(t); else { if (odd) compute(1); }
+      __syncthreads();
+    }
+  }
+
+  if (do_bias && lg == 0) {                       // every row of the ones-product is the column sum: take row 0
+    float *bs = p.bias_ws + slab_id * p.N;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bs[n0 + (wc * NI + ni) * 16 + li] = acc_b[ni][0];
+  }
+  // slab[n][k]; lane holds k = kb + 4*lg + r, n = nb + li
+  float *slab = p.ws + slab_id * (int64_t)p.N * p.K;
+#ifdef WW_ABL_NOSLAB
+  if (acc[0][0][0] != 12345.f) return;
+#endif
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + (wc * NI + ni) * 16 + li;
+#pragma unroll
+    for (int ki = 0; ki < KI; ++ki) {
+      const int k = k0 + (wr * KI + ki) * 16 + 4 * lg;
+      *(f32x4 *)(slab + (int64_t)n * p.K + k) = acc[ki][ni];
+    }
+  }
+#ifdef M3_WGRAD_CLOCK
+  if (lin == 0 && tid == 0) {
+    g_wgrad_clock[0] = __builtin_amdgcn_s_memtime() - clk_t0;
+    g_wgrad_clock[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    g_wgrad_clock[2] = (unsigned long long)nst;
+  }
+#endif
+}
+
 // slabs -> dW (blocks [0, nb_w)) and, in the same launch, bias slabs -> db (blocks [nb_w, ...)); splits in order
 __global__ void wgrad_reduce_kernel(const float *ws, int splits, int64_t elems4, float *dW, int beta, int nb_w,
                                     const float *bias_ws, int64_t belems4, float *db, int beta_db) {
@@ -410,6 +661,33 @@ static int colsum_strips_per_group(int64_t M, int G) {
 
 using namespace m3;
 
+// the output tile (n x k) m3_wgrad_tn uses for a shape: callers size `splits` / `units` (and with them the slab
+// workspace) for ceil(N / tn) * ceil(K / tk) tiles per group.  The wide tiles are opt-in (m3_wgrad_set_wide(1) or
+// M3_WGRAD_WIDE=1): 5-20 % faster per launch by themselves, not faster inside the two-stream training step.
+#ifdef M3_WGRAD_CLOCK
+extern "C" int m3_debug_wgrad_clock(unsigned long long *dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wgrad_clock), sizeof(g_wgrad_clock)) == hipSuccess ? M3_OK : M3_ERR_LAUNCH;
+}
+#endif
+
+static int g_wgrad_wide = -1;
+extern "C" int m3_wgrad_set_wide(int on) {
+  M3_REQUIRE(on >= -1 && on <= 1, "m3_wgrad_set_wide: %d", on);
+  g_wgrad_wide = on;
+  return M3_OK;
+}
+
+extern "C" int m3_wgrad_tile(int N, int K, int dtype, int *tn, int *tk) {
+  M3_REQUIRE(tn && tk, "m3_wgrad_tile: null output");
+  if (g_wgrad_wide < 0) { const char *e = getenv("M3_WGRAD_WIDE"); g_wgrad_wide = e ? (atoi(e) ? 1 : 0) : 0; }
+  *tn = WG_T; *tk = WG_T;
+  if (g_wgrad_wide && dtype == M3_F16) {
+    if (K == 384 && N % 128 == 0 && N >= 768) { *tn = 128; *tk = 384; }
+    else if (N == 384 && K % 128 == 0 && K >= 768) { *tn = 384; *tk = 128; }
+  }
+  return M3_OK;
+}
+
 extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   M3_REQUIRE(a && a->dC && a->A && a->ws, "m3_wgrad_tn: null operand");
   M3_REQUIRE(a->dtype == M3_F32 || a->dtype == M3_F16, "m3_wgrad_tn: bad dtype");
@@ -429,12 +707,36 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   M3_REQUIRE(a->chunk_rows >= 0 && (a->chunk_rows == 0 || (a->group_offsets && a->chunk_rows % WG_ROWS == 0 && a->units >= 1 && a->G <= 64)),
              "m3_wgrad_tn: balanced mode needs group_offsets, G <= 64, chunk_rows a multiple of %d and units >= 1", WG_ROWS);
   d.chunk_rows = a->chunk_rows;
+  hipStream_t s = (hipStream_t)stream;
+  const bool gc = a->c_row_idx != nullptr, ga = a->a_row_idx != nullptr;
+  // wide tiles (fp16): the shapes m3_wgrad_tile() names; the caller sized `splits` / `units` for that tile count
+  int tn_w = 0, tk_w = 0;
+  m3_wgrad_tile(a->N, a->K, a->dtype, &tn_w, &tk_w);
+  if ((tn_w != WG_T || tk_w != WG_T) && (d.a_row_div & (d.a_row_div - 1)) == 0) {
+    constexpr int WR = M3_WGRAD_WIDE_ROWS;
+    const bool wide_k = tk_w == 384;
+    d.tiles_k = a->K / tk_w;
+    const dim3 wgrid((a->N / tn_w) * d.tiles_k, a->chunk_rows ? a->units : a->G, a->chunk_rows ? 1 : a->splits), wblock(WW_THREADS);
+    const size_t wl = 2 * WR * (WwCfg<true>::SC + WwCfg<true>::SA);
+    static bool wattr = false;
+#define M3_WW_ALL(F) F(true, true, true) F(true, true, false) F(true, false, true) F(true, false, false) \
+                     F(false, true, true) F(false, true, false) F(false, false, true) F(false, false, false)
+    if (!wattr) {
+#define M3_WW_ATTR(GC_, GA_, WK_) (void)hipFuncSetAttribute((const void *)wgrad_wide_kernel<GC_, GA_, WK_, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
+      M3_WW_ALL(M3_WW_ATTR)
+#undef M3_WW_ATTR
+      wattr = true;
+    }
+#define M3_WW_LAUNCH(GC_, GA_, WK_) if (gc == GC_ && ga == GA_ && wide_k == WK_) hipLaunchKernelGGL((wgrad_wide_kernel<GC_, GA_, WK_, WR>), wgrid, wblock, wl, s, d);
+    M3_WW_ALL(M3_WW_LAUNCH)
+#undef M3_WW_LAUNCH
+#undef M3_WW_ALL
+    return check_launch("m3_wgrad_tn");
+  }
   const int tiles_n = (a->N + WG_T - 1) / WG_T;
   d.tiles_k = (a->K + WG_T - 1) / WG_T;
   const dim3 grid(tiles_n * d.tiles_k, a->chunk_rows ? a->units : a->G, a->chunk_rows ? 1 : a->splits), block(WG_THREADS);
-  hipStream_t s = (hipStream_t)stream;
   M3_REQUIRE(a->N * es >= 16 && a->K * es >= 16, "m3_wgrad_tn: N, K too small");
-  const bool gc = a->c_row_idx != nullptr, ga = a->a_row_idx != nullptr;
   const size_t lds16 = 4 * WgLds<half_t>::ROWS * WgLds<half_t>::STRIDE, lds32 = 4 * WgLds<float>::ROWS * WgLds<float>::STRIDE;
 #define M3_WG(TT, LDS)                                                                               \
   do {                                                                                               \

@@ -172,7 +172,7 @@ class BackboneEngine:
         for (M, N, K, G) in [(T, self.Hd, D, 1), (T, D, self.Hd, 1), (T, 3 * D, D, 1), (T, D, D, 1),
                              (R, self.Hm, D, self.E), (R, D, self.Hm, self.E), (self.B * self.np_, D, Kp, 1),
                              (T, D, self.E, 1)]:
-            wg = max(wg, ops.wgrad_ws_elems(M, N, K, G, grouped=G > 1))
+            wg = max(wg, ops.wgrad_ws_elems(M, N, K, G, grouped=G > 1, dtype=self.dt))
         self.ws_wgrad = self._e(wg, dtype=f32)
         cs = max(int(ops.lib().m3_colsum_ws_elems(T, 3 * D, 1)), int(ops.lib().m3_colsum_ws_elems(T, self.Hd, 1)),
                  int(ops.lib().m3_colsum_ws_elems(R, max(self.Hm, D), self.E)))

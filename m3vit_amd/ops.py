@@ -6,6 +6,7 @@ HIP stream.  No function in this module computes anything with torch ops.
 """
 from __future__ import annotations
 
+import ctypes
 from ctypes import byref, c_void_p
 from typing import Optional
 
@@ -289,7 +290,7 @@ def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None,
     if M is None:
         M = dC.shape[0]
     if splits is None:
-        splits = default_wgrad_splits(M, N, K, G)
+        splits = default_wgrad_splits(M, N, K, G, dC.dtype)
     balanced = group_offsets is not None
     chunk, units = wgrad_plan(M, G, splits, balanced)
     balanced = chunk > 0
@@ -340,24 +341,50 @@ def wgrad_plan(M, G, splits, grouped):
     return 0, splits * G
 
 
-def wgrad_ws_elems(M, N, K, G, grouped, bias=True):
+def wgrad_ws_elems(M, N, K, G, grouped, bias=True, dtype=None):
     """fp32 elements of workspace wgrad_tn needs for this shape with the default splits"""
-    _, units = wgrad_plan(M, G, default_wgrad_splits(M, N, K, G), grouped)
+    _, units = wgrad_plan(M, G, default_wgrad_splits(M, N, K, G, dtype), grouped)
     return units * N * (K + (1 if bias else 0))
 
 
 _WGRAD_MIN_STEPS = 16      # 32-row steps per split at least (measured on the 8-image configs; no effect at batch 128)
 
 
-def default_wgrad_splits(M, N, K, G):
-    """Row splits of the TN GEMM: fill the 512 resident workgroup slots (2 per CU) exactly once - more
-    splits only add slab traffic and a ragged second wave of workgroups - but keep at least
-    _WGRAD_MIN_STEPS 32-row steps per split, so that short contractions (few tokens) do not pay a 64 KiB slab
-    write + reduce per handful of steps."""
-    tiles = ((N + 127) // 128) * ((K + 127) // 128) * G
+def wgrad_set_wide(on: int):
+    """wide weight-gradient tiles on / off (include/m3vit_hip.h: m3_wgrad_set_wide); switch before sizing workspaces"""
+    check(lib().m3_wgrad_set_wide(int(on)), "m3_wgrad_set_wide")
+
+
+def wgrad_tile(N, K, dtype=None):
+    """(tn, tk): the output tile m3_wgrad_tn uses for this shape (m3_wgrad_tile in include/m3vit_hip.h)"""
+    if dtype is None:
+        return 128, 128
+    tn, tk = ctypes.c_int(0), ctypes.c_int(0)
+    check(lib().m3_wgrad_tile(N, K, dt_code(dtype), byref(tn), byref(tk)), "m3_wgrad_tile")
+    return tn.value, tk.value
+
+
+def default_wgrad_splits(M, N, K, G, dtype=None):
+    """Row splits of the TN GEMM.  128 x 128 tiles: fill the 512 resident workgroup slots (2 per CU) exactly once - more
+    splits only add slab traffic and a ragged second wave of workgroups - but keep at least _WGRAD_MIN_STEPS 32-row
+    steps per split, so that short contractions (few tokens) do not pay a 64 KiB slab write + reduce per handful of
+    steps.  Wide tiles (one 512-thread workgroup per CU, 256 slots): as many splits as fill the slots once; with more
+    tiles than a third of the slots (grouped experts) the split count whose workgroups come closest to whole rounds."""
+    tn, tk = wgrad_tile(N, K, dtype)
+    tiles = ((N + tn - 1) // tn) * ((K + tk - 1) // tk) * G
     steps = max(1, (M // max(G, 1) + 31) // 32)
-    s = max(1, min(steps // _WGRAD_MIN_STEPS, 32, 512 // tiles if tiles <= 512 else 1))
-    return int(s)
+    cap = max(1, steps // _WGRAD_MIN_STEPS)
+    if (tn, tk) == (128, 128):
+        return int(max(1, min(cap, 32, 512 // tiles if tiles <= 512 else 1)))
+    slots = 256
+    if 3 * tiles <= slots:
+        return int(max(1, min(cap, slots // tiles)))
+    best, best_cost = 1, None
+    for s_ in range(1, min(cap, 8) + 1):
+        cost = -(-tiles * s_ // slots) / s_ * (1 + 0.15 * s_)      # rounds x length of a unit (+ its slab: measured, tools/wgrad_bench.py --splits)
+        if best_cost is None or cost < best_cost:
+            best, best_cost = s_, cost
+    return int(best)
 
 
 def colsum(dC, db, *, M=None, beta=0, c_row_idx=None, group_offsets=None, ws=None):
