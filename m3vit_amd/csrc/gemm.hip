@@ -545,9 +545,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const Gemm
 // rows stay in that XCD's L2 - and its workgroups split the band's tiles, column-major, into equal runs (a run that
 // crosses a column or expert boundary reloads the weight fragments).
 constexpr int WS_THREADS = 512;
-constexpr int WS_NS = 2;                           // ring slots: slice q is read while slice q + 1 is written
+constexpr int WS_NS = 3;                           // ring slots: slice q (and the head of q + 1) is read while slice q + 2 is written
 constexpr int WS_SLICE = 16384;                    // 128 rows x 128 B
-constexpr int WS_RING = WS_NS * WS_SLICE;          // 32 KiB
+constexpr int WS_RING = WS_NS * WS_SLICE;          // 48 KiB
 constexpr int WS_STAGE = BM * BN * 4;              // 64 KiB fp32 tile
 constexpr int WS_IDX = 2 * BM * 4;                 // two tables of 128 source rows
 constexpr int WS_TAB = 1024;                        // 64 tiles x {g, nt, m_begin, m_end}
@@ -635,6 +635,8 @@ __global__ __launch_bounds__(WS_THREADS, 2) void gemm_nt_ws_kernel(const GemmDev
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) rdA[kc] = li * 128 + (((kc * 4 + lg) ^ swl) << 4);      // + m8 * 16 * 128
     int iv0 = 0, iv1 = 0;
+    frag af0[8], af1[8];                           // activation fragments: first / second 32-deep half of a slice
+    bool primed = false;
 #pragma nounroll
     for (int it = 0; it <= ntl; ++it) {
       const bool live = it < ntl;
@@ -672,43 +674,59 @@ __global__ __launch_bounds__(WS_THREADS, 2) void gemm_nt_ws_kernel(const GemmDev
           iv0 = p.a_row_idx[m0]; iv1 = p.a_row_idx[m1];
         }
         if (live) {
-          const char *sb = ring + ((it * WS_KS + s) & 1) * WS_SLICE;
-          frag af[2][8];                            // both 32-deep halves of the slice are requested up front
+          // Slice q is multiplied in two 32-deep halves.  The fragments of its FIRST half were requested in the middle
+          // of the previous step (the ring is written two steps ahead, so slice q was complete one barrier ago); the
+          // second half is requested now and arrives under the first half's 16 MFMAs; then the next slice's first
+          // half is requested under the second half's MFMAs.  No MFMA ever waits on a read issued behind its barrier.
+          const char *sb = ring + (s % WS_NS) * WS_SLICE;           // slice q lives in slot q % 3 = s % 3 (six slices a tile)
+          const char *sbn = ring + ((s + 1) % WS_NS) * WS_SLICE;
+#if defined(WS_ABL_NOMFMA)                         // diagnostic builds: one ingredient of a step removed (results are wrong)
+#define WS_MMA(a_, b_, c_) ((c_) + f32x4{(float)(b_)[0], 0.f, 0.f, 0.f})
+#else
+#define WS_MMA(a_, b_, c_) MM::mma(a_, b_, c_)
+#endif
+#ifdef WS_ABL_NOREAD
+#define WS_RD(ptr_) bf[0][0]
+#else
+#define WS_RD(ptr_) (*(const frag *)(ptr_))
+#endif
+          if (!primed) {                            // first slice of the run
 #pragma unroll
-          for (int kc = 0; kc < 2; ++kc)
+            for (int m8 = 0; m8 < 8; ++m8) af0[m8] = WS_RD(sb + rdA[0] + m8 * 16 * 128);
+            primed = true;
+          }
 #pragma unroll
-            for (int m8 = 0; m8 < 8; ++m8) af[kc][m8] = *(const frag *)(sb + rdA[kc] + m8 * 16 * 128);
-          __builtin_amdgcn_sched_barrier(0);        // [16 reads][32 MFMAs]: keep the reads in flight together
-          if (s + 1 < WS_KS) {
+          for (int m8 = 0; m8 < 8; ++m8) af1[m8] = WS_RD(sb + rdA[1] + m8 * 16 * 128);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kc = 0; kc < 2; ++kc)
+          for (int m8 = 0; m8 < 8; ++m8) {
+            acc[m8][0] = WS_MMA(bf[0][2 * s], af0[m8], acc[m8][0]);
+            acc[m8][1] = WS_MMA(bf[1][2 * s], af0[m8], acc[m8][1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (s + 1 < WS_KS || it + 1 < ntl) {
 #pragma unroll
-              for (int m8 = 0; m8 < 8; ++m8) {
-                acc[m8][0] = MM::mma(bf[0][2 * s + kc], af[kc][m8], acc[m8][0]);
-                acc[m8][1] = MM::mma(bf[1][2 * s + kc], af[kc][m8], acc[m8][1]);
+            for (int m8 = 0; m8 < 8; ++m8) af0[m8] = WS_RD(sbn + rdA[0] + m8 * 16 * 128);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int m8 = 0; m8 < 8; ++m8) {
+            acc[m8][0] = WS_MMA(bf[0][2 * s + 1], af1[m8], acc[m8][0]);
+            acc[m8][1] = WS_MMA(bf[1][2 * s + 1], af1[m8], acc[m8][1]);
+            if (s + 1 == WS_KS && m8 > 0) {
+              // last slice: a row block's accumulators go to the staging image as soon as they are final - row
+              // m = 16 m8 + li, columns 32 wave + 16 n2 + 4 lg .. + 3 (fp32, 16 bytes) - under the MFMAs of the blocks
+              // behind it.  (The helpers read the image in steps 0-4 only: it is free once B(5) has opened.)
+#pragma unroll
+              for (int n2 = 0; n2 < 2; ++n2) {
+                const int row = (m8 - 1) * 16 + li;
+                const int chunk = 8 * wave + 4 * n2 + lg;
+                *(f32x4 *)(stage + row * 512 + ((chunk ^ (row & 31)) << 4)) = acc[m8 - 1][n2];
               }
-            __builtin_amdgcn_sched_barrier(0);
-          } else {
-            // last slice: row block by row block, each block's accumulators go to the staging image as soon as they are
-            // final - row m = 16 m8 + li, columns 32 wave + 16 n2 + 4 lg .. + 3 (fp32, 16 bytes) - under the MFMAs of
-            // the blocks behind it.  (The helpers read the image in steps 0-4 only: it is free once B(5) has opened.)
-#pragma unroll
-            for (int m8 = 0; m8 < 8; ++m8) {
-#pragma unroll
-              for (int kc = 0; kc < 2; ++kc) {
-                acc[m8][0] = MM::mma(bf[0][2 * s + kc], af[kc][m8], acc[m8][0]);
-                acc[m8][1] = MM::mma(bf[1][2 * s + kc], af[kc][m8], acc[m8][1]);
-              }
-              if (m8 > 0) {
-#pragma unroll
-                for (int n2 = 0; n2 < 2; ++n2) {
-                  const int row = (m8 - 1) * 16 + li;
-                  const int chunk = 8 * wave + 4 * n2 + lg;
-                  *(f32x4 *)(stage + row * 512 + ((chunk ^ (row & 31)) << 4)) = acc[m8 - 1][n2];
-                }
-              }
-              __builtin_amdgcn_sched_barrier(0);
             }
+            if (s + 1 == WS_KS) __builtin_amdgcn_sched_barrier(0);
+          }
+          if (s + 1 == WS_KS) {
 #pragma unroll
             for (int n2 = 0; n2 < 2; ++n2) {
               const int row = 7 * 16 + li;
@@ -716,6 +734,7 @@ __global__ __launch_bounds__(WS_THREADS, 2) void gemm_nt_ws_kernel(const GemmDev
               *(f32x4 *)(stage + row * 512 + ((chunk ^ (row & 31)) << 4)) = acc[7][n2];
             }
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
         if (s == 4 && idx_job) {
           int *tab = idx_tab + ((it + 2) & 1) * BM;
@@ -744,11 +763,17 @@ __global__ __launch_bounds__(WS_THREADS, 2) void gemm_nt_ws_kernel(const GemmDev
       }
     };
     auto fetch = [&](int ks, u32x4(&r)[4]) {
+#ifdef WS_ABL_NOFETCH
+      if (tid >= 0) return;
+#endif
 #pragma unroll
       for (int pc = 0; pc < 4; ++pc) r[pc] = *(const u32x4 *)(src[pc] + ks * 128);
     };
-    auto put = [&](int q, const u32x4(&r)[4]) {
-      char *dst = ring + (q & 1) * WS_SLICE + (4 * hw) * 1024 + lane * 16;
+    auto put = [&](int slot, const u32x4(&r)[4]) {
+#ifdef WS_ABL_NOPUT
+      if (tid >= 0) return;
+#endif
+      char *dst = ring + slot * WS_SLICE + (4 * hw) * 1024 + lane * 16;
 #pragma unroll
       for (int pc = 0; pc < 4; ++pc) *(u32x4 *)(dst + pc * 1024) = r[pc];
     };
@@ -757,6 +782,7 @@ __global__ __launch_bounds__(WS_THREADS, 2) void gemm_nt_ws_kernel(const GemmDev
     for (int ks = 0; ks < WS_KS; ++ks) fetch(ks, lq[ks]);
     if (ntl > 1) set_src(1, false);                // (the table serves tiles 2 ...)
     put(0, lq[0]);
+    if (ntl * WS_KS > 1) put(1, lq[1]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     // One round = the six steps of tile `it`.  LIVE: tile `it` exists (its slices go to the ring); MORE: so does tile
@@ -798,7 +824,12 @@ __global__ __launch_bounds__(WS_THREADS, 2) void gemm_nt_ws_kernel(const GemmDev
         // requested first so that their latency runs under the load / ring-write issue below
         constexpr int first[WS_KS + 1] = {0, 1, 3, 5, 7, 8, 8};
         f32x4 sv[2][2];
-        if constexpr (HAVE) {
+#ifdef WS_ABL_NOEPI
+        constexpr bool EPI_ON = false;
+#else
+        constexpr bool EPI_ON = true;
+#endif
+        if constexpr (HAVE && EPI_ON) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             if (first[s] + j >= first[s + 1]) continue;
@@ -811,11 +842,11 @@ __global__ __launch_bounds__(WS_THREADS, 2) void gemm_nt_ws_kernel(const GemmDev
         if constexpr (LIVE) {
           if constexpr (MORE) {
             if constexpr (HAVE) { if (s == 0) set_src(it + 1, true); }      // (tile 1's rows were set in the prologue)
-            fetch(s, lq[s]);                                     // slice s of tile it + 1; set s went to LDS a step ago
+            fetch(s, lq[s]);                                     // slice s of tile it + 1; set s went to LDS two steps ago
           }
-          if (s + 1 < WS_KS || MORE) put(it * WS_KS + s + 1, lq[(s + 1) % WS_KS]);
+          if (s + 2 < WS_KS || MORE) put((s + 2) % WS_NS, lq[(s + 2) % WS_KS]);    // slice q + 2 -> slot (q + 2) % 3
         }
-        if constexpr (HAVE) {
+        if constexpr (HAVE && EPI_ON) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             if (first[s] + j >= first[s + 1]) continue;

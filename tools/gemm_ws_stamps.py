@@ -62,9 +62,9 @@ names = ["mfma", "helper"]
 for r in range(2):
     print(f"  {names[r]:6s} arrives last at {100 * (last == r).mean():5.1f} % of barriers; "
           f"mean slack before release {np.mean(release - rel[:, r, :]):.0f} ticks")
-# per position within a round (7 barriers: 6 slices + B2)
-for pos in range(7):
-    sel = np.arange(pos, nb, 7)
+# per position within a round (6 barriers: one per slice)
+for pos in range(6):
+    sel = np.arange(pos, nb, 6)
     sel = sel[sel > 0]
     if len(sel) == 0:
         continue
