@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", choices=["f16", "f32"], default="f16")
     ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--checkpoint", action="store_true",
+                    help="the reference's default memory mode: keep block inputs only, recompute each block in backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
@@ -181,13 +183,15 @@ def main():
         """One timed configuration: W untimed warm-up steps, exactly K timed steps between barriers, max over ranks.
         Returns the fields of the JSON line that depend on the mode."""
         cfg = BackboneConfig(**VIT_SMALL_MOE)
+        torch.cuda.reset_peak_memory_stats(dev)
         dtype = torch.float16 if dtype_name == "f16" else torch.float32
         params = init_params(cfg, seed=1)                       # same weights on every rank
         # m3vit_amd/step.py: one engine context + HIP stream per task pass, hipGraph capture, and for N > 1 the
         # all-reduce of the upper blocks' gradients overlapped with the lower blocks' backward
         runner = MultiTaskStep(cfg, params, batch=args.batch, dtype=dtype, device=str(dev), cv_weight=CV_WEIGHT,
                                parallel_tasks=not args.serial_tasks, graph=not args.no_graph, world=world, rank=rank,
-                               expert_parallel=expert_parallel, wgrad_streams=args.wgrad_streams, dp_parts=args.dp_parts)
+                               expert_parallel=expert_parallel, wgrad_streams=args.wgrad_streams, dp_parts=args.dp_parts,
+                               checkpoint=args.checkpoint and not expert_parallel)
         use_ep, par_tasks, ntasks = runner.use_ep, runner.par, len(runner.tasks)
         g = torch.Generator().manual_seed(1000 + rank)          # each rank its own images
         images = torch.randn(args.batch, 3, *cfg.img_size, generator=g).to(dev)
@@ -236,6 +240,8 @@ def main():
                "model_tflops": round(step_flops * args.steps / dt / 1e12 * world, 2), "launch": runner.launch,
                "task_streams": ntasks if par_tasks else 1, "wgrad_streams": len(runner.engs) if args.wgrad_streams else 0,
                "task_passes": ntasks, "tokens_per_image": cfg.num_tokens,
+               "activation_checkpointing": bool(args.checkpoint and not expert_parallel),
+               "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                "parallelism": "single" if world == 1 else (f"dp{world}+ep{world} (experts sharded, RCCL all-to-all + all-reduce)"
                                                             if use_ep else f"dp{world} (replicated experts, RCCL all-reduce)")}
         if want_roofline:
@@ -345,6 +351,8 @@ def main():
                    "routing": ("noisy gate std=1 (supplied noise, CDF load loss)" if args.noisy else "deterministic (std=0)") +
                               (", skewed: expert 0 in every token's top-k" if args.skew else ""),
                    "task_streams": main_res["task_streams"], "wgrad_streams": main_res["wgrad_streams"],
+                   "activation_checkpointing": main_res["activation_checkpointing"],
+                   "peak_hbm_gib": main_res["peak_hbm_gib"],
                    "parallelism": main_res["parallelism"]},
         "model_tflops": main_res["model_tflops"],
     }

@@ -39,7 +39,7 @@ class _Cfg:
 class BackboneEngine:
     def __init__(self, cfg, params: Dict[str, torch.Tensor], batch: int, dtype=torch.float16,
                  device="cuda:0", ep_group=None, ep_world: int = 1, ep_rank: int = 0, share: "BackboneEngine" = None,
-                 wgrad_stream: bool = False):
+                 wgrad_stream: bool = False, checkpoint: bool = False):
         """params: GLOBAL parameters (all E experts).  With ep_world > 1 this rank keeps experts
         [ep_rank*E/W, (ep_rank+1)*E/W) (utils/common_config.py:179-185) and exchanges routed rows with
         the other ranks over torch.distributed (RCCL) - see _experts_fwd_ep.
@@ -47,7 +47,14 @@ class BackboneEngine:
         uses (params is ignored); it gets its own activations, scratch and gradient buffer, so the two
         can run different task passes concurrently on different HIP streams.
         wgrad_stream: launch the weight-gradient GEMMs of backward() on a second HIP stream - they hang off
-        the dgrad chain (nothing downstream reads them), so they can fill the chain's memory-bound phases."""
+        the dgrad chain (nothing downstream reads them), so they can fill the chain's memory-bound phases.
+        checkpoint: the reference's default memory mode (`use_checkpointing`, train_fastmoe.py:178 ->
+        torch.utils.checkpoint around every block, vision_transformer_moe.py:495-524): forward keeps only each block's
+        input; backward re-runs a block's forward (same kernels, same inputs: bit-identical activations) right before
+        its backward.  All blocks then share ONE set of activation buffers."""
+        assert not (checkpoint and wgrad_stream), "checkpoint mode re-uses the activation buffers a wgrad stream may still read"
+        assert not (checkpoint and ep_world > 1), "checkpoint mode is single-rank (the recompute would repeat the exchanges)"
+        self.checkpoint = bool(checkpoint)
         self.cfg = cfg
         self.dev = torch.device(device)
         self.dt = dtype
@@ -128,25 +135,36 @@ class BackboneEngine:
         T, D, R = self.T, self.D, self.R
         f32 = torch.float32
         self.act = []
-        for i in range(self.depth):
-            a = {}
-            a["x_in"] = None                                   # alias of previous block's output
-            a["mean1"], a["rstd1"] = self._e(T, dtype=f32), self._e(T, dtype=f32)
-            a["h1"] = self._e(T, D)
-            a["qkv"] = self._e(T, 3 * D)
-            a["o"] = self._e(T, D)
-            a["lse"] = self._e(self.B, self.heads, self.N, dtype=f32)
-            a["x1"] = self._e(T, D, dtype=f32)
-            a["mean2"], a["rstd2"] = self._e(T, dtype=f32), self._e(T, dtype=f32)
-            a["h2"] = self._e(T, D)
-            if self.is_moe[i]:
-                a["hid_pre"] = self._e(R, self.Hm)
-                a["hid"] = self._e(R, self.Hm)
-                a["y"] = self._e(R, D)
+        shared = {}                                            # checkpoint mode: one buffer per (block kind, name)
+
+        def buf(a, key, *shape, dtype=None):
+            if self.checkpoint and key != "x2":
+                k_ = (a["_moe"], key)
+                if k_ not in shared:
+                    shared[k_] = self._e(*shape, dtype=dtype)
+                a[key] = shared[k_]
             else:
-                a["pre"] = self._e(T, self.Hd)
-                a["u"] = self._e(T, self.Hd)
-            a["x2"] = self._e(T, D, dtype=f32)
+                a[key] = self._e(*shape, dtype=dtype)
+
+        for i in range(self.depth):
+            a = {"_moe": bool(self.is_moe[i])}
+            a["x_in"] = None                                   # alias of previous block's output
+            buf(a, "mean1", T, dtype=f32); buf(a, "rstd1", T, dtype=f32)
+            buf(a, "h1", T, D)
+            buf(a, "qkv", T, 3 * D)
+            buf(a, "o", T, D)
+            buf(a, "lse", self.B, self.heads, self.N, dtype=f32)
+            buf(a, "x1", T, D, dtype=f32)
+            buf(a, "mean2", T, dtype=f32); buf(a, "rstd2", T, dtype=f32)
+            buf(a, "h2", T, D)
+            if self.is_moe[i]:
+                buf(a, "hid_pre", R, self.Hm)
+                buf(a, "hid", R, self.Hm)
+                buf(a, "y", R, D)
+            else:
+                buf(a, "pre", T, self.Hd)
+                buf(a, "u", T, self.Hd)
+            buf(a, "x2", T, D, dtype=f32)
             self.act.append(a)
         Kp = self.cfg.in_chans * self.P * self.P
         self.rows = self._e(self.B * self.np_, Kp)
@@ -309,6 +327,60 @@ class BackboneEngine:
                 self.grads[n] += g
         self._tsf = None
 
+    def _block_forward(self, i, x, loss_acc):
+        """block i on residual stream x -> its output buffer (vision_transformer_moe.py:438-562: pre-LN attention +
+        MLP / MoE branch).  Called by forward() and, in checkpoint mode, again by backward_blocks() right before the
+        block's backward (loss_acc None there: the balance loss was already counted)."""
+        task_id, tsf_bias, noises, path_scales = self._fwd_ctx
+        P_, p = self.P, self.params
+        B, T, D = self.B, self.T, self.D
+        N = self.N
+        a = self.act[i]
+        b = f"blocks.{i}."
+        a["x_in"] = x
+        ops.layernorm_fwd(x, p[b + "norm1.weight"], p[b + "norm1.bias"], a["h1"], a["mean1"], a["rstd1"])
+        ops.gemm_nt(a["h1"], self.wc[b + "attn.qkv"], a["qkv"], bias=p[b + "attn.qkv.bias"])
+        ops.attention_fwd(a["qkv"], B, self.N, self.heads, self.dh, a["o"], a["lse"])
+        ps = None if path_scales is None else path_scales.get(i)
+        a["ps"] = ps
+        sa, sm = (None, None) if ps is None else ps
+        ops.gemm_nt(a["o"], self.wc[b + "attn.proj"], a["x1"], bias=p[b + "attn.proj.bias"], residual=x,
+                    row_scale=sa, row_scale_div=N)
+        ops.layernorm_fwd(a["x1"], p[b + "norm2.weight"], p[b + "norm2.bias"], a["h2"], a["mean2"], a["rstd2"])
+        if not self.is_moe[i]:
+            ops.gemm_nt(a["h2"], self.wc[b + "mlp.fc1"], a["u"], bias=p[b + "mlp.fc1.bias"], act=M3_ACT_GELU,
+                        pre_out=a["pre"])
+            ops.gemm_nt(a["u"], self.wc[b + "mlp.fc2"], a["x2"], bias=p[b + "mlp.fc2.bias"], residual=a["x1"],
+                        row_scale=sm, row_scale_div=N)
+        else:
+            wname = self._gate_weight(i, task_id)
+            a["wname"] = wname
+            wg = p[wname]
+            wg_tok = wg if wg.shape[0] == D else wg[:D]
+            noise = None if noises is None else noises.get(i)
+            std = (self.cfg.vmoe_noisy_std / self.E) if noise is not None else 0.0
+            # gate + balance loss (importance, load, cv^2 and its gradient) - two launches
+            g = ops.gate_fwd(a["h2"], wg_tok, self.k, logit_bias=None if tsf_bias is None else tsf_bias[i],
+                             noise=noise, noise_std=std, dense=True, loss_acc=loss_acc)
+            a["gate"] = g
+            if self.ep_world > 1:
+                self._experts_fwd_ep(i, a, g)
+            else:
+                r = ops.route_build(g["idx32"], self.E)
+                a["route"] = r
+                ops.gemm_nt(a["h2"], self.wc[b + "mlp.experts.htoh4"], a["hid"], M=self.R,
+                            bias=p[b + "mlp.experts.htoh4.bias"], act=M3_ACT_GELU, pre_out=a["hid_pre"],
+                            a_row_idx=r.row_of_slot, a_row_div=self.k, group_offsets=r.offsets,
+                            tile_starts=r.tile_starts)
+                ops.gemm_nt(a["hid"], self.wc[b + "mlp.experts.h4toh"], a["y"], M=self.R,
+                            bias=p[b + "mlp.experts.h4toh.bias"], c_row_idx=r.row_of_slot,
+                            group_offsets=r.offsets, tile_starts=r.tile_starts)
+            if sm is not None:                          # out = x1 + scale[sample] * sum_j score_j y_j
+                a["sm_tok"] = sm.view(B, 1).expand(B, N).reshape(T, 1).contiguous()
+                a["score_s"] = g["score"] * a["sm_tok"]
+            ops.combine_fwd(a["y"], a["score_s"] if sm is not None else g["score"], a["x1"], a["x2"])
+        return a["x2"]
+
     def forward(self, images: torch.Tensor, task_id: Optional[int], tsf_bias=None, noises=None, path_scales=None):
         """Returns (tokens fp32 [B,N,D], total_cv_loss).  noises: {block: [T,E]} caller-supplied N(0,1).
         Task-conditioned configs compute the per-block logit bias tsf @ w_gate[D:] here (tsf_bias overrides
@@ -330,52 +402,9 @@ class BackboneEngine:
         x = self.x0
         self.cv_acc.zero_()
         self.task_id = task_id
+        self._fwd_ctx = (task_id, tsf_bias, noises, path_scales)
         for i in range(self.depth):
-            a = self.act[i]
-            b = f"blocks.{i}."
-            a["x_in"] = x
-            ops.layernorm_fwd(x, p[b + "norm1.weight"], p[b + "norm1.bias"], a["h1"], a["mean1"], a["rstd1"])
-            ops.gemm_nt(a["h1"], self.wc[b + "attn.qkv"], a["qkv"], bias=p[b + "attn.qkv.bias"])
-            ops.attention_fwd(a["qkv"], B, self.N, self.heads, self.dh, a["o"], a["lse"])
-            ps = None if path_scales is None else path_scales.get(i)
-            a["ps"] = ps
-            sa, sm = (None, None) if ps is None else ps
-            ops.gemm_nt(a["o"], self.wc[b + "attn.proj"], a["x1"], bias=p[b + "attn.proj.bias"], residual=x,
-                        row_scale=sa, row_scale_div=N)
-            ops.layernorm_fwd(a["x1"], p[b + "norm2.weight"], p[b + "norm2.bias"], a["h2"], a["mean2"], a["rstd2"])
-            if not self.is_moe[i]:
-                ops.gemm_nt(a["h2"], self.wc[b + "mlp.fc1"], a["u"], bias=p[b + "mlp.fc1.bias"], act=M3_ACT_GELU,
-                            pre_out=a["pre"])
-                ops.gemm_nt(a["u"], self.wc[b + "mlp.fc2"], a["x2"], bias=p[b + "mlp.fc2.bias"], residual=a["x1"],
-                            row_scale=sm, row_scale_div=N)
-            else:
-                wname = self._gate_weight(i, task_id)
-                a["wname"] = wname
-                wg = p[wname]
-                wg_tok = wg if wg.shape[0] == D else wg[:D]
-                noise = None if noises is None else noises.get(i)
-                std = (self.cfg.vmoe_noisy_std / self.E) if noise is not None else 0.0
-                # gate + balance loss (importance, load, cv^2 and its gradient) - two launches
-                g = ops.gate_fwd(a["h2"], wg_tok, self.k, logit_bias=None if tsf_bias is None else tsf_bias[i],
-                                 noise=noise, noise_std=std, dense=True, loss_acc=self.cv_acc)
-                a["gate"] = g
-                if self.ep_world > 1:
-                    self._experts_fwd_ep(i, a, g)
-                else:
-                    r = ops.route_build(g["idx32"], self.E)
-                    a["route"] = r
-                    ops.gemm_nt(a["h2"], self.wc[b + "mlp.experts.htoh4"], a["hid"], M=self.R,
-                                bias=p[b + "mlp.experts.htoh4.bias"], act=M3_ACT_GELU, pre_out=a["hid_pre"],
-                                a_row_idx=r.row_of_slot, a_row_div=self.k, group_offsets=r.offsets,
-                                tile_starts=r.tile_starts)
-                    ops.gemm_nt(a["hid"], self.wc[b + "mlp.experts.h4toh"], a["y"], M=self.R,
-                                bias=p[b + "mlp.experts.h4toh.bias"], c_row_idx=r.row_of_slot,
-                                group_offsets=r.offsets, tile_starts=r.tile_starts)
-                if sm is not None:                          # out = x1 + scale[sample] * sum_j score_j y_j
-                    a["sm_tok"] = sm.view(B, 1).expand(B, N).reshape(T, 1).contiguous()
-                    a["score_s"] = g["score"] * a["sm_tok"]
-                ops.combine_fwd(a["y"], a["score_s"] if sm is not None else g["score"], a["x1"], a["x2"])
-            x = a["x2"]
+            x = self._block_forward(i, x, self.cv_acc)
         # total cv_loss = sum over MoE blocks of cv^2(importance) + cv^2(load)  (vision_transformer_moe.py:453-459,540)
         return x.view(B, self.N, D), self.cv_acc[0].clone()
 
@@ -523,6 +552,8 @@ class BackboneEngine:
         for i in range(hi, lo - 1, -1):
             a = self.act[i]
             b = f"blocks.{i}."
+            if self.checkpoint:                             # the shared activation buffers hold another block's values
+                self._block_forward(i, a["x_in"], None)
             sa, sm = (None, None) if a.get("ps") is None else a["ps"]
             if not self.is_moe[i]:
                 if sm is not None:                          # DropPath: the gradient entering the branch is scale * d x

@@ -26,7 +26,7 @@ from .engine import BackboneEngine
 class MultiTaskStep:
     def __init__(self, cfg, params, batch: int, dtype=torch.float16, device="cuda:0", tasks=None, cv_weight: float = 0.01,
                  parallel_tasks: bool = True, graph: bool = True, world: int = 1, rank: int = 0, expert_parallel: bool = False,
-                 wgrad_streams: bool = False, dp_parts: int = 6):
+                 wgrad_streams: bool = False, dp_parts: int = 6, checkpoint: bool = False):
         self.cfg, self.dev, self.world, self.cv_weight = cfg, torch.device(device), int(world), float(cv_weight)
         if tasks is None:
             tasks = list(range(cfg.num_tasks)) if (cfg.multi_gate or cfg.gate_task_specific_dim >= 0) else [None]
@@ -35,10 +35,11 @@ class MultiTaskStep:
         wg = bool(wgrad_streams) and not self.use_ep
         self.eng = BackboneEngine(cfg, params, batch=batch, dtype=dtype, device=str(self.dev),
                                   ep_world=self.world if self.use_ep else 1, ep_rank=rank if self.use_ep else 0,
-                                  wgrad_stream=wg)
+                                  wgrad_stream=wg, checkpoint=checkpoint)
         self.par = bool(parallel_tasks) and not self.use_ep and len(self.tasks) > 1
         self.engs = [self.eng] + ([BackboneEngine(cfg, None, batch=batch, dtype=dtype, device=str(self.dev), share=self.eng,
-                                                   wgrad_stream=wg) for _ in self.tasks[1:]] if self.par else [])
+                                                   wgrad_stream=wg, checkpoint=checkpoint) for _ in self.tasks[1:]]
+                                    if self.par else [])
         self.streams = [torch.cuda.Stream(device=self.dev) for _ in self.engs[1:]]
         self.flat = self.eng.flat_grads
         # cutting the step only makes sense when there is a collective to hide and the passes run side by side

@@ -477,3 +477,55 @@ def test_multitask_step_data_parallel_parts(task_cond):
     finally:
         if own_group:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_checkpoint_mode_recomputes_bit_identically(dtype):
+    """BackboneEngine(checkpoint=True) - the reference's default memory mode (train_fastmoe.py:178,
+    vision_transformer_moe.py:495-524: torch.utils.checkpoint around every block): one shared set of activation buffers,
+    each block's forward re-run right before its backward.  Same kernels on the same inputs: tokens, balance loss and
+    every gradient must be bit-identical to the keep-everything mode; with DropPath, noisy gating, a task-conditioned
+    gate; through the step runner's hipGraph as well; and the activation footprint must shrink."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from m3vit_amd.engine import BackboneEngine
+    from m3vit_amd.step import MultiTaskStep
+    from oracle import ref_torch as R
+    cfg = R.BackboneCfg(img_size=(64, 64), embed_dim=64, depth=6, num_heads=2, mlp_ratio=4.0, moe_mlp_ratio=1.0,
+                        moe_experts=8, moe_top_k=2, gate_dim=66, multi_gate=True, vmoe_noisy_std=1.0)
+    P = R.init_backbone_params(cfg, seed=5)
+    torch.manual_seed(11)
+    B = 6
+    img = torch.randn(B, 3, 64, 64).cuda()
+    dtok = (torch.randn(B, cfg.num_tokens, 64) * 0.1).cuda()
+    T = B * cfg.num_tokens
+    noises = {i: torch.randn(T, 8).cuda() for i in (1, 3, 5)}
+    keep = 0.8
+    ps = {i: tuple(((torch.rand(B) < keep).float() / keep).cuda() for _ in range(2)) for i in range(cfg.depth)}
+    out = []
+    for ck in (False, True):
+        e = BackboneEngine(cfg, P, batch=B, dtype=dtype, checkpoint=ck)
+        e.prepare_weights(); e.zero_grad()
+        tok, cv = e.forward(img, 1, noises=noises, path_scales=ps)
+        tok = tok.clone()
+        e.backward(dtok, cv_weight=0.01)
+        torch.cuda.synchronize()
+        act_bytes = sum(v.numel() * v.element_size() for v in
+                        {t.data_ptr(): t for a in e.act for t in a.values() if isinstance(t, torch.Tensor)}.values())
+        out.append((tok, float(cv), e.flat_grads.clone(), act_bytes))
+        del e
+    (t0, c0, g0, m0), (t1, c1, g1, m1) = out
+    assert torch.equal(t0, t1) and c0 == c1 and torch.equal(g0, g1)
+    assert float(g0.abs().max()) > 0
+    assert m1 < 0.45 * m0, (m0, m1)              # 6 blocks -> one dense + one MoE set (+ the 6 block outputs)
+    # the step runner (two task streams + hipGraph) in checkpoint mode against the plain serial step
+    cfg.vmoe_noisy_std = 0.0
+    ref = MultiTaskStep(cfg, P, batch=B, dtype=dtype, cv_weight=0.01)
+    ref.bind(img, dtok); ref.serial_step(); torch.cuda.synchronize()
+    run = MultiTaskStep(cfg, P, batch=B, dtype=dtype, cv_weight=0.01, checkpoint=True)
+    run.bind(img, dtok)
+    run.step(); torch.cuda.synchronize()
+    assert rel(run.flat, ref.flat) < 1e-5
+    assert run.capture()
+    run.flat.fill_(3.0); run.step(); torch.cuda.synchronize()
+    assert rel(run.flat, ref.flat) < 1e-5
