@@ -14,7 +14,7 @@
  *   - return value: 0 = ok, negative = M3_ERR_* ; m3_last_error() gives the text of
  *     the last failure on the calling thread.  Shape/alignment violations are
  *     rejected on the host before anything is launched.
- *   - dtype codes (M3_F32, M3_F16) describe ACTIVATION storage; accumulation is
+ *   - dtype codes (M3_F32, M3_F16, M3_BF16) describe ACTIVATION storage; accumulation is
  *     always fp32; parameters/gradients of parameters are fp32.
  *   - indices are int32 on the device-internal path and int64 where the reference
  *     API exposes them (gate_top_k_idx from torch.topk).
@@ -30,6 +30,7 @@ extern "C" {
 
 #define M3_F32 0
 #define M3_F16 1
+#define M3_BF16 2            /* every entry point except m3_attention_* and m3_ffn_fwd (fp16 / fp32 there) */
 
 #define M3_OK 0
 #define M3_ERR_ARG (-1)      /* bad shape / alignment / null pointer */
@@ -170,7 +171,7 @@ typedef struct {
   int32_t G;
   const int32_t *group_offsets;    /* [G+1] device, or NULL for dense */
   const int32_t *tile_starts;      /* [G+1] device, or NULL for dense */
-  int32_t dtype;                   /* M3_F32 / M3_F16: element type of A, B, pre */
+  int32_t dtype;                   /* M3_F32 / M3_F16 / M3_BF16: element type of A, B, pre */
   const float *row_scale;          /* fp32 [ceil(rows / row_scale_div)] or NULL */
   int32_t row_scale_div;
 } m3_gemm_args;

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("M3VIT_LIB") or os.path.join(_HERE, "libm3vit_hip.so")   # M3VIT_LIB: diagnostic builds
 
-M3_F32, M3_F16 = 0, 1
+M3_F32, M3_F16, M3_BF16 = 0, 1, 2
 M3_ACT_NONE, M3_ACT_GELU = 0, 1
 
 

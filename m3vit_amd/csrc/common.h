@@ -10,6 +10,9 @@
 namespace m3 {
 
 typedef _Float16 half_t;
+typedef __bf16 bf16_t;                   // the third activation dtype (M3_BF16): everything but the attention kernels
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -86,6 +89,27 @@ template <> struct Mma<half_t> {
   static __device__ __forceinline__ half_t from_float(float v) { return (half_t)v; }
 };
 
+template <> struct Mma<bf16_t> {             // same fragment geometry as f16: one v_mfma_f32_16x16x32_bf16 per fragment pair
+  typedef bf16x8 frag;
+  static constexpr int KC = 32;
+  static constexpr int EPL = 8;
+  static constexpr int CT = 2;
+  static __device__ __forceinline__ f32x4 mma(const frag &a, const frag &b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ frag zero() {
+    return frag{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+  }
+  static __device__ __forceinline__ frag from_tiles(const f32x4 *t) {
+    frag f;
+    f[0] = (bf16_t)t[0][0]; f[1] = (bf16_t)t[0][1]; f[2] = (bf16_t)t[0][2]; f[3] = (bf16_t)t[0][3];
+    f[4] = (bf16_t)t[1][0]; f[5] = (bf16_t)t[1][1]; f[6] = (bf16_t)t[1][2]; f[7] = (bf16_t)t[1][3];
+    return f;
+  }
+  static __device__ __forceinline__ float to_float(bf16_t v) { return (float)v; }
+  static __device__ __forceinline__ bf16_t from_float(float v) { return (bf16_t)v; }
+};
+
 // 4 consecutive elements of T <-> f32x4
 template <typename T> struct Vec4;
 template <> struct Vec4<float> {
@@ -103,6 +127,19 @@ template <> struct Vec4<half_t> {
     f16x4 h;
     h[0] = (half_t)v[0]; h[1] = (half_t)v[1]; h[2] = (half_t)v[2]; h[3] = (half_t)v[3];
     *(f16x4 *)p = h;
+  }
+};
+
+template <> struct Vec4<bf16_t> {
+  typedef bf16x4 type;
+  static __device__ __forceinline__ f32x4 load(const bf16_t *p) {
+    bf16x4 h = *(const bf16x4 *)p;
+    return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+  }
+  static __device__ __forceinline__ void store(bf16_t *p, f32x4 v) {
+    bf16x4 h;
+    h[0] = (bf16_t)v[0]; h[1] = (bf16_t)v[1]; h[2] = (bf16_t)v[2]; h[3] = (bf16_t)v[3];
+    *(bf16x4 *)p = h;
   }
 };
 
@@ -124,6 +161,20 @@ template <> struct Vec8<half_t> {
     h[0] = (half_t)a[0]; h[1] = (half_t)a[1]; h[2] = (half_t)a[2]; h[3] = (half_t)a[3];
     h[4] = (half_t)b[0]; h[5] = (half_t)b[1]; h[6] = (half_t)b[2]; h[7] = (half_t)b[3];
     *(f16x8 *)p = h;
+  }
+};
+
+template <> struct Vec8<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t *p, f32x4 &a, f32x4 &b) {
+    const bf16x8 h = *(const bf16x8 *)p;
+    a = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    b = f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+  }
+  static __device__ __forceinline__ void store(bf16_t *p, f32x4 a, f32x4 b) {
+    bf16x8 h;
+    h[0] = (bf16_t)a[0]; h[1] = (bf16_t)a[1]; h[2] = (bf16_t)a[2]; h[3] = (bf16_t)a[3];
+    h[4] = (bf16_t)b[0]; h[5] = (bf16_t)b[1]; h[6] = (bf16_t)b[2]; h[7] = (bf16_t)b[3];
+    *(bf16x8 *)p = h;
   }
 };
 
@@ -181,6 +232,7 @@ int launch_reduce_rows2_f32(const float *part, int nrows, int N, float *out0, fl
 int launch_reduce_rows_i32(const int32_t *part, int nrows, int N, int G, int64_t gstride, int64_t *out, int beta,
                            hipStream_t s);
 
-static inline int dtype_size(int dt) { return dt == M3_F16 ? 2 : 4; }
+static inline int dtype_size(int dt) { return (dt == M3_F16 || dt == M3_BF16) ? 2 : 4; }
+static inline bool dtype_ok(int dt) { return dt == M3_F32 || dt == M3_F16 || dt == M3_BF16; }
 
 }  // namespace m3

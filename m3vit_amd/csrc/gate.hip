@@ -102,7 +102,8 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
       const int row = q / CPR, c = q % CPR;
       float *dst = &sx[buf][row * LDS_STRIDE + c * EPC];
       if constexpr (sizeof(T) == 2) {
-        const f16x8 h = __builtin_bit_cast(f16x8, pre[i]);
+        typedef T t16x8 __attribute__((ext_vector_type(8)));          // fp16 or bf16 rows
+        const t16x8 h = __builtin_bit_cast(t16x8, pre[i]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) dst[j] = (float)h[j];
       } else {
@@ -510,7 +511,7 @@ static int epad8_of(int E) { return E <= 8 ? 8 : E <= 16 ? 16 : E <= 32 ? 32 : 6
 extern "C" int m3_gate_fwd(const m3_gate_fwd_args *a, void *stream) {
   M3_REQUIRE(a && a->x && a->w_gate && a->idx && a->score && a->top_logits && a->part_importance && a->part_load,
              "m3_gate_fwd: null operand");
-  M3_REQUIRE(a->x_dtype == M3_F32 || a->x_dtype == M3_F16, "m3_gate_fwd: bad dtype");
+  M3_REQUIRE(dtype_ok(a->x_dtype), "m3_gate_fwd: bad dtype");
   M3_REQUIRE(a->E >= 2 && a->E <= 64, "m3_gate_fwd: E=%d outside [2,64]", a->E);
   M3_REQUIRE(a->k >= 1 && a->k <= 8 && a->k <= a->E, "m3_gate_fwd: k=%d invalid for E=%d", a->k, a->E);
   const int es = dtype_size(a->x_dtype);
@@ -529,6 +530,7 @@ extern "C" int m3_gate_fwd(const m3_gate_fwd_args *a, void *stream) {
   const dim3 grid((unsigned)m3_gate_num_blocks(a->T));
   hipStream_t s = (hipStream_t)stream;
   if (a->x_dtype == M3_F16) return launch_gate_fwd<half_t>(epad_of(a->E), grid, s, d);
+  else if (a->x_dtype == M3_BF16) return launch_gate_fwd<bf16_t>(epad_of(a->E), grid, s, d);
   return launch_gate_fwd<float>(epad_of(a->E), grid, s, d);
 }
 
@@ -584,7 +586,7 @@ extern "C" int m3_gate_bwd_params(const void *x, int x_dtype, int64_t T, int D, 
                                   int E, const float *d_logits, float *part_dw, float *d_w_gate, int beta_dw,
                                   float *dx, int64_t lddx, int beta_dx, void *stream) {
   M3_REQUIRE(x && w_gate && d_logits, "m3_gate_bwd_params: null operand");
-  M3_REQUIRE(x_dtype == M3_F32 || x_dtype == M3_F16, "m3_gate_bwd_params: bad dtype");
+  M3_REQUIRE(dtype_ok(x_dtype), "m3_gate_bwd_params: bad dtype");
   M3_REQUIRE(E >= 2 && E <= 64 && D > 0 && D <= 1024, "m3_gate_bwd_params: E in [2,64], D <= 1024");
   M3_REQUIRE((d_w_gate == nullptr) == (part_dw == nullptr), "m3_gate_bwd_params: part_dw and d_w_gate go together");
   if (T == 0) return M3_OK;
@@ -600,6 +602,9 @@ extern "C" int m3_gate_bwd_params(const void *x, int x_dtype, int64_t T, int D, 
     if (x_dtype == M3_F16) {
       if (ep == 8) M3_DW_CASE(half_t, 8); else if (ep == 16) M3_DW_CASE(half_t, 16);
       else if (ep == 32) M3_DW_CASE(half_t, 32); else M3_DW_CASE(half_t, 64);
+    } else if (x_dtype == M3_BF16) {
+      if (ep == 8) M3_DW_CASE(bf16_t, 8); else if (ep == 16) M3_DW_CASE(bf16_t, 16);
+      else if (ep == 32) M3_DW_CASE(bf16_t, 32); else M3_DW_CASE(bf16_t, 64);
     } else {
       if (ep == 8) M3_DW_CASE(float, 8); else if (ep == 16) M3_DW_CASE(float, 16);
       else if (ep == 32) M3_DW_CASE(float, 32); else M3_DW_CASE(float, 64);

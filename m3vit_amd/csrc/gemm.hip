@@ -904,7 +904,7 @@ extern "C" int m3_gemm_set_variant(int ws_mask) {
 
 extern "C" int m3_gemm_nt(const m3_gemm_args *a, void *stream) {
   M3_REQUIRE(a && a->A && a->B && a->C, "m3_gemm_nt: null operand");
-  M3_REQUIRE(a->dtype == M3_F32 || a->dtype == M3_F16, "m3_gemm_nt: bad dtype %d", a->dtype);
+  M3_REQUIRE(dtype_ok(a->dtype), "m3_gemm_nt: bad dtype %d", a->dtype);
   const int es = dtype_size(a->dtype);
   M3_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0, "m3_gemm_nt: bad shape M=%lld N=%d K=%d", (long long)a->M, a->N, a->K);
   M3_REQUIRE((a->K * es) % 16 == 0, "m3_gemm_nt: K*elem (%d) must be a multiple of 16 bytes", a->K * es);
@@ -989,8 +989,9 @@ extern "C" int m3_gemm_nt(const m3_gemm_args *a, void *stream) {
   static int dma_mode = -1;
   if (dma_mode < 0) { const char *e = getenv("M3_GEMM_DMA"); dma_mode = e ? (atoi(e) ? 1 : 0) : 2; }
   const bool dma_ok = d.vec8 && (a->K * es) % DMA_RB == 0;
-  if (dma_ok && (dma_mode == 1 || (dma_mode == 2 && a->dtype == M3_F16))) {
+  if (dma_ok && (dma_mode == 1 || (dma_mode == 2 && es == 2))) {
     if (a->dtype == M3_F16) hipLaunchKernelGGL((gemm_nt_dma_kernel<half_t>), grid, block, DMA_LDS, s, d);
+    else if (a->dtype == M3_BF16) hipLaunchKernelGGL((gemm_nt_dma_kernel<bf16_t>), grid, block, DMA_LDS, s, d);
     else hipLaunchKernelGGL((gemm_nt_dma_kernel<float>), grid, block, DMA_LDS, s, d);
     return check_launch("m3_gemm_nt");
   }
@@ -998,6 +999,9 @@ extern "C" int m3_gemm_nt(const m3_gemm_args *a, void *stream) {
   if (a->dtype == M3_F16) {
     if (ktail) hipLaunchKernelGGL((gemm_nt_kernel<half_t, true>), grid, block, lds, s, d);
     else hipLaunchKernelGGL((gemm_nt_kernel<half_t, false>), grid, block, lds, s, d);
+  } else if (a->dtype == M3_BF16) {
+    if (ktail) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, true>), grid, block, lds, s, d);
+    else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, false>), grid, block, lds, s, d);
   } else {
     if (ktail) hipLaunchKernelGGL((gemm_nt_kernel<float, true>), grid, block, lds, s, d);
     else hipLaunchKernelGGL((gemm_nt_kernel<float, false>), grid, block, lds, s, d);

@@ -305,12 +305,14 @@ static inline unsigned row_blocks(int64_t T) { return (unsigned)((T + 3) / 4); }
 extern "C" int m3_combine_fwd(const void *y, int dtype, const float *score, const float *residual, int64_t T, int k,
                               int D, float *out, void *stream) {
   M3_REQUIRE(y && score && out, "m3_combine_fwd: null operand");
-  M3_REQUIRE(dtype == M3_F32 || dtype == M3_F16, "m3_combine_fwd: bad dtype");
+  M3_REQUIRE(dtype_ok(dtype), "m3_combine_fwd: bad dtype");
   M3_REQUIRE(D % 4 == 0 && D > 0 && k >= 1, "m3_combine_fwd: D must be a multiple of 4");
   if (T == 0) return M3_OK;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == M3_F16)
     hipLaunchKernelGGL(combine_fwd_kernel<half_t>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, (const half_t *)y,
+                       score, residual, T, k, D, out);
+  else if (dtype == M3_BF16)     hipLaunchKernelGGL(combine_fwd_kernel<bf16_t>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, (const bf16_t *)y,
                        score, residual, T, k, D, out);
   else
     hipLaunchKernelGGL(combine_fwd_kernel<float>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, (const float *)y, score,
@@ -321,13 +323,15 @@ extern "C" int m3_combine_fwd(const void *y, int dtype, const float *score, cons
 extern "C" int m3_combine_bwd(const float *dout, const void *y, int dtype, const float *score, int64_t T, int k, int D,
                               void *dy, float *dscore, void *stream) {
   M3_REQUIRE(dout && y && score && dy && dscore, "m3_combine_bwd: null operand");
-  M3_REQUIRE(dtype == M3_F32 || dtype == M3_F16, "m3_combine_bwd: bad dtype");
+  M3_REQUIRE(dtype_ok(dtype), "m3_combine_bwd: bad dtype");
   M3_REQUIRE(D % 4 == 0 && D > 0 && k >= 1, "m3_combine_bwd: D must be a multiple of 4");
   if (T == 0) return M3_OK;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == M3_F16)
     hipLaunchKernelGGL(combine_bwd_kernel<half_t>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, dout,
                        (const half_t *)y, score, T, k, D, (half_t *)dy, dscore);
+  else if (dtype == M3_BF16)     hipLaunchKernelGGL(combine_bwd_kernel<bf16_t>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, dout,
+                       (const bf16_t *)y, score, T, k, D, (bf16_t *)dy, dscore);
   else
     hipLaunchKernelGGL(combine_bwd_kernel<float>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, dout, (const float *)y,
                        score, T, k, D, (float *)dy, dscore);
@@ -337,13 +341,15 @@ extern "C" int m3_combine_bwd(const float *dout, const void *y, int dtype, const
 extern "C" int m3_layernorm_fwd(const float *x, int64_t T, int D, const float *gamma, const float *beta, float eps,
                                 void *y, int y_dtype, float *mean, float *rstd, void *stream) {
   M3_REQUIRE(x && gamma && beta && y && mean && rstd, "m3_layernorm_fwd: null operand");
-  M3_REQUIRE(y_dtype == M3_F32 || y_dtype == M3_F16, "m3_layernorm_fwd: bad dtype");
+  M3_REQUIRE(dtype_ok(y_dtype), "m3_layernorm_fwd: bad dtype");
   M3_REQUIRE(D % 4 == 0 && D > 0 && D <= 1024, "m3_layernorm_fwd: D must be a multiple of 4 and <= 1024 (got %d)", D);
   if (T == 0) return M3_OK;
   hipStream_t s = (hipStream_t)stream;
   if (y_dtype == M3_F16)
     hipLaunchKernelGGL(layernorm_fwd_kernel<half_t>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, x, T, D, gamma, beta,
                        eps, (half_t *)y, mean, rstd);
+  else if (y_dtype == M3_BF16)     hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, x, T, D, gamma, beta,
+                       eps, (bf16_t *)y, mean, rstd);
   else
     hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, x, T, D, gamma, beta,
                        eps, (float *)y, mean, rstd);
@@ -356,8 +362,8 @@ extern "C" int m3_layernorm_bwd(const void *dy, int dy_dtype, const float *x, co
                                 const float *gamma, const float *dx_res, int64_t T, int D, float *dx, float *ws,
                                 float *dgamma, float *dbeta, int beta, void *dx_act, int dx_act_dtype, void *stream) {
   M3_REQUIRE(dy && x && mean && rstd && gamma && dx && ws && dgamma && dbeta, "m3_layernorm_bwd: null operand");
-  M3_REQUIRE(dy_dtype == M3_F32 || dy_dtype == M3_F16, "m3_layernorm_bwd: bad dtype");
-  M3_REQUIRE(!dx_act || dx_act_dtype == M3_F32 || dx_act_dtype == M3_F16, "m3_layernorm_bwd: bad dx_act dtype");
+  M3_REQUIRE(dtype_ok(dy_dtype), "m3_layernorm_bwd: bad dtype");
+  M3_REQUIRE(!dx_act || dtype_ok(dx_act_dtype), "m3_layernorm_bwd: bad dx_act dtype");
   M3_REQUIRE(D % 4 == 0 && D > 0 && D <= 1024, "m3_layernorm_bwd: D must be a multiple of 4 and <= 1024");
   if (T == 0) return M3_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -367,8 +373,12 @@ extern "C" int m3_layernorm_bwd(const void *dy, int dy_dtype, const float *x, co
 #define M3_LNB(TT, TA)                                                                                         \
   hipLaunchKernelGGL((layernorm_bwd_kernel<TT, TA>), dim3(nblk), dim3(LNB_THREADS), lds, s, (const TT *)dy, x, \
                      mean, rstd, gamma, dx_res, T, D, dx, ws, (TA *)dx_act)
+  const bool ab16 = dx_act && dx_act_dtype == M3_BF16;
+  // (the activation-dtype copy of dx has the dtype of the incoming gradient or is fp32; mixed 16-bit pairs are not built)
+  M3_REQUIRE(!(a16 && dy_dtype == M3_BF16) && !(ab16 && dy_dtype == M3_F16), "m3_layernorm_bwd: dy fp16 with dx_act bf16 (or the reverse) is not supported");
   if (dy_dtype == M3_F16) { if (a16) M3_LNB(half_t, half_t); else M3_LNB(half_t, float); }
-  else { if (a16) M3_LNB(float, half_t); else M3_LNB(float, float); }
+  else if (dy_dtype == M3_BF16) { if (ab16) M3_LNB(bf16_t, bf16_t); else M3_LNB(bf16_t, float); }
+  else { if (a16) M3_LNB(float, half_t); else if (ab16) M3_LNB(float, bf16_t); else M3_LNB(float, float); }
 #undef M3_LNB
   int rc = check_launch("m3_layernorm_bwd");
   if (rc) return rc;
@@ -378,10 +388,11 @@ extern "C" int m3_layernorm_bwd(const void *dy, int dy_dtype, const float *x, co
 extern "C" int m3_cast_matrix(const float *src, int G, int rows, int cols, int transpose, void *dst, int dst_dtype,
                               void *stream) {
   M3_REQUIRE(src && dst && G >= 1 && rows > 0 && cols > 0, "m3_cast_matrix: bad args");
-  M3_REQUIRE(dst_dtype == M3_F32 || dst_dtype == M3_F16, "m3_cast_matrix: bad dtype");
+  M3_REQUIRE(dtype_ok(dst_dtype), "m3_cast_matrix: bad dtype");
   const dim3 grid((cols + 31) / 32, (rows + 31) / 32, G), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (dst_dtype == M3_F16) hipLaunchKernelGGL(cast_matrix_kernel<half_t>, grid, block, 0, s, src, rows, cols, transpose, (half_t *)dst);
+  else if (dst_dtype == M3_BF16) hipLaunchKernelGGL(cast_matrix_kernel<bf16_t>, grid, block, 0, s, src, rows, cols, transpose, (bf16_t *)dst);
   else hipLaunchKernelGGL(cast_matrix_kernel<float>, grid, block, 0, s, src, rows, cols, transpose, (float *)dst);
   return check_launch("m3_cast_matrix");
 }
@@ -389,10 +400,11 @@ extern "C" int m3_cast_matrix(const float *src, int G, int rows, int cols, int t
 extern "C" int m3_cast_batch(const m3_cast_desc *descs_dev, int n_desc, int total_tiles, int dst_dtype, void *stream) {
   static_assert(sizeof(m3_cast_desc) == sizeof(CastDesc), "descriptor layout");
   M3_REQUIRE(descs_dev && n_desc >= 1 && total_tiles >= 1, "m3_cast_batch: bad args");
-  M3_REQUIRE(dst_dtype == M3_F32 || dst_dtype == M3_F16, "m3_cast_batch: bad dtype");
+  M3_REQUIRE(dtype_ok(dst_dtype), "m3_cast_batch: bad dtype");
   hipStream_t s = (hipStream_t)stream;
   const CastDesc *d = (const CastDesc *)descs_dev;
   if (dst_dtype == M3_F16) hipLaunchKernelGGL(cast_batch_kernel<half_t>, dim3(total_tiles), dim3(256), 0, s, d, n_desc);
+  else if (dst_dtype == M3_BF16) hipLaunchKernelGGL(cast_batch_kernel<bf16_t>, dim3(total_tiles), dim3(256), 0, s, d, n_desc);
   else hipLaunchKernelGGL(cast_batch_kernel<float>, dim3(total_tiles), dim3(256), 0, s, d, n_desc);
   return check_launch("m3_cast_batch");
 }
@@ -409,12 +421,13 @@ extern "C" int m3_add_f32(float *dst, const float *src, int64_t n, void *stream)
 
 extern "C" int m3_cast_f32(const float *src, int64_t n, void *dst, int dst_dtype, void *stream) {
   M3_REQUIRE(src && dst && n >= 0 && n % 4 == 0, "m3_cast_f32: n must be a multiple of 4");
-  M3_REQUIRE(dst_dtype == M3_F32 || dst_dtype == M3_F16, "m3_cast_f32: bad dtype");
+  M3_REQUIRE(dtype_ok(dst_dtype), "m3_cast_f32: bad dtype");
   if (n == 0) return M3_OK;
   const int64_t n4 = n / 4;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)((n4 + 255) / 256)), block(256);
   if (dst_dtype == M3_F16) hipLaunchKernelGGL(cast_f32_kernel<half_t>, grid, block, 0, s, src, n4, (half_t *)dst);
+  else if (dst_dtype == M3_BF16) hipLaunchKernelGGL(cast_f32_kernel<bf16_t>, grid, block, 0, s, src, n4, (bf16_t *)dst);
   else hipLaunchKernelGGL(cast_f32_kernel<float>, grid, block, 0, s, src, n4, (float *)dst);
   return check_launch("m3_cast_f32");
 }
@@ -422,22 +435,24 @@ extern "C" int m3_cast_f32(const float *src, int64_t n, void *dst, int dst_dtype
 extern "C" int m3_scale_rows_cast(const float *src, int64_t rows, int cols, const float *row_scale, int div, void *dst,
                                   int dst_dtype, void *stream) {
   M3_REQUIRE(src && dst && row_scale && rows >= 0 && cols > 0 && cols % 4 == 0 && div >= 1, "m3_scale_rows_cast: bad args");
-  M3_REQUIRE(dst_dtype == M3_F32 || dst_dtype == M3_F16, "m3_scale_rows_cast: bad dtype");
+  M3_REQUIRE(dtype_ok(dst_dtype), "m3_scale_rows_cast: bad dtype");
   if (rows == 0) return M3_OK;
   const int64_t n4 = rows * cols / 4;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)((n4 + 255) / 256)), block(256);
   if (dst_dtype == M3_F16) hipLaunchKernelGGL(scale_rows_cast_kernel<half_t>, grid, block, 0, s, src, n4, cols / 4, row_scale, div, (half_t *)dst);
+  else if (dst_dtype == M3_BF16) hipLaunchKernelGGL(scale_rows_cast_kernel<bf16_t>, grid, block, 0, s, src, n4, cols / 4, row_scale, div, (bf16_t *)dst);
   else hipLaunchKernelGGL(scale_rows_cast_kernel<float>, grid, block, 0, s, src, n4, cols / 4, row_scale, div, (float *)dst);
   return check_launch("m3_scale_rows_cast");
 }
 
 extern "C" int m3_im2row(const float *img, int B, int Cin, int H, int W, int P, void *rows, int dtype, void *stream) {
   M3_REQUIRE(img && rows, "m3_im2row: null operand");
-  M3_REQUIRE(dtype == M3_F32 || dtype == M3_F16, "m3_im2row: bad dtype");
+  M3_REQUIRE(dtype_ok(dtype), "m3_im2row: bad dtype");
   M3_REQUIRE(P % 4 == 0 && H % P == 0 && W % P == 0 && W % 4 == 0, "m3_im2row: P, W must be multiples of 4; H, W multiples of P");
   hipStream_t s = (hipStream_t)stream;
   if (dtype == M3_F16) hipLaunchKernelGGL(im2row_kernel<half_t>, dim3(2048), dim3(256), 0, s, img, B, Cin, H, W, P, (half_t *)rows);
+  else if (dtype == M3_BF16) hipLaunchKernelGGL(im2row_kernel<bf16_t>, dim3(2048), dim3(256), 0, s, img, B, Cin, H, W, P, (bf16_t *)rows);
   else hipLaunchKernelGGL(im2row_kernel<float>, dim3(2048), dim3(256), 0, s, img, B, Cin, H, W, P, (float *)rows);
   return check_launch("m3_im2row");
 }
@@ -480,11 +495,12 @@ __global__ void tokens_bwd_kernel(const float *__restrict__ dtok, int B, int np_
 extern "C" int m3_tokens_bwd(const float *dtok, int B, int np_, int D, void *dpatch, int dtype, float *dpos,
                              float *dcls, int beta, void *stream) {
   M3_REQUIRE(dtok && dpos && dcls && D % 4 == 0, "m3_tokens_bwd: bad args");
-  M3_REQUIRE(dtype == M3_F32 || dtype == M3_F16, "m3_tokens_bwd: bad dtype");
+  M3_REQUIRE(dtype_ok(dtype), "m3_tokens_bwd: bad dtype");
   const int64_t total4 = (int64_t)(np_ + 1) * D / 4;
   const dim3 grid((unsigned)((total4 + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == M3_F16) hipLaunchKernelGGL(m3::tokens_bwd_kernel<m3::half_t>, grid, block, 0, s, dtok, B, np_, D, (m3::half_t *)dpatch, dpos, dcls, beta);
+  else if (dtype == M3_BF16) hipLaunchKernelGGL(m3::tokens_bwd_kernel<m3::bf16_t>, grid, block, 0, s, dtok, B, np_, D, (m3::bf16_t *)dpatch, dpos, dcls, beta);
   else hipLaunchKernelGGL(m3::tokens_bwd_kernel<float>, grid, block, 0, s, dtok, B, np_, D, (float *)dpatch, dpos, dcls, beta);
   return m3::check_launch("m3_tokens_bwd");
 }
@@ -514,11 +530,12 @@ __global__ __launch_bounds__(ROW_THREADS) void gather_rows_kernel(const T *__res
 extern "C" int m3_gather_rows(const void *src, int dtype, const int32_t *idx, int div, int64_t nout, int k, int D,
                               void *dst, void *stream) {
   M3_REQUIRE(src && idx && dst && D % 4 == 0 && D > 0 && k >= 1 && div >= 1, "m3_gather_rows: bad args");
-  M3_REQUIRE(dtype == M3_F32 || dtype == M3_F16, "m3_gather_rows: bad dtype");
+  M3_REQUIRE(dtype_ok(dtype), "m3_gather_rows: bad dtype");
   if (nout == 0) return M3_OK;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)((nout + 3) / 4)), block(m3::ROW_THREADS);
   if (dtype == M3_F16) hipLaunchKernelGGL(m3::gather_rows_kernel<m3::half_t>, grid, block, 0, s, (const m3::half_t *)src, idx, div, nout, k, D, (m3::half_t *)dst);
+  else if (dtype == M3_BF16) hipLaunchKernelGGL(m3::gather_rows_kernel<m3::bf16_t>, grid, block, 0, s, (const m3::bf16_t *)src, idx, div, nout, k, D, (m3::bf16_t *)dst);
   else hipLaunchKernelGGL(m3::gather_rows_kernel<float>, grid, block, 0, s, (const float *)src, idx, div, nout, k, D, (float *)dst);
   return m3::check_launch("m3_gather_rows");
 }

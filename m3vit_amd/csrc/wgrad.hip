@@ -85,6 +85,7 @@ template <typename T> struct WgLds;
 #define M3_WGRAD_WIDE_ROWS 32        // contraction rows per barrier step of the wide-tile kernel
 #endif
 template <> struct WgLds<half_t> { static constexpr int STRIDE = 288; static constexpr int ROWS = M3_WGRAD_F16_ROWS; };
+template <> struct WgLds<bf16_t> { static constexpr int STRIDE = 288; static constexpr int ROWS = M3_WGRAD_F16_ROWS; };
 template <> struct WgLds<float> { static constexpr int STRIDE = 528; static constexpr int ROWS = 32; };
 
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -105,6 +106,12 @@ __device__ __forceinline__ f16x8 read_tr_frag<half_t>(const char *base, int rb, 
   f[0] = (half_t)lo[0]; f[1] = (half_t)lo[1]; f[2] = (half_t)lo[2]; f[3] = (half_t)lo[3];
   f[4] = (half_t)hi[0]; f[5] = (half_t)hi[1]; f[6] = (half_t)hi[2]; f[7] = (half_t)hi[3];
   return f;
+}
+
+template <>
+__device__ __forceinline__ bf16x8 read_tr_frag<bf16_t>(const char *base, int rb, int col, int li, int lg) {
+  // the 16-bit transposed read does not look at the element format: same addressing as f16, bits re-labelled
+  return __builtin_bit_cast(bf16x8, read_tr_frag<half_t>(base, rb, col, li, lg));
 }
 
 template <>
@@ -690,7 +697,7 @@ extern "C" int m3_wgrad_tile(int N, int K, int dtype, int *tn, int *tk) {
 
 extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   M3_REQUIRE(a && a->dC && a->A && a->ws, "m3_wgrad_tn: null operand");
-  M3_REQUIRE(a->dtype == M3_F32 || a->dtype == M3_F16, "m3_wgrad_tn: bad dtype");
+  M3_REQUIRE(dtype_ok(a->dtype), "m3_wgrad_tn: bad dtype");
   const int es = dtype_size(a->dtype);
   M3_REQUIRE(a->N > 0 && a->K > 0 && a->M >= 0 && a->G >= 1 && a->splits >= 1, "m3_wgrad_tn: bad shape");
   M3_REQUIRE(a->M < ((int64_t)1 << 31), "m3_wgrad_tn: M exceeds the 32-bit row indices");
@@ -751,6 +758,10 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
     (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<float, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
     (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<float, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
     (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<float, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
+    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<bf16_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<bf16_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<bf16_t, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<bf16_t, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
     (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<half_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
     (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<half_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
     (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<half_t, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
@@ -758,6 +769,7 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
     attr_set = true;
   }
   if (a->dtype == M3_F16) M3_WG(half_t, lds16);
+  else if (a->dtype == M3_BF16) M3_WG(bf16_t, lds16);
   else M3_WG(float, lds32);
 #undef M3_WG
   return check_launch("m3_wgrad_tn");
@@ -807,7 +819,7 @@ extern "C" int64_t m3_colsum_ws_elems(int64_t M, int N, int G) {
 extern "C" int m3_colsum(const void *dC, int dtype, int64_t lddc, const int32_t *c_row_idx, int64_t M, int N, int G,
                          const int32_t *group_offsets, float *ws, float *db, int beta, void *stream) {
   M3_REQUIRE(dC && ws && db, "m3_colsum: null operand");
-  M3_REQUIRE(dtype == M3_F32 || dtype == M3_F16, "m3_colsum: bad dtype");
+  M3_REQUIRE(dtype_ok(dtype), "m3_colsum: bad dtype");
   M3_REQUIRE(N % 4 == 0 && lddc % 4 == 0 && G >= 1, "m3_colsum: N, lddc must be multiples of 4");
   M3_REQUIRE(G == 1 || group_offsets, "m3_colsum: grouped call needs group_offsets");
   M3_REQUIRE((N * dtype_size(dtype)) % 16 == 0 && (lddc * dtype_size(dtype)) % 16 == 0 && ((uintptr_t)dC % 16) == 0,
@@ -819,6 +831,9 @@ extern "C" int m3_colsum(const void *dC, int dtype, int64_t lddc, const int32_t 
   const dim3 grid((chunks + 63) / 64, spg, G), block(256);
   if (dtype == M3_F16)
     hipLaunchKernelGGL(colsum_part_kernel<half_t>, grid, block, 0, s, (const char *)dC, lddc * es, c_row_idx, M, N,
+                       group_offsets, spg, ws);
+  else if (dtype == M3_BF16)
+    hipLaunchKernelGGL(colsum_part_kernel<bf16_t>, grid, block, 0, s, (const char *)dC, lddc * es, c_row_idx, M, N,
                        group_offsets, spg, ws);
   else
     hipLaunchKernelGGL(colsum_part_kernel<float>, grid, block, 0, s, (const char *)dC, lddc * es, c_row_idx, M, N,

@@ -55,6 +55,7 @@ class BackboneEngine:
         assert not (checkpoint and wgrad_stream), "checkpoint mode re-uses the activation buffers a wgrad stream may still read"
         assert not (checkpoint and ep_world > 1), "checkpoint mode is single-rank (the recompute would repeat the exchanges)"
         self.checkpoint = bool(checkpoint)
+        assert dtype in (torch.float16, torch.float32), "the fused executor runs fp16 or fp32 activations (attention kernels)"
         self.cfg = cfg
         self.dev = torch.device(device)
         self.dt = dtype

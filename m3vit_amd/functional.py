@@ -123,7 +123,7 @@ class LayerNormFn(torch.autograd.Function):
     def backward(ctx, gy):
         x2, gamma, mean, rstd = ctx.saved_tensors
         g = gy.reshape(x2.shape).contiguous()
-        if g.dtype not in (torch.float32, torch.float16):
+        if g.dtype not in (torch.float32, torch.float16, torch.bfloat16):
             g = g.float()
         dx = torch.empty_like(x2)
         dg = torch.empty_like(gamma, dtype=torch.float32)

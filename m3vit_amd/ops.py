@@ -13,16 +13,16 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import M3_ACT_GELU, M3_ACT_NONE, M3_F16, M3_F32, GemmArgs, WgradArgs, check, lib
+from ._lib import M3_ACT_GELU, M3_ACT_NONE, M3_BF16, M3_F16, M3_F32, GemmArgs, WgradArgs, check, lib
 
-_DT = {torch.float32: M3_F32, torch.float16: M3_F16}
+_DT = {torch.float32: M3_F32, torch.float16: M3_F16, torch.bfloat16: M3_BF16}      # bf16: everything but attention / ffn_fwd
 
 
 def dt_code(dtype: torch.dtype) -> int:
     try:
         return _DT[dtype]
     except KeyError:
-        raise _lib.M3Error(f"unsupported activation dtype {dtype}; use float32 or float16")
+        raise _lib.M3Error(f"unsupported activation dtype {dtype}; use float32, float16 or bfloat16")
 
 
 def _p(t: Optional[torch.Tensor]):
