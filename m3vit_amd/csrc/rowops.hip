@@ -105,7 +105,9 @@ constexpr int LNB_WAVES = 8;               // waves per workgroup in the backwar
 constexpr int LNB_THREADS = LNB_WAVES * 64;
 constexpr int LNB_ROWS = LNB_WAVES * 8;    // rows per workgroup (8 per wave): half the dgamma/dbeta partial rows of a 4-wave block
 
-template <typename T, typename TA>
+// NCH = ceil(D / 256): 16-byte chunks per lane (registers are sized for the row width in use: D = 384 -> 2, not 4,
+// which takes the kernel from 116 to ~70 VGPRs and from 4 to 7 waves per SIMD)
+template <typename T, typename TA, int NCH>
 __global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(const T *__restrict__ dy, const float *__restrict__ x,
                                                                     const float *__restrict__ mean,
                                                                     const float *__restrict__ rstd,
@@ -116,17 +118,17 @@ __global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(const T *__r
   extern __shared__ float sred[];   // [LNB_WAVES][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nblk = gridDim.x;
-  f32x4 dg[4], db[4];
+  f32x4 dg[NCH], db[NCH];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { dg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; db[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int i = 0; i < NCH; ++i) { dg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; db[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   for (int r = 0; r < LNB_ROWS / LNB_WAVES; ++r) {
     const int64_t t = (int64_t)blockIdx.x * LNB_ROWS + wave * (LNB_ROWS / LNB_WAVES) + r;
     if (t >= T_) break;
     const float mu = mean[t], rs = rstd[t];
-    f32x4 gdy[4], xh[4];
+    f32x4 gdy[NCH], xh[NCH];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const int d = lane * 4 + i * 256;
       if (d < D) {
         const f32x4 g = *(const f32x4 *)(gamma + d);
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(const T *__r
     }
     const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const int d = lane * 4 + i * 256;
       if (d < D) {
         f32x4 o = (gdy[i] - m1 - xh[i] * m2) * rs;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(const T *__r
   }
   // block partials: waves in order
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int d = lane * 4 + i * 256;
     if (d < D) {
       *(f32x4 *)(sred + (wave * 2 + 0) * D + d) = dg[i];
@@ -370,9 +372,15 @@ extern "C" int m3_layernorm_bwd(const void *dy, int dy_dtype, const float *x, co
   const int nblk = m3_ln_bwd_blocks(T);
   const size_t lds = (size_t)2 * LNB_WAVES * D * sizeof(float);
   const bool a16 = dx_act && dx_act_dtype == M3_F16;
-#define M3_LNB(TT, TA)                                                                                         \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<TT, TA>), dim3(nblk), dim3(LNB_THREADS), lds, s, (const TT *)dy, x, \
+  const int nch = (D + 255) / 256;
+#define M3_LNB_N(TT, TA, NC)                                                                                         \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<TT, TA, NC>), dim3(nblk), dim3(LNB_THREADS), lds, s, (const TT *)dy, x, \
                      mean, rstd, gamma, dx_res, T, D, dx, ws, (TA *)dx_act)
+#define M3_LNB(TT, TA)                                                                   \
+  do {                                                                                   \
+    if (nch == 1) M3_LNB_N(TT, TA, 1); else if (nch == 2) M3_LNB_N(TT, TA, 2);           \
+    else if (nch == 3) M3_LNB_N(TT, TA, 3); else M3_LNB_N(TT, TA, 4);                    \
+  } while (0)
   const bool ab16 = dx_act && dx_act_dtype == M3_BF16;
   // (the activation-dtype copy of dx has the dtype of the incoming gradient or is fp32; mixed 16-bit pairs are not built)
   M3_REQUIRE(!(a16 && dy_dtype == M3_BF16) && !(ab16 && dy_dtype == M3_F16), "m3_layernorm_bwd: dy fp16 with dx_act bf16 (or the reverse) is not supported");
@@ -380,6 +388,7 @@ extern "C" int m3_layernorm_bwd(const void *dy, int dy_dtype, const float *x, co
   else if (dy_dtype == M3_BF16) { if (ab16) M3_LNB(bf16_t, bf16_t); else M3_LNB(bf16_t, float); }
   else { if (a16) M3_LNB(float, half_t); else if (ab16) M3_LNB(float, bf16_t); else M3_LNB(float, float); }
 #undef M3_LNB
+#undef M3_LNB_N
   int rc = check_launch("m3_layernorm_bwd");
   if (rc) return rc;
   return launch_reduce_rows2_f32(ws, nblk, D, dgamma, dbeta, beta, s);
