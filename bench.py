@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK = {"f16": 2500.0, "f32": 157.3}      # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+PEAK = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}      # dense MFMA TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM = 8000.0                          # GB/s, MI355X_MICROARCH.md
 CV_WEIGHT = 0.01                           # --moe_noisy_gate_loss_weight default (train_fastmoe.py:118; applied at train/train_utils.py:277)
 
@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", choices=["f16", "f32"], default="f16")
+    ap.add_argument("--dtype", choices=["f16", "bf16", "f32"], default="f16")
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--checkpoint", action="store_true",
                     help="the reference's default memory mode: keep block inputs only, recompute each block in backward")
@@ -184,7 +184,7 @@ def main():
         Returns the fields of the JSON line that depend on the mode."""
         cfg = BackboneConfig(**VIT_SMALL_MOE)
         torch.cuda.reset_peak_memory_stats(dev)
-        dtype = torch.float16 if dtype_name == "f16" else torch.float32
+        dtype = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[dtype_name]
         params = init_params(cfg, seed=1)                       # same weights on every rank
         # m3vit_amd/step.py: one engine context + HIP stream per task pass, hipGraph capture, and for N > 1 the
         # all-reduce of the upper blocks' gradients overlapped with the lower blocks' backward

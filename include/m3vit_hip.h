@@ -30,7 +30,7 @@ extern "C" {
 
 #define M3_F32 0
 #define M3_F16 1
-#define M3_BF16 2            /* every entry point except m3_attention_* and m3_ffn_fwd (fp16 / fp32 there) */
+#define M3_BF16 2            /* every entry point except m3_ffn_fwd (fp16 there) */
 
 #define M3_OK 0
 #define M3_ERR_ARG (-1)      /* bad shape / alignment / null pointer */

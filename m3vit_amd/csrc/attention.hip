@@ -413,13 +413,13 @@ static size_t attn_bwd_lds() {
 }
 
 // short-sequence fp16 variants (attention_res.hip)
-int launch_attention_fwd_res(const void *qkv, int B, int N, int heads, int dh, void *o, float *lse, float scale,
+int launch_attention_fwd_res(int dtype, const void *qkv, int B, int N, int heads, int dh, void *o, float *lse, float scale,
                              hipStream_t s);
-int launch_attention_fwd_stream(const void *qkv, int B, int N, int heads, int dh, void *o, float *lse, float scale,
+int launch_attention_fwd_stream(int dtype, const void *qkv, int B, int N, int heads, int dh, void *o, float *lse, float scale,
                                 hipStream_t s);
-int launch_attention_bwd_res(const void *qkv, const void *o, const void *d_o, const float *lse, int B, int N, int heads,
+int launch_attention_bwd_res(int dtype, const void *qkv, const void *o, const void *d_o, const float *lse, int B, int N, int heads,
                              int dh, void *dqkv, float scale, hipStream_t s);
-int launch_attention_bwd_stream(const void *qkv, const void *o, const void *d_o, const float *lse, int B, int N, int heads,
+int launch_attention_bwd_stream(int dtype, const void *qkv, const void *o, const void *d_o, const float *lse, int B, int N, int heads,
                                 int dh, void *dqkv, float *dq_ws, float scale, hipStream_t s);
 constexpr int ATTN_RES_MAXN = 256;
 
@@ -430,15 +430,16 @@ using namespace m3;
 extern "C" int m3_attention_fwd(const void *qkv, int dtype, int B, int N, int heads, int dh, void *o, float *lse,
                                 void *stream) {
   M3_REQUIRE(qkv && o && lse, "m3_attention_fwd: null operand");
-  M3_REQUIRE(dtype == M3_F32 || dtype == M3_F16, "m3_attention_fwd: bad dtype");
+  M3_REQUIRE(dtype_ok(dtype), "m3_attention_fwd: bad dtype");
   M3_REQUIRE(dh == 32 || dh == 64, "m3_attention_fwd: head dim %d not in {32, 64}", dh);
   M3_REQUIRE(B > 0 && N > 0 && heads > 0, "m3_attention_fwd: bad shape");
   M3_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)o % 16) == 0, "m3_attention_fwd: alignment");
   const dim3 grid((N + AT_QB - 1) / AT_QB, B * heads), block(AT_THREADS);
   const float scale = 1.0f / sqrtf((float)dh);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == M3_F16 && N <= ATTN_RES_MAXN) return launch_attention_fwd_res(qkv, B, N, heads, dh, o, lse, scale, s);
-  if (dtype == M3_F16) return launch_attention_fwd_stream(qkv, B, N, heads, dh, o, lse, scale, s);
+  const bool b16 = dtype == M3_F16 || dtype == M3_BF16;
+  if (b16 && N <= ATTN_RES_MAXN) return launch_attention_fwd_res(dtype, qkv, B, N, heads, dh, o, lse, scale, s);
+  if (b16) return launch_attention_fwd_stream(dtype, qkv, B, N, heads, dh, o, lse, scale, s);
 #define M3_AF(TT, DD) \
   hipLaunchKernelGGL((attention_fwd_kernel<TT, DD>), grid, block, 0, s, (const TT *)qkv, B, N, heads, (TT *)o, lse, scale)
   if (dtype == M3_F16) { if (dh == 32) M3_AF(half_t, 32); else M3_AF(half_t, 64); }
@@ -476,22 +477,27 @@ extern "C" int64_t m3_attention_bwd_ws_elems(int B, int N, int heads, int dh) {
 extern "C" int m3_attention_bwd(const void *qkv, const void *o, const void *d_o, const float *lse, int dtype, int B,
                                 int N, int heads, int dh, void *dqkv, float *dq_ws, void *stream) {
   M3_REQUIRE(qkv && o && d_o && lse && dqkv, "m3_attention_bwd: null operand");
-  M3_REQUIRE(dtype == M3_F32 || dtype == M3_F16, "m3_attention_bwd: bad dtype");
+  M3_REQUIRE(dtype_ok(dtype), "m3_attention_bwd: bad dtype");
   M3_REQUIRE(dh == 32 || dh == 64, "m3_attention_bwd: head dim %d not in {32, 64}", dh);
   M3_REQUIRE(N > 0, "m3_attention_bwd: bad N");
   M3_REQUIRE(N <= AB_KEYS || dq_ws, "m3_attention_bwd: N=%d > %d needs the fp32 dQ workspace (m3_attention_bwd_ws_elems)", N, AB_KEYS);
   if (N <= AB_KEYS) dq_ws = nullptr;
   const float scale = 1.0f / sqrtf((float)dh);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == M3_F16 && N <= ATTN_RES_MAXN)
-    return launch_attention_bwd_res(qkv, o, d_o, lse, B, N, heads, dh, dqkv, scale, s);
-  if (dtype == M3_F16) {
-    int rc = launch_attention_bwd_stream(qkv, o, d_o, lse, B, N, heads, dh, dqkv, dq_ws, scale, s);
+  const bool b16 = dtype == M3_F16 || dtype == M3_BF16;
+  if (b16 && N <= ATTN_RES_MAXN)
+    return launch_attention_bwd_res(dtype, qkv, o, d_o, lse, B, N, heads, dh, dqkv, scale, s);
+  if (b16) {
+    int rc = launch_attention_bwd_stream(dtype, qkv, o, d_o, lse, B, N, heads, dh, dqkv, dq_ws, scale, s);
     if (rc) return rc;
     const int nkb = (N + AB_KEYS - 1) / AB_KEYS;
     const int64_t n4 = (int64_t)B * heads * N * dh / 4;
-    hipLaunchKernelGGL((attention_dq_reduce_kernel<half_t>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dq_ws, nkb, B,
-                       N, heads, dh, (half_t *)dqkv);
+    if (dtype == M3_BF16)
+      hipLaunchKernelGGL((attention_dq_reduce_kernel<bf16_t>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dq_ws, nkb, B,
+                         N, heads, dh, (bf16_t *)dqkv);
+    else
+      hipLaunchKernelGGL((attention_dq_reduce_kernel<half_t>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dq_ws, nkb, B,
+                         N, heads, dh, (half_t *)dqkv);
     return check_launch("m3_attention_bwd(dq reduce)");
   }
   if (dtype == M3_F16) {

@@ -32,30 +32,28 @@ template <int W> __device__ __forceinline__ int swo(int row, int byte) {
 }
 
 // row fragment: lane (li, lg) <- 8 halves of row (r0 + li), elements 32*ch + 8*lg .. +7
-template <int W> __device__ __forceinline__ f16x8 row_frag(const char *img, int r0, int ch, int li, int lg) {
-  return *(const f16x8 *)(img + swo<W>(r0 + li, ch * 64 + lg * 16));
+template <typename T, int W> __device__ __forceinline__ typename Mma<T>::frag row_frag(const char *img, int r0, int ch, int li, int lg) {
+  return *(const typename Mma<T>::frag *)(img + swo<W>(r0 + li, ch * 64 + lg * 16));
 }
 
 // transposed fragment: lane (li, lg) <- column (col + li), contraction rows rb + {4*lg + r, 16 + 4*lg + r}
-// (the k order of Mma<half_t>::from_tiles, i.e. of an accumulator pair used as the other operand)
-template <int W> __device__ __forceinline__ f16x8 tr_frag(const char *img, int rb, int col, int li, int lg) {
+// (the k order of Mma<T>::from_tiles, i.e. of an accumulator pair used as the other operand)
+template <typename T, int W> __device__ __forceinline__ typename Mma<T>::frag tr_frag(const char *img, int rb, int col, int li, int lg) {
   const int r = rb + 4 * lg + (li >> 2), byte = (col + 4 * (li & 3)) * 2;
   const ar_fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) ar_fp16x4 *)(img + swo<W>(r, byte)));
   const ar_fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) ar_fp16x4 *)(img + swo<W>(r + 16, byte)));
   f16x8 f;
   f[0] = (half_t)lo[0]; f[1] = (half_t)lo[1]; f[2] = (half_t)lo[2]; f[3] = (half_t)lo[3];
   f[4] = (half_t)hi[0]; f[5] = (half_t)hi[1]; f[6] = (half_t)hi[2]; f[7] = (half_t)hi[3];
-  return f;
+  return __builtin_bit_cast(typename Mma<T>::frag, f);   // (the 16-bit transposed read is format-agnostic: fp16 or bf16 bits)
 }
 
-__device__ __forceinline__ f32x4 mma16(const f16x8 &a, const f16x8 &b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
+// (MFMA through Mma<T>::mma: v_mfma_f32_16x16x32_f16 or _bf16)
 
 // ------------------------------------------------------------------------------ forward
-template <int DH>
-__global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_res_kernel(const half_t *__restrict__ qkv, int N, int heads,
-                                                                           half_t *__restrict__ o,
+template <typename T, int DH>
+__global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_res_kernel(const T *__restrict__ qkv, int N, int heads,
+                                                                           T *__restrict__ o,
                                                                            float *__restrict__ lse, float scale) {
   constexpr int RBY = DH * 2, CPR = RBY / 16, NCH = DH / 32, NDT = DH / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -67,19 +65,19 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_res_kernel(const 
   const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / heads, h = bh - b * heads;   // heads of an image share lines
   const int C = heads * DH;
   const int64_t ld = 3 * (int64_t)C;
-  const half_t *qbase = qkv + (int64_t)b * N * ld + h * DH;
-  const half_t *kbase = qbase + C, *vbase = qbase + 2 * C;
+  const T *qbase = qkv + (int64_t)b * N * ld + h * DH;
+  const T *kbase = qbase + C, *vbase = qbase + 2 * C;
 
   // this wave's query tiles {wave, wave + 4, ...}: Q fragments straight from global, all issued up front
   const int nkt = (N + 15) >> 4;                 // key tiles == query tiles
-  f16x8 qfs[AR_MAXN / 64][NCH];
+  typename Mma<T>::frag qfs[AR_MAXN / 64][NCH];
 #pragma unroll
   for (int i = 0; i < AR_MAXN / 64; ++i) {
     const int qrow = (i * 4 + wave) * 16 + li;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      qfs[i][ch] = Mma<half_t>::zero();
-      if (qrow < N) qfs[i][ch] = *(const f16x8 *)(qbase + (int64_t)qrow * ld + ch * 32 + 8 * lg);
+      qfs[i][ch] = Mma<T>::zero();
+      if (qrow < N) qfs[i][ch] = *(const typename Mma<T>::frag *)(qbase + (int64_t)qrow * ld + ch * 32 + 8 * lg);
     }
   }
   // K / V images: ALL loads of the thread are issued before the first LDS store (a rolled loop waits for each
@@ -125,7 +123,7 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_res_kernel(const 
       if (kt < nkt) {
         f32x4 sv = zero4;
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) sv = mma16(row_frag<DH>(sK, kt * 16, ch, li, lg), qfs[i][ch], sv);
+        for (int ch = 0; ch < NCH; ++ch) sv = Mma<T>::mma(row_frag<T, DH>(sK, kt * 16, ch, li, lg), qfs[i][ch], sv);
         if (kt == nkt - 1) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) sv[r] = (kt * 16 + 4 * lg + r < N) ? sv[r] : -INFINITY;
@@ -160,16 +158,16 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_res_kernel(const 
 #pragma unroll
     for (int cc = 0; cc < AR_MAXN / 32; ++cc) {
       if (cc * 2 < nkt) {
-        const f16x8 pf = Mma<half_t>::from_tiles(&st[cc * 2]);
+        const typename Mma<T>::frag pf = Mma<T>::from_tiles(&st[cc * 2]);
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) oacc[dt] = mma16(tr_frag<DH>(sV, cc * 32, dt * 16, li, lg), pf, oacc[dt]);
+        for (int dt = 0; dt < NDT; ++dt) oacc[dt] = Mma<T>::mma(tr_frag<T, DH>(sV, cc * 32, dt * 16, li, lg), pf, oacc[dt]);
       }
     }
     if (qrow < N) {
       const float inv = 1.0f / psum;
-      half_t *orow = o + ((int64_t)b * N + qrow) * C + h * DH;
+      T *orow = o + ((int64_t)b * N + qrow) * C + h * DH;
 #pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) Vec4<half_t>::store(orow + dt * 16 + 4 * lg, oacc[dt] * inv);
+      for (int dt = 0; dt < NDT; ++dt) Vec4<T>::store(orow + dt * 16 + 4 * lg, oacc[dt] * inv);
       if (lg == 0) lse[((int64_t)b * heads + h) * N + qrow] = mx * scale + __logf(psum);
     }
   }
@@ -190,10 +188,10 @@ __device__ unsigned long long g_attn_stamps[ASTAMP_WGS][ASTAMP_N];
 
 // ----------------------------------------------------------------------------- backward
 // NW waves; wave owns key tiles {w, w + NW, ...} (KTW = 16 / NW of them); dQ pieces (2 query tiles x NDT d tiles) = NW
-template <int DH>
+template <typename T, int DH>
 __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attention_bwd_res_kernel(
-    const half_t *__restrict__ qkv, const half_t *__restrict__ o, const half_t *__restrict__ d_o,
-    const float *__restrict__ lse, int N, int heads, half_t *__restrict__ dqkv, float scale) {
+    const T *__restrict__ qkv, const T *__restrict__ o, const T *__restrict__ d_o,
+    const float *__restrict__ lse, int N, int heads, T *__restrict__ dqkv, float scale) {
   constexpr int RBY = DH * 2, CPR = RBY / 16, NCH = DH / 32, NDT = DH / 16;
   constexpr int NW = DH == 32 ? 4 : 8, NT = NW * 64, KTW = (AR_MAXN / 16) / NW;
   static_assert(2 * NDT == NW, "one dQ piece per wave");
@@ -209,11 +207,11 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
   const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / heads, h = bh - b * heads;
   const int C = heads * DH;
   const int64_t ld = 3 * (int64_t)C;
-  const half_t *qbase = qkv + (int64_t)b * N * ld + h * DH;
-  const half_t *kbase = qbase + C, *vbase = qbase + 2 * C;
-  const half_t *obase = o + (int64_t)b * N * C + h * DH;
-  const half_t *dobase = d_o + (int64_t)b * N * C + h * DH;
-  half_t *dqbase = dqkv + (int64_t)b * N * ld + h * DH;
+  const T *qbase = qkv + (int64_t)b * N * ld + h * DH;
+  const T *kbase = qbase + C, *vbase = qbase + 2 * C;
+  const T *obase = o + (int64_t)b * N * C + h * DH;
+  const T *dobase = d_o + (int64_t)b * N * C + h * DH;
+  T *dqbase = dqkv + (int64_t)b * N * ld + h * DH;
   const float *lbase = lse + ((int64_t)b * heads + h) * N;
   ATTN_STAMP(0);
 
@@ -240,7 +238,7 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
 #pragma unroll
     for (int it = 0; it < SIT; ++it) {
       const int q = it * NT + tid, row = q / CPR, c = q % CPR;
-      const f16x8 dh8 = __builtin_bit_cast(f16x8, dv[it]), oh8 = __builtin_bit_cast(f16x8, ov[it]);
+      const typename Mma<T>::frag dh8 = __builtin_bit_cast(typename Mma<T>::frag, dv[it]), oh8 = __builtin_bit_cast(typename Mma<T>::frag, ov[it]);
       float sd = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) sd += (float)dh8[j] * (float)oh8[j];
@@ -261,17 +259,17 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
   for (int q = tid; q < 2 * NP * 4; q += NT) *(u32x4 *)(sdS + q * 16) = u32x4{0u, 0u, 0u, 0u};
   // this wave's key tiles: K / V fragments (B operands) straight from global
   const int nkt = (N + 15) >> 4;
-  f16x8 kf[KTW][NCH], vf[KTW][NCH];
+  typename Mma<T>::frag kf[KTW][NCH], vf[KTW][NCH];
 #pragma unroll
   for (int kt = 0; kt < KTW; ++kt) {
     const int key = (kt * NW + wave) * 16 + li;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      kf[kt][ch] = Mma<half_t>::zero();
-      vf[kt][ch] = Mma<half_t>::zero();
+      kf[kt][ch] = Mma<T>::zero();
+      vf[kt][ch] = Mma<T>::zero();
       if (key < N) {
-        kf[kt][ch] = *(const f16x8 *)(kbase + (int64_t)key * ld + ch * 32 + 8 * lg);
-        vf[kt][ch] = *(const f16x8 *)(vbase + (int64_t)key * ld + ch * 32 + 8 * lg);
+        kf[kt][ch] = *(const typename Mma<T>::frag *)(kbase + (int64_t)key * ld + ch * 32 + 8 * lg);
+        vf[kt][ch] = *(const typename Mma<T>::frag *)(vbase + (int64_t)key * ld + ch * 32 + 8 * lg);
       }
     }
   }
@@ -295,11 +293,11 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
     f32x4 pt[2][KTW], dst[2][KTW];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      f16x8 qfr[NCH], dof[NCH];
+      typename Mma<T>::frag qfr[NCH], dof[NCH];
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
-        qfr[ch] = row_frag<DH>(sQ, qs + qt * 16, ch, li, lg);
-        dof[ch] = row_frag<DH>(sdO, qs + qt * 16, ch, li, lg);
+        qfr[ch] = row_frag<T, DH>(sQ, qs + qt * 16, ch, li, lg);
+        dof[ch] = row_frag<T, DH>(sdO, qs + qt * 16, ch, li, lg);
       }
       float l2[4], dl[4];
 #pragma unroll
@@ -311,8 +309,8 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
           f32x4 s = zero4, dp = zero4;
 #pragma unroll
           for (int ch = 0; ch < NCH; ++ch) {
-            s = mma16(qfr[ch], kf[kt][ch], s);
-            dp = mma16(dof[ch], vf[kt][ch], dp);
+            s = Mma<T>::mma(qfr[ch], kf[kt][ch], s);
+            dp = Mma<T>::mma(dof[ch], vf[kt][ch], dp);
           }
           f32x4 pv;
 #pragma unroll
@@ -330,28 +328,28 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
     ATTN_STAMP(3 + 4 * st);                          // S, dP, P, dS of the step
     // ---- dV^T += dO^T P ; dK^T += Q^T dS   (contraction over the 32 queries of the step)
     {
-      f16x8 aq[NDT], ado[NDT];
+      typename Mma<T>::frag aq[NDT], ado[NDT];
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
-        aq[dt] = tr_frag<DH>(sQ, qs, dt * 16, li, lg);
-        ado[dt] = tr_frag<DH>(sdO, qs, dt * 16, li, lg);
+        aq[dt] = tr_frag<T, DH>(sQ, qs, dt * 16, li, lg);
+        ado[dt] = tr_frag<T, DH>(sdO, qs, dt * 16, li, lg);
       }
 #pragma unroll
       for (int kt = 0; kt < KTW; ++kt) {
         if (kt * NW + wave < nkt) {
           f32x4 tp[2] = {pt[0][kt], pt[1][kt]}, td[2] = {dst[0][kt], dst[1][kt]};
-          const f16x8 pf = Mma<half_t>::from_tiles(tp), dsf = Mma<half_t>::from_tiles(td);
+          const typename Mma<T>::frag pf = Mma<T>::from_tiles(tp), dsf = Mma<T>::from_tiles(td);
 #pragma unroll
           for (int dt = 0; dt < NDT; ++dt) {
-            dvt[dt][kt] = mma16(ado[dt], pf, dvt[dt][kt]);
-            dkt[dt][kt] = mma16(aq[dt], dsf, dkt[dt][kt]);
+            dvt[dt][kt] = Mma<T>::mma(ado[dt], pf, dvt[dt][kt]);
+            dkt[dt][kt] = Mma<T>::mma(aq[dt], dsf, dkt[dt][kt]);
           }
           // dS^T[key][q]: this lane holds 4 consecutive q of one key per (qt, kt) -> one 8-byte store
           const int krow = (kt * NW + wave) * 16 + li;
 #pragma unroll
           for (int qt = 0; qt < 2; ++qt) {
-            f16x4 v = f16x4{(half_t)dst[qt][kt][0], (half_t)dst[qt][kt][1], (half_t)dst[qt][kt][2], (half_t)dst[qt][kt][3]};
-            *(f16x4 *)(dsb + swo<32>(krow, (qt * 16 + 4 * lg) * 2)) = v;
+            typename Vec4<T>::type v = typename Vec4<T>::type{(T)dst[qt][kt][0], (T)dst[qt][kt][1], (T)dst[qt][kt][2], (T)dst[qt][kt][3]};
+            *(typename Vec4<T>::type *)(dsb + swo<32>(krow, (qt * 16 + 4 * lg) * 2)) = v;
           }
         }
       }
@@ -363,19 +361,19 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
     {
       const int qt = wave / NDT, dt = wave - qt * NDT;
       // all fragment reads first (clamped chunk index: always inside the images), then the dependent MFMA chain
-      f16x8 ka[AR_MAXN / 32], da[AR_MAXN / 32];
+      typename Mma<T>::frag ka[AR_MAXN / 32], da[AR_MAXN / 32];
 #pragma unroll
       for (int c = 0; c < AR_MAXN / 32; ++c) {
         const int cc = c < nkc ? c : nkc - 1;
-        ka[c] = tr_frag<DH>(sK, cc * 32, dt * 16, li, lg);
-        da[c] = tr_frag<32>(dsb, cc * 32, qt * 16, li, lg);
+        ka[c] = tr_frag<T, DH>(sK, cc * 32, dt * 16, li, lg);
+        da[c] = tr_frag<T, 32>(dsb, cc * 32, qt * 16, li, lg);
       }
       f32x4 acc = zero4;
 #pragma unroll
       for (int c = 0; c < AR_MAXN / 32; ++c)
-        if (c < nkc) acc = mma16(ka[c], da[c], acc);
+        if (c < nkc) acc = Mma<T>::mma(ka[c], da[c], acc);
       const int qr = qs + qt * 16 + li;
-      if (qr < N) Vec4<half_t>::store(dqbase + (int64_t)qr * ld + dt * 16 + 4 * lg, acc * scale);
+      if (qr < N) Vec4<T>::store(dqbase + (int64_t)qr * ld + dt * 16 + 4 * lg, acc * scale);
     }
     ATTN_STAMP(6 + 4 * st);                          // dQ piece of the step stored
   }
@@ -387,8 +385,8 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
     if (key < N) {
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
-        Vec4<half_t>::store(dqbase + C + (int64_t)key * ld + dt * 16 + 4 * lg, dkt[dt][kt] * scale);
-        Vec4<half_t>::store(dqbase + 2 * C + (int64_t)key * ld + dt * 16 + 4 * lg, dvt[dt][kt]);
+        Vec4<T>::store(dqbase + C + (int64_t)key * ld + dt * 16 + 4 * lg, dkt[dt][kt] * scale);
+        Vec4<T>::store(dqbase + 2 * C + (int64_t)key * ld + dt * 16 + 4 * lg, dvt[dt][kt]);
       }
     }
   }
@@ -403,9 +401,9 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
 // N > 256: one workgroup per (image, head, 64-query block); wave w owns the 16 queries q0 + 16w.  K / V are streamed in
 // 64-key tiles through a two-slot ring of swizzled LDS images (rows prefetched into registers one tile ahead, one
 // barrier per tile), online softmax in the S^T accumulator layout, V read transposed with ds_read_b64_tr_b16.
-template <int DH>
-__global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_stream_kernel(const half_t *__restrict__ qkv, int N, int heads,
-                                                                              half_t *__restrict__ o,
+template <typename T, int DH>
+__global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_stream_kernel(const T *__restrict__ qkv, int N, int heads,
+                                                                              T *__restrict__ o,
                                                                               float *__restrict__ lse, float scale) {
   constexpr int RBY = DH * 2, CPR = RBY / 16, NCH = DH / 32, NDT = DH / 16;
   constexpr int KT = 64;                              // keys per tile
@@ -421,15 +419,15 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_stream_kernel(con
   const int bh = log_id / nqb, b = bh / heads, h = bh - b * heads;
   const int C = heads * DH;
   const int64_t ld = 3 * (int64_t)C;
-  const half_t *qbase = qkv + (int64_t)b * N * ld + h * DH;
-  const half_t *kbase = qbase + C, *vbase = qbase + 2 * C;
+  const T *qbase = qkv + (int64_t)b * N * ld + h * DH;
+  const T *kbase = qbase + C, *vbase = qbase + 2 * C;
 
   const int qrow = qb * 64 + wave * 16 + li;
-  f16x8 qf[NCH];
+  typename Mma<T>::frag qf[NCH];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
-    qf[ch] = Mma<half_t>::zero();
-    if (qrow < N) qf[ch] = *(const f16x8 *)(qbase + (int64_t)qrow * ld + ch * 32 + 8 * lg);
+    qf[ch] = Mma<T>::zero();
+    if (qrow < N) qf[ch] = *(const typename Mma<T>::frag *)(qbase + (int64_t)qrow * ld + ch * 32 + 8 * lg);
   }
   u32x4 rk[NLD], rv[NLD];
   auto fetch = [&](int key0) {
@@ -475,7 +473,7 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_stream_kernel(con
     for (int kt = 0; kt < 4; ++kt) {
       f32x4 sv = zero4;
 #pragma unroll
-      for (int ch = 0; ch < NCH; ++ch) sv = mma16(row_frag<DH>(cK, kt * 16, ch, li, lg), qf[ch], sv);
+      for (int ch = 0; ch < NCH; ++ch) sv = Mma<T>::mma(row_frag<T, DH>(cK, kt * 16, ch, li, lg), qf[ch], sv);
       if (!more) {                                   // only the last tile can hold keys >= N
 #pragma unroll
         for (int r = 0; r < 4; ++r) sv[r] = (key0 + kt * 16 + 4 * lg + r < N) ? sv[r] : -INFINITY;
@@ -503,9 +501,9 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_stream_kernel(con
     for (int dt = 0; dt < NDT; ++dt) oacc[dt] *= alpha;
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
-      const f16x8 pf = Mma<half_t>::from_tiles(&st[cc * 2]);
+      const typename Mma<T>::frag pf = Mma<T>::from_tiles(&st[cc * 2]);
 #pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) oacc[dt] = mma16(tr_frag<DH>(cV, cc * 32, dt * 16, li, lg), pf, oacc[dt]);
+      for (int dt = 0; dt < NDT; ++dt) oacc[dt] = Mma<T>::mma(tr_frag<T, DH>(cV, cc * 32, dt * 16, li, lg), pf, oacc[dt]);
     }
     if (more) stash(buf ^ 1);                        // that slot was last read before the previous barrier
     __syncthreads();
@@ -514,23 +512,24 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_stream_kernel(con
   l_tot += __shfl_xor(l_tot, 32, 64);
   if (qrow < N) {
     const float inv = 1.0f / l_tot;
-    half_t *orow = o + ((int64_t)b * N + qrow) * C + h * DH;
+    T *orow = o + ((int64_t)b * N + qrow) * C + h * DH;
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) Vec4<half_t>::store(orow + dt * 16 + 4 * lg, oacc[dt] * inv);
+    for (int dt = 0; dt < NDT; ++dt) Vec4<T>::store(orow + dt * 16 + 4 * lg, oacc[dt] * inv);
     if (lg == 0) lse[((int64_t)b * heads + h) * N + qrow] = m_run * scale + __logf(l_tot);
   }
 }
 
-int launch_attention_fwd_stream(const void *qkv, int B, int N, int heads, int dh, void *o, float *lse, float scale,
+template <typename T>
+static int launch_attention_fwd_stream_t(const void *qkv, int B, int N, int heads, int dh, void *o, float *lse, float scale,
                                 hipStream_t s) {
   const dim3 grid((N + 63) / 64, B * heads);
   const size_t lds = (size_t)4 * 64 * dh * 2;
   if (dh == 32)
-    hipLaunchKernelGGL(attention_fwd_stream_kernel<32>, grid, dim3(AR_THREADS), lds, s, (const half_t *)qkv, N, heads,
-                       (half_t *)o, lse, scale);
+    hipLaunchKernelGGL((attention_fwd_stream_kernel<T, 32>), grid, dim3(AR_THREADS), lds, s, (const T *)qkv, N, heads,
+                       (T *)o, lse, scale);
   else
-    hipLaunchKernelGGL(attention_fwd_stream_kernel<64>, grid, dim3(AR_THREADS), lds, s, (const half_t *)qkv, N, heads,
-                       (half_t *)o, lse, scale);
+    hipLaunchKernelGGL((attention_fwd_stream_kernel<T, 64>), grid, dim3(AR_THREADS), lds, s, (const T *)qkv, N, heads,
+                       (T *)o, lse, scale);
   return check_launch("m3_attention_fwd");
 }
 
@@ -540,27 +539,27 @@ int launch_attention_fwd_stream(const void *qkv, int B, int N, int heads, int dh
 // step ahead (registers -> the other half of a two-slot LDS ring, visible after the step's single barrier).
 // delta[q] = <dO[q], O[q]> comes from a row kernel run once per call; the key block's dQ contribution goes to an fp32
 // slab summed in key-block order by attention_dq_reduce_kernel (attention.hip).
-template <int DH>
-__global__ __launch_bounds__(64) void attention_delta_kernel(const half_t *__restrict__ o, const half_t *__restrict__ d_o,
+template <typename T, int DH>
+__global__ __launch_bounds__(64) void attention_delta_kernel(const T *__restrict__ o, const T *__restrict__ d_o,
                                                              int64_t rows, int heads, float *__restrict__ delta) {
   // one wave per 64 (token, head) rows; delta laid out [token][head]
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= rows * heads) return;
-  const half_t *po = o + i * DH, *pd = d_o + i * DH;
+  const T *po = o + i * DH, *pd = d_o + i * DH;
   float s = 0.f;
 #pragma unroll
   for (int c = 0; c < DH / 8; ++c) {
-    const f16x8 a = *(const f16x8 *)(po + c * 8), b = *(const f16x8 *)(pd + c * 8);
+    const typename Mma<T>::frag a = *(const typename Mma<T>::frag *)(po + c * 8), b = *(const typename Mma<T>::frag *)(pd + c * 8);
 #pragma unroll
     for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)b[j];
   }
   delta[i] = s;
 }
 
-template <int DH>
+template <typename T, int DH>
 __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attention_bwd_stream_kernel(
-    const half_t *__restrict__ qkv, const half_t *__restrict__ d_o, const float *__restrict__ lse,
-    const float *__restrict__ delta, int N, int heads, half_t *__restrict__ dqkv, float *__restrict__ dq_ws, float scale) {
+    const T *__restrict__ qkv, const T *__restrict__ d_o, const float *__restrict__ lse,
+    const float *__restrict__ delta, int N, int heads, T *__restrict__ dqkv, float *__restrict__ dq_ws, float scale) {
   constexpr int RBY = DH * 2, CPR = RBY / 16, NCH = DH / 32, NDT = DH / 16;
   constexpr int NW = DH == 32 ? 4 : 8, NT = NW * 64, KTW = 16 / NW, KB = 256;
   static_assert(2 * NDT == NW && 32 * CPR * 2 == NT, "one dQ piece and one staged chunk per thread");
@@ -580,10 +579,10 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
   const int kb0 = kbi * KB;
   const int C = heads * DH;
   const int64_t ld = 3 * (int64_t)C;
-  const half_t *qbase = qkv + (int64_t)b * N * ld + h * DH;
-  const half_t *kbase = qbase + C, *vbase = qbase + 2 * C;
-  const half_t *dobase = d_o + (int64_t)b * N * C + h * DH;
-  half_t *dqbase = dqkv + (int64_t)b * N * ld + h * DH;
+  const T *qbase = qkv + (int64_t)b * N * ld + h * DH;
+  const T *kbase = qbase + C, *vbase = qbase + 2 * C;
+  const T *dobase = d_o + (int64_t)b * N * C + h * DH;
+  T *dqbase = dqkv + (int64_t)b * N * ld + h * DH;
   const float *lbase = lse + ((int64_t)b * heads + h) * N;
   const float *dbase = delta + (int64_t)b * N * heads + h;             // [token][head]
   float *dqw = dq_ws + ((int64_t)kbi * (gridDim.x / nkb) + bh) * N * DH;
@@ -599,17 +598,17 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
     *(u32x4 *)(sK + swo<DH>(row, c * 16)) = kv;
   }
   for (int q = tid; q < 2 * KB * 4; q += NT) *(u32x4 *)(sdS + q * 16) = u32x4{0u, 0u, 0u, 0u};
-  f16x8 kf[KTW][NCH], vf[KTW][NCH];
+  typename Mma<T>::frag kf[KTW][NCH], vf[KTW][NCH];
 #pragma unroll
   for (int kt = 0; kt < KTW; ++kt) {
     const int key = kb0 + (kt * NW + wave) * 16 + li;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      kf[kt][ch] = Mma<half_t>::zero();
-      vf[kt][ch] = Mma<half_t>::zero();
+      kf[kt][ch] = Mma<T>::zero();
+      vf[kt][ch] = Mma<T>::zero();
       if (key < N) {
-        kf[kt][ch] = *(const f16x8 *)(kbase + (int64_t)key * ld + ch * 32 + 8 * lg);
-        vf[kt][ch] = *(const f16x8 *)(vbase + (int64_t)key * ld + ch * 32 + 8 * lg);
+        kf[kt][ch] = *(const typename Mma<T>::frag *)(kbase + (int64_t)key * ld + ch * 32 + 8 * lg);
+        vf[kt][ch] = *(const typename Mma<T>::frag *)(vbase + (int64_t)key * ld + ch * 32 + 8 * lg);
       }
     }
   }
@@ -659,11 +658,11 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
     f32x4 pt[2][KTW], dst[2][KTW];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      f16x8 qfr[NCH], dof[NCH];
+      typename Mma<T>::frag qfr[NCH], dof[NCH];
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
-        qfr[ch] = row_frag<DH>(cQ, qt * 16, ch, li, lg);
-        dof[ch] = row_frag<DH>(cdO, qt * 16, ch, li, lg);
+        qfr[ch] = row_frag<T, DH>(cQ, qt * 16, ch, li, lg);
+        dof[ch] = row_frag<T, DH>(cdO, qt * 16, ch, li, lg);
       }
       float l2[4], dl[4];
 #pragma unroll
@@ -675,8 +674,8 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
           f32x4 s = zero4, dp = zero4;
 #pragma unroll
           for (int ch = 0; ch < NCH; ++ch) {
-            s = mma16(qfr[ch], kf[kt][ch], s);
-            dp = mma16(dof[ch], vf[kt][ch], dp);
+            s = Mma<T>::mma(qfr[ch], kf[kt][ch], s);
+            dp = Mma<T>::mma(dof[ch], vf[kt][ch], dp);
           }
           f32x4 pv;
 #pragma unroll
@@ -694,27 +693,27 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
     ATTN_STAMP(3 + 4 * st);                          // S, dP, P, dS of the step
     // ---- dV^T += dO^T P ; dK^T += Q^T dS   (contraction over the 32 queries of the step)
     {
-      f16x8 aq[NDT], ado[NDT];
+      typename Mma<T>::frag aq[NDT], ado[NDT];
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
-        aq[dt] = tr_frag<DH>(cQ, 0, dt * 16, li, lg);
-        ado[dt] = tr_frag<DH>(cdO, 0, dt * 16, li, lg);
+        aq[dt] = tr_frag<T, DH>(cQ, 0, dt * 16, li, lg);
+        ado[dt] = tr_frag<T, DH>(cdO, 0, dt * 16, li, lg);
       }
 #pragma unroll
       for (int kt = 0; kt < KTW; ++kt) {
         if (kt * NW + wave < nkt) {
           f32x4 tp[2] = {pt[0][kt], pt[1][kt]}, td[2] = {dst[0][kt], dst[1][kt]};
-          const f16x8 pf = Mma<half_t>::from_tiles(tp), dsf = Mma<half_t>::from_tiles(td);
+          const typename Mma<T>::frag pf = Mma<T>::from_tiles(tp), dsf = Mma<T>::from_tiles(td);
 #pragma unroll
           for (int dt = 0; dt < NDT; ++dt) {
-            dvt[dt][kt] = mma16(ado[dt], pf, dvt[dt][kt]);
-            dkt[dt][kt] = mma16(aq[dt], dsf, dkt[dt][kt]);
+            dvt[dt][kt] = Mma<T>::mma(ado[dt], pf, dvt[dt][kt]);
+            dkt[dt][kt] = Mma<T>::mma(aq[dt], dsf, dkt[dt][kt]);
           }
           const int krow = (kt * NW + wave) * 16 + li;
 #pragma unroll
           for (int qt = 0; qt < 2; ++qt) {
-            f16x4 v = f16x4{(half_t)dst[qt][kt][0], (half_t)dst[qt][kt][1], (half_t)dst[qt][kt][2], (half_t)dst[qt][kt][3]};
-            *(f16x4 *)(dsb + swo<32>(krow, (qt * 16 + 4 * lg) * 2)) = v;
+            typename Vec4<T>::type v = typename Vec4<T>::type{(T)dst[qt][kt][0], (T)dst[qt][kt][1], (T)dst[qt][kt][2], (T)dst[qt][kt][3]};
+            *(typename Vec4<T>::type *)(dsb + swo<32>(krow, (qt * 16 + 4 * lg) * 2)) = v;
           }
         }
       }
@@ -725,17 +724,17 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
     {
       const int qt = wave / NDT, dt = wave - qt * NDT;
       // all fragment reads first (clamped chunk index: always inside the images), then the dependent MFMA chain
-      f16x8 ka[AR_MAXN / 32], da[AR_MAXN / 32];
+      typename Mma<T>::frag ka[AR_MAXN / 32], da[AR_MAXN / 32];
 #pragma unroll
       for (int c = 0; c < AR_MAXN / 32; ++c) {
         const int cc = c < nkc ? c : nkc - 1;
-        ka[c] = tr_frag<DH>(sK, cc * 32, dt * 16, li, lg);
-        da[c] = tr_frag<32>(dsb, cc * 32, qt * 16, li, lg);
+        ka[c] = tr_frag<T, DH>(sK, cc * 32, dt * 16, li, lg);
+        da[c] = tr_frag<T, 32>(dsb, cc * 32, qt * 16, li, lg);
       }
       f32x4 acc = zero4;
 #pragma unroll
       for (int c = 0; c < AR_MAXN / 32; ++c)
-        if (c < nkc) acc = mma16(ka[c], da[c], acc);
+        if (c < nkc) acc = Mma<T>::mma(ka[c], da[c], acc);
       const int qr = qs + qt * 16 + li;
       if (qr < N) *(f32x4 *)(dqw + (int64_t)qr * DH + dt * 16 + 4 * lg) = acc * scale;
     }
@@ -748,8 +747,8 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
     if (key < N) {
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
-        Vec4<half_t>::store(dqbase + C + (int64_t)key * ld + dt * 16 + 4 * lg, dkt[dt][kt] * scale);
-        Vec4<half_t>::store(dqbase + 2 * C + (int64_t)key * ld + dt * 16 + 4 * lg, dvt[dt][kt]);
+        Vec4<T>::store(dqbase + C + (int64_t)key * ld + dt * 16 + 4 * lg, dkt[dt][kt] * scale);
+        Vec4<T>::store(dqbase + 2 * C + (int64_t)key * ld + dt * 16 + 4 * lg, dvt[dt][kt]);
       }
     }
   }
@@ -758,7 +757,8 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
 size_t attn_stream_bwd_lds(int dh) { return (size_t)256 * dh * 2 + 4 * 32 * dh * 2 + 2 * 256 * 64 + 128 * sizeof(float); }
 
 // dq_ws: [nkb][B*heads][N][dh] slabs followed by delta [B*N*heads]
-int launch_attention_bwd_stream(const void *qkv, const void *o, const void *d_o, const float *lse, int B, int N, int heads,
+template <typename T>
+static int launch_attention_bwd_stream_t(const void *qkv, const void *o, const void *d_o, const float *lse, int B, int N, int heads,
                                 int dh, void *dqkv, float *dq_ws, float scale, hipStream_t s) {
   const int nkb = (N + 255) / 256;
   float *delta = dq_ws + (int64_t)nkb * B * heads * N * dh;
@@ -766,22 +766,22 @@ int launch_attention_bwd_stream(const void *qkv, const void *o, const void *d_o,
   const unsigned dblocks = (unsigned)((rows * heads + 63) / 64);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)attention_bwd_stream_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void *)attention_bwd_stream_kernel<T, 32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)attn_stream_bwd_lds(32));
-    (void)hipFuncSetAttribute((const void *)attention_bwd_stream_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void *)attention_bwd_stream_kernel<T, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)attn_stream_bwd_lds(64));
     attr_set = true;
   }
   if (dh == 32) {
-    hipLaunchKernelGGL(attention_delta_kernel<32>, dim3(dblocks), dim3(64), 0, s, (const half_t *)o, (const half_t *)d_o, rows,
+    hipLaunchKernelGGL((attention_delta_kernel<T, 32>), dim3(dblocks), dim3(64), 0, s, (const T *)o, (const T *)d_o, rows,
                        heads, delta);
-    hipLaunchKernelGGL(attention_bwd_stream_kernel<32>, dim3(B * heads * nkb), dim3(256), attn_stream_bwd_lds(32), s,
-                       (const half_t *)qkv, (const half_t *)d_o, lse, delta, N, heads, (half_t *)dqkv, dq_ws, scale);
+    hipLaunchKernelGGL((attention_bwd_stream_kernel<T, 32>), dim3(B * heads * nkb), dim3(256), attn_stream_bwd_lds(32), s,
+                       (const T *)qkv, (const T *)d_o, lse, delta, N, heads, (T *)dqkv, dq_ws, scale);
   } else {
-    hipLaunchKernelGGL(attention_delta_kernel<64>, dim3(dblocks), dim3(64), 0, s, (const half_t *)o, (const half_t *)d_o, rows,
+    hipLaunchKernelGGL((attention_delta_kernel<T, 64>), dim3(dblocks), dim3(64), 0, s, (const T *)o, (const T *)d_o, rows,
                        heads, delta);
-    hipLaunchKernelGGL(attention_bwd_stream_kernel<64>, dim3(B * heads * nkb), dim3(512), attn_stream_bwd_lds(64), s,
-                       (const half_t *)qkv, (const half_t *)d_o, lse, delta, N, heads, (half_t *)dqkv, dq_ws, scale);
+    hipLaunchKernelGGL((attention_bwd_stream_kernel<T, 64>), dim3(B * heads * nkb), dim3(512), attn_stream_bwd_lds(64), s,
+                       (const T *)qkv, (const T *)d_o, lse, delta, N, heads, (T *)dqkv, dq_ws, scale);
   }
   return check_launch("m3_attention_bwd");
 }
@@ -792,36 +792,55 @@ size_t attn_res_bwd_lds(int N, int dh) {
   return 3 * np * dh * 2 + 2 * np * 64 + 2 * np * sizeof(float);
 }
 
-int launch_attention_fwd_res(const void *qkv, int B, int N, int heads, int dh, void *o, float *lse, float scale,
+template <typename T>
+static int launch_attention_fwd_res_t(const void *qkv, int B, int N, int heads, int dh, void *o, float *lse, float scale,
                              hipStream_t s) {
   const size_t lds = attn_res_fwd_lds(N, dh);
   if (dh == 32)
-    hipLaunchKernelGGL(attention_fwd_res_kernel<32>, dim3(B * heads), dim3(AR_THREADS), lds, s, (const half_t *)qkv, N, heads,
-                       (half_t *)o, lse, scale);
+    hipLaunchKernelGGL((attention_fwd_res_kernel<T, 32>), dim3(B * heads), dim3(AR_THREADS), lds, s, (const T *)qkv, N, heads,
+                       (T *)o, lse, scale);
   else
-    hipLaunchKernelGGL(attention_fwd_res_kernel<64>, dim3(B * heads), dim3(AR_THREADS), lds, s, (const half_t *)qkv, N, heads,
-                       (half_t *)o, lse, scale);
+    hipLaunchKernelGGL((attention_fwd_res_kernel<T, 64>), dim3(B * heads), dim3(AR_THREADS), lds, s, (const T *)qkv, N, heads,
+                       (T *)o, lse, scale);
   return check_launch("m3_attention_fwd");
 }
 
-int launch_attention_bwd_res(const void *qkv, const void *o, const void *d_o, const float *lse, int B, int N, int heads,
+template <typename T>
+static int launch_attention_bwd_res_t(const void *qkv, const void *o, const void *d_o, const float *lse, int B, int N, int heads,
                              int dh, void *dqkv, float scale, hipStream_t s) {
   const size_t lds = attn_res_bwd_lds(N, dh);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)attention_bwd_res_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void *)attention_bwd_res_kernel<T, 32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)attn_res_bwd_lds(AR_MAXN, 32));
-    (void)hipFuncSetAttribute((const void *)attention_bwd_res_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void *)attention_bwd_res_kernel<T, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)attn_res_bwd_lds(AR_MAXN, 64));
     attr_set = true;
   }
   if (dh == 32)
-    hipLaunchKernelGGL(attention_bwd_res_kernel<32>, dim3(B * heads), dim3(256), lds, s, (const half_t *)qkv,
-                       (const half_t *)o, (const half_t *)d_o, lse, N, heads, (half_t *)dqkv, scale);
+    hipLaunchKernelGGL((attention_bwd_res_kernel<T, 32>), dim3(B * heads), dim3(256), lds, s, (const T *)qkv,
+                       (const T *)o, (const T *)d_o, lse, N, heads, (T *)dqkv, scale);
   else
-    hipLaunchKernelGGL(attention_bwd_res_kernel<64>, dim3(B * heads), dim3(512), lds, s, (const half_t *)qkv,
-                       (const half_t *)o, (const half_t *)d_o, lse, N, heads, (half_t *)dqkv, scale);
+    hipLaunchKernelGGL((attention_bwd_res_kernel<T, 64>), dim3(B * heads), dim3(512), lds, s, (const T *)qkv,
+                       (const T *)o, (const T *)d_o, lse, N, heads, (T *)dqkv, scale);
   return check_launch("m3_attention_bwd");
+}
+
+// fp16 / bf16 front doors (attention.hip picks these kernels for every 16-bit dtype)
+int launch_attention_fwd_stream(int dtype, const void *qkv, int B, int N, int heads, int dh, void *o, float *lse, float scale, hipStream_t s) {
+  return dtype == M3_BF16 ? launch_attention_fwd_stream_t<bf16_t>(qkv, B, N, heads, dh, o, lse, scale, s) : launch_attention_fwd_stream_t<half_t>(qkv, B, N, heads, dh, o, lse, scale, s);
+}
+
+int launch_attention_bwd_stream(int dtype, const void *qkv, const void *o, const void *d_o, const float *lse, int B, int N, int heads, int dh, void *dqkv, float *dq_ws, float scale, hipStream_t s) {
+  return dtype == M3_BF16 ? launch_attention_bwd_stream_t<bf16_t>(qkv, o, d_o, lse, B, N, heads, dh, dqkv, dq_ws, scale, s) : launch_attention_bwd_stream_t<half_t>(qkv, o, d_o, lse, B, N, heads, dh, dqkv, dq_ws, scale, s);
+}
+
+int launch_attention_fwd_res(int dtype, const void *qkv, int B, int N, int heads, int dh, void *o, float *lse, float scale, hipStream_t s) {
+  return dtype == M3_BF16 ? launch_attention_fwd_res_t<bf16_t>(qkv, B, N, heads, dh, o, lse, scale, s) : launch_attention_fwd_res_t<half_t>(qkv, B, N, heads, dh, o, lse, scale, s);
+}
+
+int launch_attention_bwd_res(int dtype, const void *qkv, const void *o, const void *d_o, const float *lse, int B, int N, int heads, int dh, void *dqkv, float scale, hipStream_t s) {
+  return dtype == M3_BF16 ? launch_attention_bwd_res_t<bf16_t>(qkv, o, d_o, lse, B, N, heads, dh, dqkv, scale, s) : launch_attention_bwd_res_t<half_t>(qkv, o, d_o, lse, B, N, heads, dh, dqkv, scale, s);
 }
 
 }  // namespace m3

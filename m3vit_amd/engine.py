@@ -55,7 +55,7 @@ class BackboneEngine:
         assert not (checkpoint and wgrad_stream), "checkpoint mode re-uses the activation buffers a wgrad stream may still read"
         assert not (checkpoint and ep_world > 1), "checkpoint mode is single-rank (the recompute would repeat the exchanges)"
         self.checkpoint = bool(checkpoint)
-        assert dtype in (torch.float16, torch.float32), "the fused executor runs fp16 or fp32 activations (attention kernels)"
+        assert dtype in (torch.float16, torch.bfloat16, torch.float32), "activation dtype: float16, bfloat16 or float32"
         self.cfg = cfg
         self.dev = torch.device(device)
         self.dt = dtype
@@ -201,7 +201,7 @@ class BackboneEngine:
         self.ws_dq = self._e(need_dq, dtype=f32) if need_dq else None
         self.ws_gate_dw = self._e(ops.lib().m3_gate_dw_blocks(T) * self.cfg_d_gate() * self.E, dtype=f32)
         # gate backward through the MFMA GEMMs when E rows are 16-byte multiples
-        es = 2 if self.dt == torch.float16 else 4
+        es = 2 if self.dt in (torch.float16, torch.bfloat16) else 4
         self.gate_via_gemm = (self.E * es) % 16 == 0
         # task-conditioned gate (custom_moe_layer.py:161-181): one shared w_gate [D + gtsd, E] per MoE block
         self.task_cond = self.cfg.gate_task_specific_dim >= 0 and not self.cfg.multi_gate

@@ -3,8 +3,9 @@ GEMM (dense epilogues, grouped gather / scatter), weight gradients (dense, group
 forward / backward, combine forward / backward, gate (indices bit-exact against the C oracle on the same bf16-rounded
 rows), operand casts, row gather - against torch fp64 on the same bf16-rounded operands (bf16 has 8 significant bits:
 outputs stored in bf16 are compared at 6e-3, fp32 outputs of bf16 products at 2e-3), and the MoE layer mirror
-(FMoETransformerMLP: gate -> dispatch -> grouped FFN -> combine) forward + backward on bfloat16 input rows.
-Attention and the fused FFN kernel stay fp16 / fp32."""
+(FMoETransformerMLP: gate -> dispatch -> grouped FFN -> combine) forward + backward on bfloat16 input rows; attention
+forward / backward (LDS-resident and streamed kernels); and the fused executor end to end in bf16 against the float64
+oracle.  Only the fused FFN kernel (m3_ffn_fwd) stays fp16."""
 import numpy as np
 import pytest
 import torch
@@ -191,3 +192,42 @@ def test_moe_layer_mirror_runs_in_bf16():
     assert rel(o, orf) < 2e-2                       # two bf16 GEMMs deep; a few tokens may route differently at bf16
     o.float().pow(2).sum().backward(); orf.float().pow(2).sum().backward()
     assert rel(x.grad, x2.grad) < 5e-2
+
+
+def _attn_ref(qkv, B, N, h, dh):
+    q, k, v = qkv.view(B, N, 3, h, dh).permute(2, 0, 3, 1, 4)
+    a = torch.softmax((q @ k.transpose(-2, -1)) * dh ** -0.5, dim=-1)
+    return (a @ v).transpose(1, 2).reshape(B * N, h * dh)
+
+
+@pytest.mark.parametrize("B,N,h,dh", [(2, 197, 6, 32), (2, 197, 3, 64), (3, 50, 2, 32), (1, 577, 2, 64), (1, 1025, 2, 32)])
+def test_attention_bf16(ops, B, N, h, dh):
+    """N <= 256: the LDS-resident kernels; longer: the streamed ones (+ the ordered dQ slab sum)"""
+    C = h * dh
+    qkv = rnd(B * N, 3 * C, seed=40).to(dev())
+    o = torch.full((B * N, C), float("nan"), dtype=BF, device=dev())
+    lse = torch.empty(B, h, N, device=dev())
+    ops.attention_fwd(qkv, B, N, h, dh, o, lse)
+    qr = qkv.double().requires_grad_()
+    ref = _attn_ref(qr, B, N, h, dh)
+    assert rel(o, ref) < TOL_BF
+    d_o = rnd(B * N, C, seed=41).to(dev())
+    ref.backward(d_o.double())
+    dqkv = torch.full_like(qkv, float("nan"))
+    need = int(ops.lib().m3_attention_bwd_ws_elems(B, N, h, dh))
+    ws = torch.empty(need, device=dev()) if need else None
+    ops.attention_bwd(qkv, o, d_o, lse, B, N, h, dh, dqkv, dq_ws=ws)
+    assert torch.isfinite(dqkv).all() and rel(dqkv, qr.grad) < 2 * TOL_BF
+
+
+def test_fused_executor_in_bf16_matches_oracle():
+    """BackboneEngine(dtype=bfloat16): tokens, balance loss and every parameter gradient of a 4-block multi-gate MoE-ViT
+    against the float64 oracle with the routing the oracle takes on the engine's own gate inputs (bf16 keeps 8
+    significant bits: bounds 8x the fp16 ones of tests/test_engine.py)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import test_engine as TE              # (tests/ is on sys.path: rootdir-relative test modules)
+    from oracle import ref_torch as R
+    cfg = R.BackboneCfg(img_size=(32, 48), embed_dim=64, depth=4, num_heads=2, mlp_ratio=4.0, moe_mlp_ratio=1.0,
+                        moe_experts=4, moe_top_k=2, gate_dim=66, multi_gate=True)
+    TE._check_backbone(cfg, BF, 8 * TE.F16_TOL, tasks=(0, 1), follow_routing=True, cv_tol=2e-2)

@@ -20,7 +20,7 @@ GRAD_FACTOR = 3     # parameter gradients: relative L2 per tensor <= GRAD_FACTOR
 F16_TOL = 1e-3
 
 
-def _check_backbone(cfg, dtype, tol, tasks, B=3, seed=5, follow_routing=False, noisy=False):
+def _check_backbone(cfg, dtype, tol, tasks, B=3, seed=5, follow_routing=False, noisy=False, cv_tol=1e-3):
     """follow_routing (fp16 runs with many experts, where a 1e-3 perturbation of the gate input flips
     near-tied experts): the engine's indices must be EXACTLY the oracle gate's top-k on the engine's own
     gate input, may differ from the float64 run's indices for a few near-tied tokens only, and the values
@@ -64,7 +64,7 @@ def _check_backbone(cfg, dtype, tol, tasks, B=3, seed=5, follow_routing=False, n
                 assert torch.equal(eng.act[i]["gate"]["idx"].cpu(), aux[i]["idx"]), f"routing differs in block {i}"
         tok_err = rel(tok, tok_ref)
         assert tok_err < tol
-        assert abs(float(cv) - float(cv_ref.detach())) < 1e-3 * max(1.0, abs(float(cv_ref.detach())))
+        assert abs(float(cv) - float(cv_ref.detach())) < cv_tol * max(1.0, abs(float(cv_ref.detach())))
         eng.backward(dtok.cuda(), cv_weight=cvw)
         tot = tot + (tok_ref * dtok.double()).sum() + cvw * cv_ref
     tot.backward()
