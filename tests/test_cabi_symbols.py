@@ -62,3 +62,29 @@ def test_wgrad_plan_covers_every_group_layout():
         assert ops.wgrad_ws_elems(M, N, K, G, grouped=True) == units * N * (K + 1)
     assert ops.wgrad_plan(1000, 1, 4, grouped=True) == (0, 4)          # one group: equal parts
     assert ops.wgrad_plan(1000, 128, 2, grouped=True) == (0, 256)      # more groups than lanes: equal parts
+
+
+def test_wide_wgrad_tile_rule_and_splits_on_the_host():
+    """m3_wgrad_tile / m3_wgrad_set_wide are host code: the tile rule (128 x 384 for K = 384, 384 x 128 for N = 384, fp16
+    only, off by default) and the split heuristic that goes with it (256 one-per-CU slots; grouped calls with many tiles
+    prefer one unit per expert) - and the slab workspace the planner reserves always covers what the kernel indexes"""
+    import torch
+    from m3vit_amd import ops
+    h = torch.float16
+    try:
+        ops.wgrad_set_wide(0)
+        assert ops.wgrad_tile(1536, 384, h) == (128, 128) and ops.default_wgrad_splits(25216, 1536, 384, 1, h) == 14
+        ops.wgrad_set_wide(1)
+        assert ops.wgrad_tile(1536, 384, h) == (128, 384) and ops.wgrad_tile(384, 1536, h) == (384, 128)
+        assert ops.wgrad_tile(384, 384, h) == (128, 128) and ops.wgrad_tile(1536, 384, torch.float32) == (128, 128)
+        assert ops.wgrad_tile(1536, 384, torch.bfloat16) == (128, 128)            # the wide kernel is fp16 only
+        assert ops.default_wgrad_splits(25216, 1536, 384, 1, h) == 21              # 12 tiles x 21 = 252 of 256 slots
+        assert ops.default_wgrad_splits(25216, 1152, 384, 1, h) == 28
+        assert ops.default_wgrad_splits(100864, 1536, 384, 16, h) == 1             # 192 tile-experts: one unit each
+        assert ops.default_wgrad_splits(100864, 1536, 384, 4, h) >= 2              # 48 tile-experts: split the rows
+        for (M, N, K, G) in ((25216, 1536, 384, 1), (100864, 384, 1536, 16), (3000, 1152, 384, 1)):
+            s = ops.default_wgrad_splits(M, N, K, G, h)
+            _, units = ops.wgrad_plan(M, G, s, grouped=G > 1)
+            assert ops.wgrad_ws_elems(M, N, K, G, grouped=G > 1, dtype=h) == units * N * (K + 1)
+    finally:
+        ops.wgrad_set_wide(0)
