@@ -192,7 +192,7 @@ def main():
                                parallel_tasks=not args.serial_tasks, graph=not args.no_graph, world=world, rank=rank,
                                expert_parallel=expert_parallel, wgrad_streams=args.wgrad_streams, dp_parts=args.dp_parts,
                                checkpoint=args.checkpoint and not expert_parallel)
-        use_ep, par_tasks, ntasks = runner.use_ep, runner.par, len(runner.tasks)
+        use_ep, par_tasks, ntasks = runner.use_ep, runner.par or runner.par_ep, len(runner.tasks)
         g = torch.Generator().manual_seed(1000 + rank)          # each rank its own images
         images = torch.randn(args.batch, 3, *cfg.img_size, generator=g).to(dev)
         dtok = (torch.randn(args.batch, cfg.num_tokens, cfg.embed_dim, generator=g) * 0.05).to(dev)

@@ -391,23 +391,31 @@ class BackboneEngine:
         pretrain/configs/deit_moe_small.yaml:51 trains with drop_path > 0); the factor rides on the epilogue of the
         GEMM that closes the branch (proj, fc2) or on the combine scores (MoE), and on the gradient entering the
         branch in backward."""
+        x = self.forward_begin(images, task_id, tsf_bias=tsf_bias, noises=noises, path_scales=path_scales)
+        for i in range(self.depth):
+            x = self._block_forward(i, x, self.cv_acc)
+        return self.forward_end(x)
+
+    # The forward in resumable pieces (patch embedding / one block at a time / result), so that a step runner can
+    # interleave the blocks of several task passes on the host (expert parallelism: while one pass waits for its
+    # exchange's split sizes, the other pass's queued kernels keep the GPU busy).
+    def forward_begin(self, images: torch.Tensor, task_id: Optional[int], tsf_bias=None, noises=None, path_scales=None):
         P_, p = self.P, self.params
-        B, T, D = self.B, self.T, self.D
-        N = self.N
+        B, D = self.B, self.D
         self._tsf = None
         if self.task_cond and tsf_bias is None and task_id is not None:
             tsf_bias = self._task_feature(task_id)
         ops.im2row(images, P_, self.rows)
         ops.gemm_nt(self.rows, self.wc["patch_embed.proj"], self.patch, bias=p["patch_embed.proj.bias"])
         ops.assemble_tokens(self.patch, p["cls_token"], p["pos_embed"], B, self.np_, D, self.x0)
-        x = self.x0
         self.cv_acc.zero_()
         self.task_id = task_id
         self._fwd_ctx = (task_id, tsf_bias, noises, path_scales)
-        for i in range(self.depth):
-            x = self._block_forward(i, x, self.cv_acc)
+        return self.x0
+
+    def forward_end(self, x):
         # total cv_loss = sum over MoE blocks of cv^2(importance) + cv^2(load)  (vision_transformer_moe.py:453-459,540)
-        return x.view(B, self.N, D), self.cv_acc[0].clone()
+        return x.view(self.B, self.N, self.D), self.cv_acc[0].clone()
 
     # ------------------------------------------------------------- expert parallel
     def _a2a(self, x, in_splits, out_splits):

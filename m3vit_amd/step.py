@@ -14,7 +14,8 @@ accumulated), laid out for the GPU:
   stream under the following parts; only the last slice's all-reduce is exposed.  `dp_parts` large collectives per step
   (replicated experts make the gradient buffer ~0.5 GB: with 6 parts one MoE block's ~80 MB are left for the end).
 
-Expert-parallel runs (ep_world > 1) read per-layer counts on the host and therefore execute eagerly on one stream."""
+Expert-parallel runs (ep_world > 1) read each MoE layer's exchange split sizes on the host and therefore execute eagerly;
+their task passes still get a stream each, with their blocks interleaved on the host (_ep_interleaved)."""
 from __future__ import annotations
 
 import torch
@@ -37,9 +38,14 @@ class MultiTaskStep:
                                   ep_world=self.world if self.use_ep else 1, ep_rank=rank if self.use_ep else 0,
                                   wgrad_stream=wg, checkpoint=checkpoint)
         self.par = bool(parallel_tasks) and not self.use_ep and len(self.tasks) > 1
+        # expert parallel: the task passes still get their own engine contexts and streams, but their blocks are
+        # interleaved on the host (_ep_interleaved): each pass stops once per MoE layer to read its exchange's split
+        # sizes, and its all-to-alls run on RCCL's stream - both under the other passes' queued kernels
+        self.par_ep = bool(parallel_tasks) and self.use_ep and len(self.tasks) > 1
         self.engs = [self.eng] + ([BackboneEngine(cfg, None, batch=batch, dtype=dtype, device=str(self.dev), share=self.eng,
+                                                   ep_world=self.world if self.use_ep else 1, ep_rank=rank if self.use_ep else 0,
                                                    wgrad_stream=wg, checkpoint=checkpoint) for _ in self.tasks[1:]]
-                                    if self.par else [])
+                                    if (self.par or self.par_ep) else [])
         self.streams = [torch.cuda.Stream(device=self.dev) for _ in self.engs[1:]]
         self.flat = self.eng.flat_grads
         # cutting the step only makes sense when there is a collective to hide and the passes run side by side
@@ -118,8 +124,44 @@ class MultiTaskStep:
         for t in self.tasks:
             self._full(self.eng, t)
 
+    def _ep_interleaved(self):
+        """expert-parallel step with the task passes on their own streams, block by block: forward block i of every
+        pass, then block i + 1 ...; backward likewise from the top.  One host thread issues everything in the same
+        order on every rank, so the collectives of the passes line up across ranks."""
+        main = torch.cuda.current_stream()
+        sts = [main] + self.streams
+        self.eng.prepare_weights()
+        for st in self.streams:
+            st.wait_stream(main)
+        xs = []
+        for e, t, st in zip(self.engs, self.tasks, sts):
+            with torch.cuda.stream(st):
+                e.zero_grad()
+                xs.append(e.forward_begin(self.images, t, tsf_bias=self.logit_bias,
+                                          noises=None if self.noises is None else self.noises.get(t)))
+        depth = self.eng.depth
+        for i in range(depth):
+            for n, (e, st) in enumerate(zip(self.engs, sts)):
+                with torch.cuda.stream(st):
+                    xs[n] = e._block_forward(i, xs[n], e.cv_acc)
+        for e, st in zip(self.engs, sts):
+            with torch.cuda.stream(st):
+                e.backward_begin(self.dtok, cv_weight=self.cv_weight)
+        for i in range(depth - 1, -1, -1):
+            for e, st in zip(self.engs, sts):
+                with torch.cuda.stream(st):
+                    e.backward_blocks(i, i)
+        for e, st in zip(self.engs, sts):
+            with torch.cuda.stream(st):
+                e.backward_end()
+        for st in self.streams:
+            main.wait_stream(st)
+        self._add(0, self.flat.numel())
+
     def part(self, j: int):
         """part j of the step on the current stream (part 0 alone is the whole step unless the step is cut)"""
+        if self.par_ep:
+            return self._ep_interleaved()
         if not self.par:
             return self.serial_step()
         if j == 0:

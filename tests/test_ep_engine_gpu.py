@@ -145,3 +145,56 @@ def test_data_parallel_step_parts_two_ranks_one_gpu():
     for p in procs:
         p.join(timeout=30)
     assert all(r[1] == "ok" for r in res), res
+
+
+def _ep_step_worker(rank, world, port, q):
+    """expert-parallel step runner: the task passes on their own streams with their blocks interleaved on the host
+    (MultiTaskStep._ep_interleaved) must leave the gradients of the one-pass-after-the-other expert-parallel step"""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from m3vit_amd.config import BackboneConfig, init_params
+        from m3vit_amd.step import MultiTaskStep
+        torch.cuda.set_device(0)
+        cfg = BackboneConfig(img_size=(32, 48), embed_dim=64, depth=4, num_heads=2, moe_experts=4, moe_top_k=2,
+                             gate_dim=67, multi_gate=True)                                   # 3 task passes
+        P = init_params(cfg, seed=3, zero_bias=False)
+        B = 3
+        g = torch.Generator().manual_seed(70 + rank)
+        img = torch.randn(B, 3, 32, 48, generator=g).cuda()
+        dtok = (torch.randn(B, cfg.num_tokens, 64, generator=g) * 0.1).cuda()
+        ser = MultiTaskStep(cfg, P, batch=B, dtype=torch.float32, world=world, rank=rank, expert_parallel=True,
+                            parallel_tasks=False)
+        par = MultiTaskStep(cfg, P, batch=B, dtype=torch.float32, world=world, rank=rank, expert_parallel=True)
+        assert ser.use_ep and not ser.par_ep and par.par_ep and len(par.engs) == 3 and not par.want_graph
+        for run in (ser, par):
+            run.bind(img, dtok)
+        for _ in range(2):                                   # twice: buffers and streams are re-used step after step
+            ser.step(); par.step()
+            torch.cuda.synchronize()
+            e = rel(par.flat, ser.flat)
+            assert e < 1e-5, e
+        assert float(ser.flat.abs().max()) > 0
+        q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_expert_parallel_step_with_interleaved_task_streams_two_ranks_one_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ep_step_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert all(r[1] == "ok" for r in res), res
