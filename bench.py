@@ -30,6 +30,8 @@ if ROOT not in sys.path:
 
 PEAK = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}      # dense MFMA TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM = 8000.0                          # GB/s, MI355X_MICROARCH.md
+METRIC = "images/sec fwd+bwd ViT-S/16 MoE(E=16,k=4) 224^2 bs=128"
+EP_WATCHDOG_S = 420                        # N > 1: the expert-parallel leg may not hang the whole line (see attempt())
 CV_WEIGHT = 0.01                           # --moe_noisy_gate_loss_weight default (train_fastmoe.py:118; applied at train/train_utils.py:277)
 
 
@@ -51,12 +53,20 @@ def parse():
     ap.add_argument("--serial-tasks", action="store_true", help="run the task passes one after the other on one "
                     "stream (default: one HIP stream per task pass, gradients summed at the end)")
     ap.add_argument("--wgrad-streams", action="store_true", help="also launch the weight-gradient GEMMs of each "
-                    "pass on their own stream (fork / join by events; captured into the hipGraph like the rest)")
+                    "pass on their own stream (fork / join by events).  With --serial-tasks the pattern is captured into "
+                    "the hipGraph; with the default concurrent task streams the nested fork cannot be captured (ROCm 7.2 "
+                    "faults in hipStreamEndCapture: tools/nested_capture_probe.py) and the step runs eagerly "
+                    "(config.capture_refused says so); off under expert parallelism")
     ap.add_argument("--ep", action="store_true", help="N > 1: time ONLY the expert-parallel form (experts sharded over the "
                     "ranks, all-to-all over RCCL); default: expert parallel (primary, when E %% N == 0) AND data parallel")
     ap.add_argument("--dp-only", action="store_true", help="N > 1: time only the replicated-experts data-parallel form")
     ap.add_argument("--no-f32", action="store_true", help="N = 1: skip the fp32 run reported as the sub-object \"f32\"")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.checkpoint and a.wgrad_streams:
+        ap.error("--checkpoint re-uses the activation buffers a wgrad stream may still read: pick one of the two")
+    if a.ep and a.dp_only:
+        ap.error("--ep and --dp-only exclude each other")
+    return a
 
 
 class GemmTimer:
@@ -179,6 +189,9 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
+    # the library that really moves the bytes: backend "nccl" is RCCL on ROCm; gloo only in CPU-side rehearsals
+    coll = {"nccl": "RCCL"}.get(backend, backend)
+
     def run_mode(dtype_name, expert_parallel, want_roofline):
         """One timed configuration: W untimed warm-up steps, exactly K timed steps between barriers, max over ranks.
         Returns the fields of the JSON line that depend on the mode."""
@@ -238,12 +251,14 @@ def main():
         step_flops = 3.0 * cfg.fwd_flops_per_image() * args.batch * ntasks
         res = {"value": round(world * args.batch * args.steps / dt, 2), "ms_per_step": round(ms_per_step, 3),
                "model_tflops": round(step_flops * args.steps / dt / 1e12 * world, 2), "launch": runner.launch,
-               "task_streams": ntasks if par_tasks else 1, "wgrad_streams": len(runner.engs) if args.wgrad_streams else 0,
+               "task_streams": ntasks if par_tasks else 1,
+               "wgrad_streams": sum(1 for e in runner.engs if e.wg_stream is not None),
+               "capture_refused": runner.capture_refused,
                "task_passes": ntasks, "tokens_per_image": cfg.num_tokens,
                "activation_checkpointing": bool(args.checkpoint and not expert_parallel),
                "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
-               "parallelism": "single" if world == 1 else (f"dp{world}+ep{world} (experts sharded, RCCL all-to-all + all-reduce)"
-                                                            if use_ep else f"dp{world} (replicated experts, RCCL all-reduce)")}
+               "parallelism": "single" if world == 1 else (f"dp{world}+ep{world} (experts sharded, {coll} all-to-all + all-reduce)"
+                                                            if use_ep else f"dp{world} (replicated experts, {coll} all-reduce)")}
         if want_roofline:
             res["roofline"] = roofline_of(ops, runner, dtype_name, step, serial_step, par_tasks, ntasks)
         del runner
@@ -278,13 +293,21 @@ def main():
         traffic = traffic_source = None
         try:
             import glob
-            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-            with open(files[-1]) as fh:
-                pm = json.load(fh)
-            if pm.get("dtype") == dtype_name and args.batch == 128:
-                traffic = round(pm["kernels"]["gemm_nt_all"]["hbm_bytes_per_launch"])
-                traffic_source = f"profiles/{os.path.basename(files[-1])} (rocprofv3 --pmc passes" + \
-                                 (f", taken at commit {pm['head']}" if pm.get("head") else "") + "; not measured in this run)"
+            from m3vit_amd._lib import csrc_sha16
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
+                with open(f) as fh:
+                    pm = json.load(fh)
+                if pm.get("dtype") != dtype_name or args.batch != 128:
+                    continue
+                where = f"profiles/{os.path.basename(f)} (rocprofv3 --pmc passes" + \
+                        (f", taken at commit {pm['head']}" if pm.get("head") else "")
+                if pm.get("csrc_sha16") != csrc_sha16():
+                    # measured on other kernels than the ones in this tree: say so instead of replaying it
+                    traffic_source = where + "): STALE - the kernel sources changed since; traffic withheld"
+                else:
+                    traffic = round(pm["kernels"]["gemm_nt_all"]["hbm_bytes_per_launch"])
+                    traffic_source = where + "; not measured in this run)"
+                break
         except Exception:
             traffic = traffic_source = None
         # Which roof binds: the launches' arithmetic intensity (algorithmic FLOPs / algorithmic bytes) against the machine
@@ -322,57 +345,110 @@ def main():
     #         --moe_data_distributed mode) is timed as well: both appear as the sub-objects "ep" and "dp".
     E = VIT_SMALL_MOE["moe_experts"]
     extra = {}
+
+    def emit(main_res, final=False):
+        """rank 0 prints THE JSON line (once: at the end, or from the watchdog)"""
+        out = {
+            "metric": METRIC,
+            "value": main_res["value"], "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "configs[1]: ViT-Small/16 + MoE E=16 top-k=4 multi_gate, synthetic 224x224",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world, "task_passes": main_res["task_passes"],
+                       "tokens_per_image": main_res["tokens_per_image"], "cv_loss_weight": CV_WEIGHT,
+                       "launch": main_res["launch"],
+                       "routing": ("noisy gate std=1 (supplied noise, CDF load loss)" if args.noisy else "deterministic (std=0)") +
+                                  (", skewed: expert 0 in every token's top-k" if args.skew else ""),
+                       "task_streams": main_res["task_streams"], "wgrad_streams": main_res["wgrad_streams"],
+                       "capture_refused": main_res["capture_refused"],
+                       "activation_checkpointing": main_res["activation_checkpointing"],
+                       "peak_hbm_gib": main_res["peak_hbm_gib"],
+                       "parallelism": main_res["parallelism"]},
+            "model_tflops": main_res["model_tflops"],
+        }
+        if "roofline" in main_res:
+            out["roofline"] = main_res["roofline"]
+        out.update(extra)
+        if final and rank == 0 and world == 1 and not args.no_cpu_baseline:
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                cores = os.cpu_count() or 1
+            cores = max(1, min(cores, 16))          # the GPU box gives one GPU a 16-core share
+            v, n = cpu_baseline(VIT_SMALL_MOE, args.cpu_batch, cores)
+            out["cpu_baseline"] = {"value": round(v, 3), "unit": "images/s", "cores": cores, "kind": "port",
+                                   "sample": f"{n} full steps (2 task passes fwd+bwd, fp32 torch CPU oracle) at batch "
+                                             f"{args.cpu_batch}, scaled per image"}
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+
+
+    def attempt(tag, fn, watchdog_s=None, on_timeout=None):
+        """run one configuration; an exception (first contact with a collective library, an out-of-memory ...) costs
+        that configuration only: the text goes into the JSON line as "<tag>_error".  watchdog_s: a collective that never
+        returns cannot be caught - after that many seconds on_timeout() reports what was measured so far and the process
+        ends (every rank has its own timer)."""
+        import threading
+        import traceback
+        timer = None
+        if watchdog_s and on_timeout is not None:
+            timer = threading.Timer(watchdog_s, on_timeout)
+            timer.daemon = True
+            timer.start()
+        try:
+            return fn()
+        except Exception as exc:      # noqa: BLE001 - whatever it is, the other configuration's line must survive
+            log(f"{tag}: FAILED: {type(exc).__name__}: {exc}")
+            traceback.print_exc(file=sys.stderr)
+            extra[f"{tag}_error"] = f"{type(exc).__name__}: {exc}"[:400]
+            try:
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+            except Exception:         # noqa: BLE001
+                pass
+            return None
+        finally:
+            if timer is not None:
+                timer.cancel()
+
+    main_res = None
     if world == 1:
         main_res = run_mode(args.dtype, False, True)
         if args.dtype == "f16" and not args.no_f32:
-            f32 = run_mode("f32", False, True)
-            extra["f32"] = {k: f32[k] for k in ("value", "ms_per_step", "model_tflops", "launch", "roofline")}
-            extra["f32"]["dtype"] = "f32"
+            f32 = attempt("f32", lambda: run_mode("f32", False, True))
+            if f32 is not None:
+                extra["f32"] = {k: f32[k] for k in ("value", "ms_per_step", "model_tflops", "launch", "roofline")}
+                extra["f32"]["dtype"] = "f32"
     else:
-        modes = []
-        if args.ep or (not args.dp_only and E % world == 0):
-            modes.append(True)
-        if not args.ep:
-            modes.append(False)
-        results = {ep: run_mode(args.dtype, ep, False) for ep in modes}
-        primary = modes[0]
-        main_res = results[primary]
-        for ep, r in results.items():
-            extra["ep" if ep else "dp"] = {k: r[k] for k in ("value", "ms_per_step", "model_tflops", "launch", "parallelism")}
-    out = {
-        "metric": "images/sec fwd+bwd ViT-S/16 MoE(E=16,k=4) 224^2 bs=128",
-        "value": main_res["value"], "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "configs[1]: ViT-Small/16 + MoE E=16 top-k=4 multi_gate, synthetic 224x224",
-                   "batch_per_gpu": args.batch, "global_batch": args.batch * world, "task_passes": main_res["task_passes"],
-                   "tokens_per_image": main_res["tokens_per_image"], "cv_loss_weight": CV_WEIGHT,
-                   "launch": main_res["launch"],
-                   "routing": ("noisy gate std=1 (supplied noise, CDF load loss)" if args.noisy else "deterministic (std=0)") +
-                              (", skewed: expert 0 in every token's top-k" if args.skew else ""),
-                   "task_streams": main_res["task_streams"], "wgrad_streams": main_res["wgrad_streams"],
-                   "activation_checkpointing": main_res["activation_checkpointing"],
-                   "peak_hbm_gib": main_res["peak_hbm_gib"],
-                   "parallelism": main_res["parallelism"]},
-        "model_tflops": main_res["model_tflops"],
-    }
-    if "roofline" in main_res:
-        out["roofline"] = main_res["roofline"]
-    out.update(extra)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except AttributeError:
-            cores = os.cpu_count() or 1
-        cores = max(1, min(cores, 16))          # the GPU box gives one GPU a 16-core share
-        v, n = cpu_baseline(VIT_SMALL_MOE, args.cpu_batch, cores)
-        out["cpu_baseline"] = {"value": round(v, 3), "unit": "images/s", "cores": cores, "kind": "port",
-                               "sample": f"{n} full steps (2 task passes fwd+bwd, fp32 torch CPU oracle) at batch "
-                                         f"{args.cpu_batch}, scaled per image"}
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+        want_ep = args.ep or (not args.dp_only and E % world == 0)
+        want_dp = not args.ep
+        results = {}
+        sub = ("value", "ms_per_step", "model_tflops", "launch", "parallelism")
+        # data parallel first: it needs one collective (all-reduce) and its line must survive whatever the expert-parallel
+        # leg (count all-to-all + uneven all-to-all-v on several streams) does at its first contact with RCCL
+        if want_dp:
+            results[False] = attempt("dp", lambda: run_mode(args.dtype, False, False))
+            if results[False] is not None:
+                extra["dp"] = {k: results[False][k] for k in sub}
+        if want_ep:
+            def ep_hung():
+                extra["ep_error"] = f"no result after {EP_WATCHDOG_S} s (a collective that never returned); reporting the data-parallel leg"
+                if rank == 0 and results.get(False) is not None:
+                    emit(results[False])
+                os._exit(0 if results.get(False) is not None else 1)
+            results[True] = attempt("ep", lambda: run_mode(args.dtype, True, False), watchdog_s=EP_WATCHDOG_S, on_timeout=ep_hung)
+            if results[True] is not None:
+                extra["ep"] = {k: results[True][k] for k in sub}
+        # primary: the expert-parallel form (north_star) when it ran, else the data-parallel one
+        main_res = results.get(True) or results.get(False)
+        if main_res is None:
+            if rank == 0:
+                print(json.dumps({"metric": METRIC, "value": None, "n_gpus": world, **extra}), flush=True)
+            sys.exit(1)
+    emit(main_res, final=True)
     if world > 1:
         dist.destroy_process_group()
+
 
 
 if __name__ == "__main__":

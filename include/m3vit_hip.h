@@ -190,7 +190,8 @@ int m3_gemm_set_variant(int ws_mask);
  * fused into the operand load / the store, and for the dense `Mlp.forward`
  * (models/moe/ckpt/vision_transformer_moe.py:255-261) with Block's residual add (:450).  The hidden activations
  * [rows, H] are never written: this is the forward of the reference's default activation-checkpointing mode
- * (vision_transformer_moe.py:495-524); the backward recomputes them (m3_ffn_bwd).
+ * (vision_transformer_moe.py:495-524); a backward that recomputes them is not built (the engine's checkpoint mode re-runs
+ * the unfused block forward instead).
  * X [*, D] (row stride ldx elements), W1 [G][H][D], W2p [G][D][H] = W2 with the h index permuted inside every
  * aligned group of 32 (position 8a + 4b + c holds h = 16b + 4a + c, a < 4, b < 2, c < 4: M3_CAST_PERM32 of
  * m3_cast_batch), b1 [G][H], b2 [G][D] fp32 (NULL = 0).  Y [*, D] f16 or fp32 (row stride ldy elements);

@@ -147,6 +147,22 @@ SIGNATURES = {
     "m3_tokens_bwd": (c_int, [_V, _I, _I, _I, _V, _I, _V, _V, _I, _V]),
 }
 
+def csrc_sha16() -> str:
+    """first 16 hex digits of the sha256 over the kernel sources (csrc/*.hip, *.h and the C header, by name): stamps a
+    PMC traffic file with the kernels it was measured on, so that bench.py can tell a stale replayed measurement
+    (the GPU box has no .git to ask)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "m3vit_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 _lib = None
 
 

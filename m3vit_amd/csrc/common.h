@@ -10,7 +10,7 @@
 namespace m3 {
 
 typedef _Float16 half_t;
-typedef __bf16 bf16_t;                   // the third activation dtype (M3_BF16): everything but the attention kernels
+typedef __bf16 bf16_t;                   // the third activation dtype (M3_BF16)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -15,7 +15,7 @@ import torch
 from . import _lib
 from ._lib import M3_ACT_GELU, M3_ACT_NONE, M3_BF16, M3_F16, M3_F32, GemmArgs, WgradArgs, check, lib
 
-_DT = {torch.float32: M3_F32, torch.float16: M3_F16, torch.bfloat16: M3_BF16}      # bf16: everything but attention / ffn_fwd
+_DT = {torch.float32: M3_F32, torch.float16: M3_F16, torch.bfloat16: M3_BF16}      # bf16: every entry point except the opt-in fused m3_ffn_fwd
 
 
 def dt_code(dtype: torch.dtype) -> int:

@@ -60,14 +60,17 @@ class MultiTaskStep:
         # hipGraph capture: expert-parallel steps read split sizes on the host (eager).  Weight-gradient streams capture
         # fine when forked from the capturing stream itself (tools/wgrad_capture_probe.py: capture + replay bit-exact),
         # but forked from a stream that is ITSELF a fork of the capturing stream (task streams x wgrad streams: a nested
-        # fork) hipStreamEndCapture of ROCm 7.2 segfaults (profiles/r02_wgrad_capture_segv.txt) - that combination is
+        # fork) hipStreamEndCapture of ROCm 7.2 segfaults - also with plain torch streams, events and elementwise
+        # kernels and no engine at all (tools/nested_capture_probe.py, profiles/r03_nested_capture_probe.txt; first seen
+        # in profiles/r02_wgrad_capture_segv.txt): the runtime's fault, not the engine's event use.  That combination is
         # refused here and runs eagerly.
         self.capture_refused = None
         if self.use_ep:
             self.capture_refused = "expert-parallel steps read the exchange's split sizes on the host"
         elif wg and self.par:
-            self.capture_refused = ("wgrad streams forked from forked task streams: hipStreamEndCapture (ROCm 7.2) "
-                                    "segfaults on the nested fork; use serial tasks or no wgrad streams to replay a graph")
+            self.capture_refused = ("wgrad streams forked from forked task streams: hipStreamEndCapture (ROCm 7.2) segfaults on "
+                                    "a nested fork (engine-free reproducer: tools/nested_capture_probe.py); use serial tasks or "
+                                    "no wgrad streams to replay a graph")
         self.want_graph = bool(graph) and self.capture_refused is None
         self.graphs = None
         self.capture_error = None

@@ -2,7 +2,9 @@
 """One-shot probe: capture a step whose weight-gradient GEMMs run on their own HIP stream (BackboneEngine(wgrad_stream=
 True): fork by event from the capturing stream, join by wait_stream) into a hipGraph, replay it and compare with the
 eager gradients.  Prints the HIP error text if the capture fails.  Run it in its own process (a hard fault in the
-runtime must not take a test session down):   python tools/wgrad_capture_probe.py [--tasks 2]"""
+runtime must not take a test session down):   python tools/wgrad_capture_probe.py [--batch 4]
+The NESTED pattern (task streams x wgrad streams) has its own engine-free reproducer: tools/nested_capture_probe.py
+(result: profiles/r03_nested_capture_probe.txt - it faults in hipStreamEndCapture with plain torch streams)."""
 import argparse
 import os
 import sys
