@@ -204,7 +204,7 @@ def main():
         runner = MultiTaskStep(cfg, params, batch=args.batch, dtype=dtype, device=str(dev), cv_weight=CV_WEIGHT,
                                parallel_tasks=not args.serial_tasks, graph=not args.no_graph, world=world, rank=rank,
                                expert_parallel=expert_parallel, wgrad_streams=args.wgrad_streams, dp_parts=args.dp_parts,
-                               checkpoint=args.checkpoint and not expert_parallel)
+                               checkpoint=args.checkpoint)
         use_ep, par_tasks, ntasks = runner.use_ep, runner.par or runner.par_ep, len(runner.tasks)
         g = torch.Generator().manual_seed(1000 + rank)          # each rank its own images
         images = torch.randn(args.batch, 3, *cfg.img_size, generator=g).to(dev)
@@ -255,7 +255,7 @@ def main():
                "wgrad_streams": sum(1 for e in runner.engs if e.wg_stream is not None),
                "capture_refused": runner.capture_refused,
                "task_passes": ntasks, "tokens_per_image": cfg.num_tokens,
-               "activation_checkpointing": bool(args.checkpoint and not expert_parallel),
+               "activation_checkpointing": bool(args.checkpoint),
                "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                "parallelism": "single" if world == 1 else (f"dp{world}+ep{world} (experts sharded, {coll} all-to-all + all-reduce)"
                                                             if use_ep else f"dp{world} (replicated experts, {coll} all-reduce)")}

@@ -152,9 +152,12 @@ int m3_ep_plan(const int64_t *send_counts, const int64_t *recv_counts, int W, in
  *   row of C for slot m (MOEGather back to token-major).
  * Epilogue, in this order: + bias[g][n] (fp32) ; store pre-activation to pre_out (act
  * dtype) if non-NULL ; act (GELU) ; * gelu'(gelu_grad_pre[m,n]) if non-NULL ;
- * * row_scale[crow(m) / row_scale_div] (fp32) if non-NULL - the per-sample DropPath factor of the residual branch
- * the GEMM closes, vision_transformer_moe.py:167-185,441,450 ; + residual[m,n] (fp32) if non-NULL ; store as c_dtype
- * (M3_F32 or the act dtype).
+ * * row_scale[srow(m) / row_scale_div] (fp32) if non-NULL, srow(m) = row_scale_idx[m] when that is given, else crow(m)
+ * - the per-sample DropPath factor of the residual branch the GEMM closes, vision_transformer_moe.py:167-185,441,450,
+ * or (row_scale_idx = the slot -> routed-entry map, div 1) the gate score of a routed row: the backward of the combine
+ * bmm(gate_score, moe_outp), custom_moe_layer.py:298-305, is d moe_outp[t*k+j] = score[t,j] * d out[t], a row scaling
+ * that commutes with the expert GEMM behind it, so the scaled copy [T*k, D] is never materialised ;
+ * + residual[m,n] (fp32) if non-NULL ; store as c_dtype (M3_F32 or the act dtype).
  * Requirements: K*sizeof(elem) % 16 == 0, lda/ldb rows 16-byte aligned, N % 4 == 0. */
 typedef struct {
   const void *A; int64_t lda;
@@ -174,6 +177,7 @@ typedef struct {
   int32_t dtype;                   /* M3_F32 / M3_F16 / M3_BF16: element type of A, B, pre */
   const float *row_scale;          /* fp32 [ceil(rows / row_scale_div)] or NULL */
   int32_t row_scale_div;
+  const int32_t *row_scale_idx;    /* i32 [M] device or NULL: which row_scale entry slot m takes (before the division) */
 } m3_gemm_args;
 int m3_gemm_nt(const m3_gemm_args *args, void *stream);
 /* Tuning knob, no reference counterpart: which calls of m3_gemm_nt may take the weight-stationary persistent kernel
@@ -238,6 +242,12 @@ typedef struct {
                                       group's slabs */
   int32_t units;                   /* balanced mode: slab slots >= sum_g ceil(rows_g / chunk_rows)
                                       (M / chunk_rows + G always suffices) */
+  int32_t c_row_div;               /* with c_row_idx: the dC row of slot m is c_row_idx[m] / c_row_div (0 or 1: no division) */
+  const float *c_row_scale;        /* with c_row_idx, fp32 or NULL: that row is multiplied by c_row_scale[c_row_idx[m]] on
+                                      its way in.  Together: dC = the [T, N] gradient of the combine's OUTPUT, read through
+                                      the slot -> routed-entry map with div = k and scaled by the entry's gate score - the
+                                      combine backward d moe_outp[t*k+j] = score[t,j] * d out[t]
+                                      (custom_moe_layer.py:298-305) without materialising the [T*k, N] copy */
 } m3_wgrad_args;
 int m3_wgrad_tn(const m3_wgrad_args *args, void *stream);
 /* The output tile (n x k) m3_wgrad_tn uses for a shape - 128 x 128, or, with the wide tiles switched on, for fp16
@@ -273,7 +283,9 @@ int m3_colsum(const void *dC, int dtype, int64_t lddc, const int32_t *c_row_idx,
  *   major), residual/out fp32 [T, D] (residual may be NULL). */
 int m3_combine_fwd(const void *y, int dtype, const float *score, const float *residual,
                    int64_t T, int k, int D, float *out, void *stream);
-/* dy[t*k+j,:] = score[t,j] * dout[t,:] (act dtype) ; dscore[t,j] = <dout[t,:], y[t*k+j,:]> */
+/* dy[t*k+j,:] = score[t,j] * dout[t,:] (act dtype) ; dscore[t,j] = <dout[t,:], y[t*k+j,:]>.
+ * dy may be NULL (d score only): the expert backward can take score * dout straight from dout through
+ * m3_gemm_args.row_scale_idx / m3_wgrad_args.c_row_scale instead of reading a materialised dy. */
 int m3_combine_bwd(const float *dout, const void *y, int dtype, const float *score,
                    int64_t T, int k, int D, void *dy, float *dscore, void *stream);
 
@@ -290,13 +302,23 @@ int m3_gather_rows(const void *src, int dtype, const int32_t *idx, int div, int6
 int m3_layernorm_fwd(const float *x, int64_t T, int D, const float *gamma, const float *beta,
                      float eps, void *y, int y_dtype, float *mean, float *rstd, void *stream);
 /* dx[t,:] = dx_res[t,:] + LN'(dy[t,:]) ; dgamma/dbeta via per-block partials in ws
- * (fp32 [2][m3_ln_bwd_blocks(T)][D]) reduced in fixed order (beta = accumulate).
+ * (fp32 [2][m3_ln_bwd_blocks(T, D)][D]) reduced in fixed order (beta = accumulate).
  * dx_act (optional): a copy of dx in the activation dtype for the GEMMs that consume it next. */
-int m3_ln_bwd_blocks(int64_t T);
+int m3_ln_bwd_blocks(int64_t T, int D);
+/* dgamma == dbeta == NULL: the per-block partials are left in ws for m3_layernorm_bwd_reduce. */
 int m3_layernorm_bwd(const void *dy, int dy_dtype, const float *x, const float *mean,
                      const float *rstd, const float *gamma, const float *dx_res,
                      int64_t T, int D, float *dx, float *ws, float *dgamma, float *dbeta,
                      int beta, void *dx_act, int dx_act_dtype, void *stream);
+
+/* dgamma / dbeta of `count` LayerNorms in ONE launch: layer j (first <= j < first + count) has its partials
+ * (written by m3_layernorm_bwd with dgamma = dbeta = NULL) at ws + j * layer_stride floats and its outputs in
+ * grads_dev[j] (a DEVICE array); fixed summation order; beta = accumulate.  The reference's autograd produces these one
+ * LayerNorm at a time (vision_transformer_moe.py:441-442); here the 24-workgroup reduction behind every LayerNorm
+ * backward becomes one launch per group of blocks. */
+typedef struct m3_ln_param_grads { float *dgamma; float *dbeta; } m3_ln_param_grads;
+int m3_layernorm_bwd_reduce(const float *ws, int64_t layer_stride, int nblk, int D,
+                            const m3_ln_param_grads *grads_dev, int first, int count, int beta, void *stream);
 
 /* ----------------------------------------------------------- attention (a8)
  * softmax(q k^T * dh^-0.5) v over the packed qkv activations written by the qkv

@@ -38,6 +38,7 @@ class GemmArgs(Structure):
         ("tile_starts", c_void_p),
         ("dtype", c_int32),
         ("row_scale", c_void_p), ("row_scale_div", c_int32),
+        ("row_scale_idx", c_void_p),
     ]
 
 
@@ -52,6 +53,7 @@ class WgradArgs(Structure):
         ("dtype", c_int32),
         ("bias_ws", c_void_p),
         ("chunk_rows", c_int32), ("units", c_int32),
+        ("c_row_div", c_int32), ("c_row_scale", c_void_p),
     ]
 
 
@@ -132,8 +134,9 @@ SIGNATURES = {
     "m3_combine_bwd": (c_int, [_V, _V, _I, _V, _L, _I, _I, _V, _V, _V]),
     "m3_gather_rows": (c_int, [_V, _I, _V, _I, _L, _I, _I, _V, _V]),
     "m3_layernorm_fwd": (c_int, [_V, _L, _I, _V, _V, _F, _V, _I, _V, _V, _V]),
-    "m3_ln_bwd_blocks": (c_int, [_L]),
+    "m3_ln_bwd_blocks": (c_int, [_L, _I]),
     "m3_layernorm_bwd": (c_int, [_V, _I, _V, _V, _V, _V, _V, _L, _I, _V, _V, _V, _V, _I, _V, _I, _V]),
+    "m3_layernorm_bwd_reduce": (c_int, [_V, _L, _I, _I, _V, _I, _I, _I, _V]),
     "m3_attention_fwd": (c_int, [_V, _I, _I, _I, _I, _I, _V, _V, _V]),
     "m3_attention_bwd_ws_elems": (c_int64, [_I, _I, _I, _I]),
     "m3_attention_bwd": (c_int, [_V, _V, _V, _V, _I, _I, _I, _I, _I, _V, _V, _V]),

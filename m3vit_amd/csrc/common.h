@@ -226,9 +226,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
+// row index / divisor with the divisor a kernel argument: a shift when it is a power of two (top-k = 2, 4, 8 ...: the
+// routed-entry -> token map of every gathered operand), else the (~30 instruction) integer division
+static inline int div_shift(int d) { return (d >= 1 && (d & (d - 1)) == 0) ? __builtin_ctz((unsigned)d) : -1; }
+__device__ __forceinline__ int32_t div_by(int32_t v, int32_t d, int32_t sh) { return sh >= 0 ? (v >> sh) : (v / d); }
+
 int launch_reduce_rows_f32(const float *part, int nrows, int N, int G, int64_t gstride, float *out, int beta,
                            hipStream_t s);
 int launch_reduce_rows2_f32(const float *part, int nrows, int N, float *out0, float *out1, int beta, hipStream_t s);
+int launch_reduce_rows2_batch_f32(const float *part, int64_t layer_stride, int nrows, int N, const m3_ln_param_grads *outs,
+                                  int first, int count, int beta, hipStream_t s);
 int launch_reduce_rows_i32(const int32_t *part, int nrows, int N, int G, int64_t gstride, int64_t *out, int beta,
                            hipStream_t s);
 

@@ -43,7 +43,7 @@ constexpr int GEMM_THREADS = 256;
 
 struct GemmDev {
   const char *A; int64_t lda_b;                 // byte strides
-  const int32_t *a_row_idx; int32_t a_row_div;
+  const int32_t *a_row_idx; int32_t a_row_div; int32_t a_row_sh;   // a_row_sh: log2(a_row_div) if a power of two, else -1
   const char *B; int64_t ldb_b; int64_t b_group_b;
   char *C; int64_t ldc; int32_t c_f32;
   const int32_t *c_row_idx;
@@ -51,7 +51,8 @@ struct GemmDev {
   char *pre_out; int64_t ld_pre;
   const char *gpre; int64_t ld_gpre;
   const float *residual; int64_t ld_res;
-  const float *row_scale; int32_t row_scale_div;   // value *= row_scale[crow / div] in front of the residual add
+  const float *row_scale; int32_t row_scale_div;   // value *= row_scale[srow / div] in front of the residual add,
+  const int32_t *row_scale_idx;                    // srow = row_scale_idx ? row_scale_idx[m] : crow
   int32_t act;
   int64_t M; int32_t N; int32_t K;
   int32_t G;
@@ -61,6 +62,39 @@ struct GemmDev {
   int32_t m_tiles_max;
   int32_t vec8;                                 // N and all leading dims multiples of 8: staged epilogue
 };
+
+// Grouped call: which (group, first row, end row) owns row tile mt, and how many workgroups are live.  G <= 64: ONE
+// vector load of the tile prefix (lane l holds tile_starts[l + 1]) + a ballot instead of a chain of up to G dependent
+// scalar loads in front of every tile (the expert GEMMs run ~800 row tiles x 3 column tiles per launch).
+struct TileOwner { int g; int64_t m_begin, m_end; };
+__device__ __forceinline__ int grouped_live_tiles(const int32_t *tile_starts, int G, int lane, int &ts_lane) {
+  if (G <= 64) {
+    ts_lane = lane < G ? tile_starts[lane + 1] : 0x7fffffff;
+    return __builtin_amdgcn_readfirstlane(__shfl(ts_lane, G - 1, 64));
+  }
+  ts_lane = 0;
+  return tile_starts[G];
+}
+__device__ __forceinline__ TileOwner grouped_tile_owner(const int32_t *tile_starts, const int32_t *group_offsets, int G,
+                                                        int mt, int lane, int ts_lane) {
+  TileOwner o;
+  int g = 0, t0;
+  if (G <= 64) {
+    // groups whose END prefix is <= mt lie wholly before the tile (the prefix is monotone; the last group never counts)
+    g = __popcll(__ballot(lane < G - 1 && ts_lane <= mt));
+    t0 = g ? __shfl(ts_lane, g - 1, 64) : 0;
+  } else {
+    while (g + 1 < G && tile_starts[g + 1] <= mt) ++g;
+    t0 = tile_starts[g];
+  }
+  // (everything here is wave-uniform: say so, or the compiler carries the tile bounds in vector registers)
+  g = __builtin_amdgcn_readfirstlane(g);
+  t0 = __builtin_amdgcn_readfirstlane(t0);
+  o.g = g;
+  o.m_begin = (int64_t)__builtin_amdgcn_readfirstlane(group_offsets[g]) + (int64_t)(mt - t0) * 128;
+  o.m_end = __builtin_amdgcn_readfirstlane(group_offsets[g + 1]);
+  return o;
+}
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4);
@@ -84,16 +118,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
   // ---- which tile
   // grouped: the grid is sized for the upper bound of row tiles; remap only the LIVE workgroups over the XCDs (a remap
   // over the whole grid would park the surplus ids, i.e. no work, on the last XCD)
-  const int nwg = p.tile_starts ? p.tile_starts[p.G] * p.n_tiles : (int)gridDim.x;
+  int ts_lane = 0;
+  const int nwg = p.tile_starts ? grouped_live_tiles(p.tile_starts, p.G, lane, ts_lane) * p.n_tiles : (int)gridDim.x;
   if ((int)blockIdx.x >= nwg) return;
   const int t = xcd_remap(blockIdx.x, nwg);
   const int mt = t / p.n_tiles, nt = t - mt * p.n_tiles;
   int g = 0;
   int64_t m_begin, m_end;
   if (p.tile_starts) {
-    while (g + 1 < p.G && p.tile_starts[g + 1] <= mt) ++g;
-    m_begin = (int64_t)p.group_offsets[g] + (int64_t)(mt - p.tile_starts[g]) * BM;
-    m_end = p.group_offsets[g + 1];
+    const TileOwner ow = grouped_tile_owner(p.tile_starts, p.group_offsets, p.G, mt, lane, ts_lane);
+    g = ow.g; m_begin = ow.m_begin; m_end = ow.m_end;
   } else {
     m_begin = (int64_t)mt * BM;
     m_end = p.M;
@@ -116,7 +150,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
     int64_t m = m_begin + row;
     if (m >= m_end) m = m_end - 1;
     int64_t src = m;
-    if (p.a_row_idx) src = (int64_t)(p.a_row_idx[m] / p.a_row_div);
+    if (p.a_row_idx) src = (int64_t)div_by(p.a_row_idx[m], p.a_row_div, p.a_row_sh);
     a_off[i] = (uint32_t)(src * p.lda_b) + c_stage * 16;
     int n = n0 + row;
     if (n >= p.N) n = p.N - 1;
@@ -267,7 +301,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
           for (int j = 0; j < 4; ++j) { v0[j] *= gelu_grad_f(p0[j]); v1[j] *= gelu_grad_f(p1[j]); }
         }
         if (p.row_scale) {
-          const float sc = p.row_scale[crow / p.row_scale_div];
+          const int64_t srow = p.row_scale_idx ? (int64_t)p.row_scale_idx[m] : crow;
+          const float sc = p.row_scale[srow / p.row_scale_div];
           v0 *= sc; v1 *= sc;
         }
         if (p.residual) {
@@ -309,7 +344,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
         v[0] *= gelu_grad_f(pr[0]); v[1] *= gelu_grad_f(pr[1]);
         v[2] *= gelu_grad_f(pr[2]); v[3] *= gelu_grad_f(pr[3]);
       }
-      if (p.row_scale) v *= p.row_scale[crow / p.row_scale_div];
+      if (p.row_scale) v *= p.row_scale[(p.row_scale_idx ? (int64_t)p.row_scale_idx[m] : crow) / p.row_scale_div];
       if (p.residual) v += *(const f32x4 *)(p.residual + crow * p.ld_res + n);
       if (p.c_f32) *(f32x4 *)((float *)p.C + crow * p.ldc + n) = v;
       else Vec4<T>::store((T *)p.C + crow * p.ldc + n, v);
@@ -337,6 +372,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
 //     vmcnt(0) that retires it (hipcc drains LDS-DMA at a barrier).
 constexpr int DMA_RB = 128;                // bytes of a row slice = one cache line
 constexpr int DMA_LDS = 2 * BM * DMA_RB;   // A + B image: 32 KiB
+constexpr int DMA_LDS_ALL = DMA_LDS + BM * 4;   // + the tile's 128 per-row epilogue factors (row_scale)
 
 __device__ __forceinline__ int dma_swz(int row) { return (row >> 1) & 7; }
 
@@ -366,16 +402,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const Gemm
   }
 #endif
 
-  const int nwg = p.tile_starts ? p.tile_starts[p.G] * p.n_tiles : (int)gridDim.x;     // live workgroups (see above)
+  int ts_lane = 0;
+  const int nwg = p.tile_starts ? grouped_live_tiles(p.tile_starts, p.G, lane, ts_lane) * p.n_tiles : (int)gridDim.x;     // live workgroups (see above)
   if ((int)blockIdx.x >= nwg) return;
   const int t = xcd_remap(blockIdx.x, nwg);
   const int mt = t / p.n_tiles, nt = t - mt * p.n_tiles;
   int g = 0;
   int64_t m_begin, m_end;
   if (p.tile_starts) {
-    while (g + 1 < p.G && p.tile_starts[g + 1] <= mt) ++g;
-    m_begin = (int64_t)p.group_offsets[g] + (int64_t)(mt - p.tile_starts[g]) * BM;
-    m_end = p.group_offsets[g + 1];
+    const TileOwner ow = grouped_tile_owner(p.tile_starts, p.group_offsets, p.G, mt, lane, ts_lane);
+    g = ow.g; m_begin = ow.m_begin; m_end = ow.m_end;
   } else {
     m_begin = (int64_t)mt * BM;
     m_end = p.M;
@@ -393,13 +429,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const Gemm
     int64_t m = m_begin + row;
     if (m >= m_end) m = m_end - 1;
     int64_t src = m;
-    if (p.a_row_idx) src = (int64_t)(p.a_row_idx[m] / p.a_row_div);
+    if (p.a_row_idx) src = (int64_t)div_by(p.a_row_idx[m], p.a_row_div, p.a_row_sh);
     a_src[j] = p.A + src * p.lda_b + c * 16;
     int n = n0 + row;
     if (n >= p.N) n = p.N - 1;
     b_src[j] = p.B + (int64_t)g * p.b_group_b + (int64_t)n * p.ldb_b + c * 16;
   }
   const int nk = (p.K * (int)sizeof(T)) / RB;
+
+  // per-row epilogue factor (DropPath scale / gate score of the routed row): thread r < 128 requests row r's factor NOW -
+  // an index load and a dependent load - so that they arrive under the K loop instead of in front of every store pass
+  float my_rs = 1.0f;
+  if (p.row_scale && tid < BM) {
+    int64_t m = m_begin + tid;
+    if (m >= m_end) m = m_end - 1;
+    const int64_t crow = p.c_row_idx ? (int64_t)p.c_row_idx[m] : m;
+    const int64_t srow = p.row_scale_idx ? (int64_t)p.row_scale_idx[m] : crow;
+    my_rs = p.row_scale[srow / p.row_scale_div];
+  }
 
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
@@ -459,6 +506,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const Gemm
   const int n = n0 + cg * 8;
   f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
   if (bias && n < p.N) { b0 = *(const f32x4 *)(bias + n); b1 = *(const f32x4 *)(bias + n + 4); }
+  float *const s_rs = (float *)(smem + DMA_LDS);         // (behind the operand images: written once, read after the barriers below)
+  if (p.row_scale && tid < BM) s_rs[tid] = my_rs;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if (h) __syncthreads();
@@ -496,7 +545,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const Gemm
           for (int j = 0; j < 4; ++j) { v0[j] *= gelu_grad_f(p0[j]); v1[j] *= gelu_grad_f(p1[j]); }
         }
         if (p.row_scale) {
-          const float sc = p.row_scale[crow / p.row_scale_div];
+          const float sc = s_rs[h * 64 + lrow];
           v0 *= sc; v1 *= sc;
         }
         if (p.residual) {
@@ -927,6 +976,7 @@ extern "C" int m3_gemm_nt(const m3_gemm_args *a, void *stream) {
   GemmDev d;
   d.A = (const char *)a->A; d.lda_b = a->lda * es;
   d.a_row_idx = a->a_row_idx; d.a_row_div = a->a_row_idx ? a->a_row_div : 1;
+  d.a_row_sh = div_shift(d.a_row_div);
   d.B = (const char *)a->B; d.ldb_b = a->ldb * es; d.b_group_b = (int64_t)a->N * a->ldb * es;
   d.C = (char *)a->C; d.ldc = a->ldc; d.c_f32 = (a->c_dtype == M3_F32) ? 1 : 0;
   d.c_row_idx = a->c_row_idx;
@@ -935,6 +985,7 @@ extern "C" int m3_gemm_nt(const m3_gemm_args *a, void *stream) {
   d.gpre = (const char *)a->gelu_grad_pre; d.ld_gpre = a->ld_gpre;
   d.residual = a->residual; d.ld_res = a->ld_res;
   d.row_scale = a->row_scale; d.row_scale_div = a->row_scale ? a->row_scale_div : 1;
+  d.row_scale_idx = a->row_scale ? a->row_scale_idx : nullptr;
   d.act = a->act;
   d.M = a->M; d.N = a->N; d.K = a->K; d.G = a->G;
   d.group_offsets = a->group_offsets; d.tile_starts = a->tile_starts;
@@ -990,9 +1041,9 @@ extern "C" int m3_gemm_nt(const m3_gemm_args *a, void *stream) {
   if (dma_mode < 0) { const char *e = getenv("M3_GEMM_DMA"); dma_mode = e ? (atoi(e) ? 1 : 0) : 2; }
   const bool dma_ok = d.vec8 && (a->K * es) % DMA_RB == 0;
   if (dma_ok && (dma_mode == 1 || (dma_mode == 2 && es == 2))) {
-    if (a->dtype == M3_F16) hipLaunchKernelGGL((gemm_nt_dma_kernel<half_t>), grid, block, DMA_LDS, s, d);
-    else if (a->dtype == M3_BF16) hipLaunchKernelGGL((gemm_nt_dma_kernel<bf16_t>), grid, block, DMA_LDS, s, d);
-    else hipLaunchKernelGGL((gemm_nt_dma_kernel<float>), grid, block, DMA_LDS, s, d);
+    if (a->dtype == M3_F16) hipLaunchKernelGGL((gemm_nt_dma_kernel<half_t>), grid, block, DMA_LDS_ALL, s, d);
+    else if (a->dtype == M3_BF16) hipLaunchKernelGGL((gemm_nt_dma_kernel<bf16_t>), grid, block, DMA_LDS_ALL, s, d);
+    else hipLaunchKernelGGL((gemm_nt_dma_kernel<float>), grid, block, DMA_LDS_ALL, s, d);
     return check_launch("m3_gemm_nt");
   }
   const bool ktail = (a->K * es) % ROWB != 0;

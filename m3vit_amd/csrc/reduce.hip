@@ -51,6 +51,38 @@ __global__ __launch_bounds__(256) void reduce_rows2_kernel(const float *__restri
   }
 }
 
+// the same for `count` layers in one launch (blockIdx.z = layer first + z): layer j's partials at part + j * layer_stride,
+// its outputs from a device-resident pointer table
+__global__ __launch_bounds__(256) void reduce_rows2_batch_kernel(const float *__restrict__ part, int64_t layer_stride, int nrows,
+                                                                 int N, const m3_ln_param_grads *__restrict__ outs, int first,
+                                                                 int beta) {
+  __shared__ float s[8][33];
+  const int c = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + c, g = blockIdx.y, layer = first + blockIdx.z;
+  float acc = 0.f;
+  if (n < N) {
+    const float *p = part + (int64_t)layer * layer_stride + (int64_t)g * nrows * N + n;
+#pragma unroll 4
+    for (int r = rl; r < nrows; r += 8) acc += p[(int64_t)r * N];
+  }
+  s[rl][c] = acc;
+  __syncthreads();
+  if (rl == 0 && n < N) {
+    float t = s[0][c];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) t += s[i][c];
+    float *o = (g ? outs[layer].dbeta : outs[layer].dgamma) + n;
+    *o = beta ? (*o + t) : t;
+  }
+}
+
+int launch_reduce_rows2_batch_f32(const float *part, int64_t layer_stride, int nrows, int N, const m3_ln_param_grads *outs,
+                                  int first, int count, int beta, hipStream_t s) {
+  hipLaunchKernelGGL(reduce_rows2_batch_kernel, dim3((N + 31) / 32, 2, count), dim3(256), 0, s, part, layer_stride, nrows, N,
+                     outs, first, beta);
+  return check_launch("reduce_rows2_batch_f32");
+}
+
 int launch_reduce_rows2_f32(const float *part, int nrows, int N, float *out0, float *out1, int beta, hipStream_t s) {
   hipLaunchKernelGGL(reduce_rows2_kernel, dim3((N + 31) / 32, 2), dim3(256), 0, s, part, nrows, N, out0, out1, beta);
   return check_launch("reduce_rows2_f32");

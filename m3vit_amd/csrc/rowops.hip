@@ -48,7 +48,7 @@ __global__ __launch_bounds__(ROW_THREADS) void combine_bwd_kernel(const float *_
       const f32x4 g = *(const f32x4 *)(dout + t * D + d);
       const f32x4 v = Vec4<T>::load(y + (t * k + j) * D + d);
       dot += g[0] * v[0] + g[1] * v[1] + g[2] * v[2] + g[3] * v[3];
-      Vec4<T>::store(dy + (t * k + j) * D + d, f32x4{s * g[0], s * g[1], s * g[2], s * g[3]});
+      if (dy) Vec4<T>::store(dy + (t * k + j) * D + d, f32x4{s * g[0], s * g[1], s * g[2], s * g[3]});
     }
     dot = wave_sum(dot);
     if (lane == 0) dscore[t * k + j] = dot;
@@ -101,28 +101,49 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_fwd_kernel(const float 
 
 // dx = dx_res + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)); per-block partial
 // dgamma/dbeta (rows of a block summed in row order).
-constexpr int LNB_WAVES = 8;               // waves per workgroup in the backward
-constexpr int LNB_THREADS = LNB_WAVES * 64;
-constexpr int LNB_ROWS = LNB_WAVES * 8;    // rows per workgroup (8 per wave): half the dgamma/dbeta partial rows of a 4-wave block
+// Geometry: ln_bwd_waves() waves per workgroup (8; M3_LN_WAVES overrides it for tuning), each wave owns `rpw` consecutive
+// rows (default LNB_RPW; M3_LN_ROWS).  Measured at T = 25 216, D = 384 (tools/ln_bench.py, operands streamed; then the
+// two-stream training step, same box): 4 waves x 1 / 2 / 4 / 8 / 16 rows 34.7 / 36.7 / 41.7 / 39.7 / 60.5 us per launch,
+// 16 waves x 1 / 2 / 4 rows 42.1 / 41.4 / 40.5 us, 8 waves x 8 rows 38.0 us.  Fewer rows per wave stream faster by
+// themselves but leave one dgamma / dbeta partial row per workgroup (6304 rows x 2 x D floats at one row per wave: 12 % of
+// the kernel's bytes), and 1024-thread workgroups cannot be placed beside the other task stream's kernels (the step went
+// 18.16 -> 18.57 ms with them); 8 x 8 is the fastest INSIDE the step.  The partials are summed by ONE batched launch for
+// many layers (m3_layernorm_bwd_reduce) instead of a 24-workgroup reduce launch behind every LayerNorm backward.
+constexpr int LNB_RPW = 8;                 // default rows per wave
+static inline int ln_bwd_waves(int D) {
+  static int forced = -1;                    // M3_LN_WAVES = 4 / 8 / 16 (tuning; 16 only while the image fits 64 KiB)
+  if (forced < 0) { const char *e = getenv("M3_LN_WAVES"); forced = e ? atoi(e) : 0; }
+  if (forced == 4 || forced == 8 || (forced == 16 && D <= 512)) return forced;
+  return 8;
+}
+static int ln_rows_per_wave() {
+  static int rpw = 0;
+  if (rpw == 0) {
+    const char *e = getenv("M3_LN_ROWS");
+    const int v = e ? atoi(e) : LNB_RPW;
+    rpw = (v >= 1 && v <= 64) ? v : LNB_RPW;
+  }
+  return rpw;
+}
 
 // NCH = ceil(D / 256): 16-byte chunks per lane (registers are sized for the row width in use: D = 384 -> 2, not 4,
 // which takes the kernel from 116 to ~70 VGPRs and from 4 to 7 waves per SIMD)
-template <typename T, typename TA, int NCH>
-__global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(const T *__restrict__ dy, const float *__restrict__ x,
+template <typename T, typename TA, int NCH, int LNB_WAVES>
+__global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const T *__restrict__ dy, const float *__restrict__ x,
                                                                     const float *__restrict__ mean,
                                                                     const float *__restrict__ rstd,
                                                                     const float *__restrict__ gamma,
                                                                     const float *__restrict__ dx_res, int64_t T_, int D,
                                                                     float *__restrict__ dx, float *__restrict__ part,
-                                                                    TA *__restrict__ dx_act) {
+                                                                    TA *__restrict__ dx_act, int rpw) {
   extern __shared__ float sred[];   // [LNB_WAVES][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nblk = gridDim.x;
   f32x4 dg[NCH], db[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) { dg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; db[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  for (int r = 0; r < LNB_ROWS / LNB_WAVES; ++r) {
-    const int64_t t = (int64_t)blockIdx.x * LNB_ROWS + wave * (LNB_ROWS / LNB_WAVES) + r;
+  for (int r = 0; r < rpw; ++r) {
+    const int64_t t = ((int64_t)blockIdx.x * LNB_WAVES + wave) * rpw + r;
     if (t >= T_) break;
     const float mu = mean[t], rs = rstd[t];
     f32x4 gdy[NCH], xh[NCH];
@@ -163,7 +184,7 @@ __global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(const T *__r
     }
   }
   __syncthreads();
-  for (int d = threadIdx.x; d < D; d += LNB_THREADS) {
+  for (int d = threadIdx.x; d < D; d += LNB_WAVES * 64) {
     float a = 0.f, b = 0.f;
     for (int w = 0; w < LNB_WAVES; ++w) { a += sred[(w * 2 + 0) * D + d]; b += sred[(w * 2 + 1) * D + d]; }
     part[(int64_t)blockIdx.x * D + d] = a;
@@ -324,7 +345,7 @@ extern "C" int m3_combine_fwd(const void *y, int dtype, const float *score, cons
 
 extern "C" int m3_combine_bwd(const float *dout, const void *y, int dtype, const float *score, int64_t T, int k, int D,
                               void *dy, float *dscore, void *stream) {
-  M3_REQUIRE(dout && y && score && dy && dscore, "m3_combine_bwd: null operand");
+  M3_REQUIRE(dout && y && score && dscore, "m3_combine_bwd: null operand");
   M3_REQUIRE(dtype_ok(dtype), "m3_combine_bwd: bad dtype");
   M3_REQUIRE(D % 4 == 0 && D > 0 && k >= 1, "m3_combine_bwd: D must be a multiple of 4");
   if (T == 0) return M3_OK;
@@ -358,28 +379,37 @@ extern "C" int m3_layernorm_fwd(const float *x, int64_t T, int D, const float *g
   return check_launch("m3_layernorm_fwd");
 }
 
-extern "C" int m3_ln_bwd_blocks(int64_t T) { return (int)((T + LNB_ROWS - 1) / LNB_ROWS); }
+extern "C" int m3_ln_bwd_blocks(int64_t T, int D) {
+  const int64_t rows = (int64_t)ln_bwd_waves(D) * ln_rows_per_wave();
+  return (int)((T + rows - 1) / rows);
+}
 
 extern "C" int m3_layernorm_bwd(const void *dy, int dy_dtype, const float *x, const float *mean, const float *rstd,
                                 const float *gamma, const float *dx_res, int64_t T, int D, float *dx, float *ws,
                                 float *dgamma, float *dbeta, int beta, void *dx_act, int dx_act_dtype, void *stream) {
-  M3_REQUIRE(dy && x && mean && rstd && gamma && dx && ws && dgamma && dbeta, "m3_layernorm_bwd: null operand");
+  M3_REQUIRE(dy && x && mean && rstd && gamma && dx && ws, "m3_layernorm_bwd: null operand");
+  M3_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "m3_layernorm_bwd: dgamma and dbeta go together");
   M3_REQUIRE(dtype_ok(dy_dtype), "m3_layernorm_bwd: bad dtype");
   M3_REQUIRE(!dx_act || dtype_ok(dx_act_dtype), "m3_layernorm_bwd: bad dx_act dtype");
   M3_REQUIRE(D % 4 == 0 && D > 0 && D <= 1024, "m3_layernorm_bwd: D must be a multiple of 4 and <= 1024");
   if (T == 0) return M3_OK;
   hipStream_t s = (hipStream_t)stream;
-  const int nblk = m3_ln_bwd_blocks(T);
-  const size_t lds = (size_t)2 * LNB_WAVES * D * sizeof(float);
+  const int nblk = m3_ln_bwd_blocks(T, D), rpw = ln_rows_per_wave(), nw = ln_bwd_waves(D);
+  const size_t lds = (size_t)2 * nw * D * sizeof(float);
   const bool a16 = dx_act && dx_act_dtype == M3_F16;
   const int nch = (D + 255) / 256;
-#define M3_LNB_N(TT, TA, NC)                                                                                         \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<TT, TA, NC>), dim3(nblk), dim3(LNB_THREADS), lds, s, (const TT *)dy, x, \
-                     mean, rstd, gamma, dx_res, T, D, dx, ws, (TA *)dx_act)
+#define M3_LNB_N(TT, TA, NC, NW)                                                                                     \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<TT, TA, NC, NW>), dim3(nblk), dim3(NW * 64), lds, s, (const TT *)dy, x,  \
+                     mean, rstd, gamma, dx_res, T, D, dx, ws, (TA *)dx_act, rpw)
+#define M3_LNB_W(TT, TA, NC)                                                              \
+  do {                                                                                   \
+    if (nw == 16) M3_LNB_N(TT, TA, NC, 16); else if (nw == 8) M3_LNB_N(TT, TA, NC, 8);   \
+    else M3_LNB_N(TT, TA, NC, 4);                                                        \
+  } while (0)
 #define M3_LNB(TT, TA)                                                                   \
   do {                                                                                   \
-    if (nch == 1) M3_LNB_N(TT, TA, 1); else if (nch == 2) M3_LNB_N(TT, TA, 2);           \
-    else if (nch == 3) M3_LNB_N(TT, TA, 3); else M3_LNB_N(TT, TA, 4);                    \
+    if (nch == 1) M3_LNB_W(TT, TA, 1); else if (nch == 2) M3_LNB_W(TT, TA, 2);           \
+    else if (nch == 3) M3_LNB_W(TT, TA, 3); else M3_LNB_W(TT, TA, 4);                    \
   } while (0)
   const bool ab16 = dx_act && dx_act_dtype == M3_BF16;
   // (the activation-dtype copy of dx has the dtype of the incoming gradient or is fp32; mixed 16-bit pairs are not built)
@@ -388,10 +418,19 @@ extern "C" int m3_layernorm_bwd(const void *dy, int dy_dtype, const float *x, co
   else if (dy_dtype == M3_BF16) { if (ab16) M3_LNB(bf16_t, bf16_t); else M3_LNB(bf16_t, float); }
   else { if (a16) M3_LNB(float, half_t); else if (ab16) M3_LNB(float, bf16_t); else M3_LNB(float, float); }
 #undef M3_LNB
+#undef M3_LNB_W
 #undef M3_LNB_N
   int rc = check_launch("m3_layernorm_bwd");
-  if (rc) return rc;
+  if (rc || !dgamma) return rc;                  // no dgamma / dbeta: the partials stay in ws for m3_layernorm_bwd_reduce
   return launch_reduce_rows2_f32(ws, nblk, D, dgamma, dbeta, beta, s);
+}
+
+extern "C" int m3_layernorm_bwd_reduce(const float *ws, int64_t layer_stride, int nblk, int D,
+                                       const m3_ln_param_grads *grads_dev, int first, int count, int beta, void *stream) {
+  M3_REQUIRE(ws && grads_dev && nblk >= 1 && D > 0 && first >= 0 && count >= 0 && layer_stride >= (int64_t)2 * nblk * D,
+             "m3_layernorm_bwd_reduce: bad args");
+  if (count == 0) return M3_OK;
+  return launch_reduce_rows2_batch_f32(ws, layer_stride, nblk, D, grads_dev, first, count, beta, (hipStream_t)stream);
 }
 
 extern "C" int m3_cast_matrix(const float *src, int G, int rows, int cols, int transpose, void *dst, int dst_dtype,

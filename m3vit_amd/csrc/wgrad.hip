@@ -27,6 +27,8 @@ constexpr int WG_THREADS = 256;
 
 struct WgradDev {
   const char *dC; int64_t lddc_b; const int32_t *c_row_idx;
+  int32_t c_row_div; const float *c_row_scale;   // dC row of slot m = c_row_scale[c_row_idx[m]] * dC[c_row_idx[m] / c_row_div]
+  int32_t a_row_sh, c_row_sh;                    // log2 of the divisors when they are powers of two, else -1
   const char *A; int64_t lda_b; const int32_t *a_row_idx; int32_t a_row_div;
   int64_t M; int32_t N; int32_t K; int32_t G;
   const int32_t *group_offsets;
@@ -125,7 +127,25 @@ __device__ __forceinline__ f32x4 read_tr_frag<float>(const char *base, int rb, i
   return f;
 }
 
-template <typename T, bool GC, bool GA>
+// a 16-byte chunk of T times a per-row factor (the gate score of a routed row: the combine's backward d y = score * d out
+// applied where the row enters the LDS image, so that the scaled [T*k, D] copy never exists in memory)
+template <typename T> __device__ __forceinline__ u32x4 scale_chunk(u32x4 v, float s);
+template <> __device__ __forceinline__ u32x4 scale_chunk<half_t>(u32x4 v, float s) {
+  const half_t h = (half_t)s;
+  const f16x8 f = __builtin_bit_cast(f16x8, v) * f16x8{h, h, h, h, h, h, h, h};      // 4 x v_pk_mul_f16
+  return __builtin_bit_cast(u32x4, f);
+}
+template <> __device__ __forceinline__ u32x4 scale_chunk<bf16_t>(u32x4 v, float s) {
+  bf16x8 f = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (bf16_t)((float)f[j] * s);
+  return __builtin_bit_cast(u32x4, f);
+}
+template <> __device__ __forceinline__ u32x4 scale_chunk<float>(u32x4 v, float s) {
+  return __builtin_bit_cast(u32x4, __builtin_bit_cast(f32x4, v) * s);
+}
+
+template <typename T, bool GC, bool GA, bool SC = false>
 __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev p) {
   typedef Mma<T> MM;
   typedef typename MM::frag frag;
@@ -206,22 +226,26 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
       if (GA) ia[i] = p.a_row_idx[m];
     }
   };
-  auto load_global = [&](int step, const int32_t(&ic)[NLD], const int32_t(&ia)[NLD], u32x4(&rc)[NLD], u32x4(&ra)[NLD]) {
+  // SC: the per-row factor travels with the row's data (loaded next to it, applied at the LDS store)
+  auto load_global = [&](int step, const int32_t(&ic)[NLD], const int32_t(&ia)[NLD], u32x4(&rc)[NLD], u32x4(&ra)[NLD],
+                         float(&rs)[NLD]) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int64_t m = row_of(step, i);
-      const int64_t cr = GC ? (int64_t)ic[i] : m;
-      const int64_t ar = GA ? (int64_t)(ia[i] / p.a_row_div) : m;
+      const int64_t cr = GC ? (int64_t)div_by(ic[i], p.c_row_div, p.c_row_sh) : m;
+      const int64_t ar = GA ? (int64_t)div_by(ia[i], p.a_row_div, p.a_row_sh) : m;
       rc[i] = *(const u32x4 *)(c_base + cr * p.lddc_b);
       ra[i] = *(const u32x4 *)(a_base + ar * p.lda_b);
+      if (SC) rs[i] = p.c_row_scale[ic[i]];
     }
   };
-  auto store_lds = [&](int buf, int step, const u32x4(&rc)[NLD], const u32x4(&ra)[NLD]) {
+  auto store_lds = [&](int buf, int step, const u32x4(&rc)[NLD], const u32x4(&ra)[NLD], const float(&rs)[NLD]) {
     char *base = smem + buf * (2 * OPB) + st_off;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const bool ok = rbase + (int64_t)step * ROWS + i * RSTEP < r1;
-      *(u32x4 *)(base + i * RSTEP * STRIDE) = ok ? rc[i] : u32x4{0u, 0u, 0u, 0u};
+      const u32x4 cv = SC ? scale_chunk<T>(rc[i], rs[i]) : rc[i];
+      *(u32x4 *)(base + i * RSTEP * STRIDE) = ok ? cv : u32x4{0u, 0u, 0u, 0u};
       *(u32x4 *)(base + i * RSTEP * STRIDE + OPB) = ok ? ra[i] : u32x4{0u, 0u, 0u, 0u};
     }
   };
@@ -262,43 +286,44 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
     const int last = nst - 1;
     auto cl = [&](int s_) { return s_ < last ? s_ : last; };
     u32x4 rc0[NLD], ra0[NLD], rc1[NLD], ra1[NLD];
+    float sc0[NLD], sc1[NLD];
     int32_t ic[NLD], ia[NLD];
     load_index(0, ic, ia);
-    load_global(0, ic, ia, rc1, ra1);
+    load_global(0, ic, ia, rc1, ra1, sc1);
     load_index(cl(1), ic, ia);
-    load_global(cl(1), ic, ia, rc0, ra0);
+    load_global(cl(1), ic, ia, rc0, ra0, sc0);
     load_index(cl(2), ic, ia);
-    store_lds(0, 0, rc1, ra1);
+    store_lds(0, 0, rc1, ra1, sc1);
     __syncthreads();
     // entry of even local step t: buf0 = tile t, set0 = tile t+1, (ic, ia) = indices of tile t+2
     int t = 0;
     for (; t + 3 < nst; t += 2) {
-      load_global(t + 2, ic, ia, rc1, ra1);
+      load_global(t + 2, ic, ia, rc1, ra1, sc1);
       load_index(cl(t + 3), ic, ia);
       __builtin_amdgcn_sched_barrier(0);
       compute(0);
-      store_lds(1, t + 1, rc0, ra0);
+      store_lds(1, t + 1, rc0, ra0, sc0);
       __syncthreads();
-      load_global(t + 3, ic, ia, rc0, ra0);
+      load_global(t + 3, ic, ia, rc0, ra0, sc0);
       load_index(cl(t + 4), ic, ia);
       __builtin_amdgcn_sched_barrier(0);
       compute(1);
-      store_lds(0, t + 2, rc1, ra1);
+      store_lds(0, t + 2, rc1, ra1, sc1);
       __syncthreads();
     }
     const int rem = nst - t;
     if (rem == 3) {
-      load_global(t + 2, ic, ia, rc1, ra1);
+      load_global(t + 2, ic, ia, rc1, ra1, sc1);
       compute(0);
-      store_lds(1, t + 1, rc0, ra0);
+      store_lds(1, t + 1, rc0, ra0, sc0);
       __syncthreads();
       compute(1);
-      store_lds(0, t + 2, rc1, ra1);
+      store_lds(0, t + 2, rc1, ra1, sc1);
       __syncthreads();
       compute(0);
     } else if (rem == 2) {
       compute(0);
-      store_lds(1, t + 1, rc0, ra0);
+      store_lds(1, t + 1, rc0, ra0, sc0);
       __syncthreads();
       compute(1);
     } else {
@@ -708,7 +733,13 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   M3_REQUIRE(!a->a_row_idx || a->a_row_div >= 1, "m3_wgrad_tn: a_row_div");
   WgradDev d;
   d.dC = (const char *)a->dC; d.lddc_b = a->lddc * es; d.c_row_idx = a->c_row_idx;
+  M3_REQUIRE(a->c_row_idx || (!a->c_row_scale && a->c_row_div <= 1), "m3_wgrad_tn: c_row_div / c_row_scale need c_row_idx");
+  M3_REQUIRE(a->c_row_div >= 0, "m3_wgrad_tn: c_row_div");
+  d.c_row_div = (a->c_row_idx && a->c_row_div >= 1) ? a->c_row_div : 1;
+  d.c_row_scale = a->c_row_scale;
+  d.c_row_sh = div_shift(d.c_row_div);
   d.A = (const char *)a->A; d.lda_b = a->lda * es; d.a_row_idx = a->a_row_idx; d.a_row_div = a->a_row_idx ? a->a_row_div : 1;
+  d.a_row_sh = div_shift(d.a_row_div);
   d.M = a->M; d.N = a->N; d.K = a->K; d.G = a->G; d.group_offsets = a->group_offsets;
   d.splits = a->splits; d.ws = a->ws; d.bias_ws = a->bias_ws;
   M3_REQUIRE(a->chunk_rows >= 0 && (a->chunk_rows == 0 || (a->group_offsets && a->chunk_rows % WG_ROWS == 0 && a->units >= 1 && a->G <= 64)),
@@ -719,7 +750,7 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   // wide tiles (fp16): the shapes m3_wgrad_tile() names; the caller sized `splits` / `units` for that tile count
   int tn_w = 0, tk_w = 0;
   m3_wgrad_tile(a->N, a->K, a->dtype, &tn_w, &tk_w);
-  if ((tn_w != WG_T || tk_w != WG_T) && (d.a_row_div & (d.a_row_div - 1)) == 0) {
+  if ((tn_w != WG_T || tk_w != WG_T) && (d.a_row_div & (d.a_row_div - 1)) == 0 && !d.c_row_scale && d.c_row_div == 1) {
     constexpr int WR = M3_WGRAD_WIDE_ROWS;
     const bool wide_k = tk_w == 384;
     d.tiles_k = a->K / tk_w;
@@ -745,27 +776,29 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   const dim3 grid(tiles_n * d.tiles_k, a->chunk_rows ? a->units : a->G, a->chunk_rows ? 1 : a->splits), block(WG_THREADS);
   M3_REQUIRE(a->N * es >= 16 && a->K * es >= 16, "m3_wgrad_tn: N, K too small");
   const size_t lds16 = 4 * WgLds<half_t>::ROWS * WgLds<half_t>::STRIDE, lds32 = 4 * WgLds<float>::ROWS * WgLds<float>::STRIDE;
+  const bool sc = a->c_row_scale != nullptr;
 #define M3_WG(TT, LDS)                                                                               \
   do {                                                                                               \
-    if (gc && ga) hipLaunchKernelGGL((wgrad_tn_kernel<TT, true, true>), grid, block, LDS, s, d);     \
+    if (sc && ga) hipLaunchKernelGGL((wgrad_tn_kernel<TT, true, true, true>), grid, block, LDS, s, d);    \
+    else if (sc) hipLaunchKernelGGL((wgrad_tn_kernel<TT, true, false, true>), grid, block, LDS, s, d);    \
+    else if (gc && ga) hipLaunchKernelGGL((wgrad_tn_kernel<TT, true, true>), grid, block, LDS, s, d); \
     else if (gc) hipLaunchKernelGGL((wgrad_tn_kernel<TT, true, false>), grid, block, LDS, s, d);     \
     else if (ga) hipLaunchKernelGGL((wgrad_tn_kernel<TT, false, true>), grid, block, LDS, s, d);     \
     else hipLaunchKernelGGL((wgrad_tn_kernel<TT, false, false>), grid, block, LDS, s, d);            \
   } while (0)
   static bool attr_set = false;
   if (!attr_set) {                               // both images exceed the 64 KiB a launch gets without asking
-    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<float, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
-    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<float, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
-    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<float, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
-    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<float, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
-    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<bf16_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
-    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<bf16_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
-    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<bf16_t, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
-    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<bf16_t, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
-    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<half_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
-    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<half_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
-    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<half_t, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
-    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<half_t, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+#define M3_WG_ATTR(TT, LDS)                                                                                                             \
+    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<TT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);      \
+    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<TT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);     \
+    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<TT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);     \
+    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<TT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);    \
+    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<TT, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); \
+    (void)hipFuncSetAttribute((const void *)wgrad_tn_kernel<TT, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    M3_WG_ATTR(float, lds32)
+    M3_WG_ATTR(bf16_t, lds16)
+    M3_WG_ATTR(half_t, lds16)
+#undef M3_WG_ATTR
     attr_set = true;
   }
   if (a->dtype == M3_F16) M3_WG(half_t, lds16);

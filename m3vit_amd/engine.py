@@ -51,9 +51,11 @@ class BackboneEngine:
         checkpoint: the reference's default memory mode (`use_checkpointing`, train_fastmoe.py:178 ->
         torch.utils.checkpoint around every block, vision_transformer_moe.py:495-524): forward keeps only each block's
         input; backward re-runs a block's forward (same kernels, same inputs: bit-identical activations) right before
-        its backward.  All blocks then share ONE set of activation buffers."""
+        its backward.  All blocks then share ONE set of activation buffers.  With sharded experts (ep_world > 1, the
+        reference's default combination) the recompute repeats NO collective: what crossed the wire in the forward - the
+        exchange plan, the rows received for the local experts and the expert outputs that came back - is kept per MoE
+        block, and only the local work (gate, FC1 of the local experts) is re-run."""
         assert not (checkpoint and wgrad_stream), "checkpoint mode re-uses the activation buffers a wgrad stream may still read"
-        assert not (checkpoint and ep_world > 1), "checkpoint mode is single-rank (the recompute would repeat the exchanges)"
         self.checkpoint = bool(checkpoint)
         assert dtype in (torch.float16, torch.bfloat16, torch.float32), "activation dtype: float16, bfloat16 or float32"
         self.cfg = cfg
@@ -138,8 +140,10 @@ class BackboneEngine:
         self.act = []
         shared = {}                                            # checkpoint mode: one buffer per (block kind, name)
 
+        keep = ("x2", "y") if self.ep_world > 1 else ("x2",)     # expert parallel: the returned expert outputs stay per block
+
         def buf(a, key, *shape, dtype=None):
-            if self.checkpoint and key != "x2":
+            if self.checkpoint and key not in keep:
                 k_ = (a["_moe"], key)
                 if k_ not in shared:
                     shared[k_] = self._e(*shape, dtype=dtype)
@@ -181,7 +185,9 @@ class BackboneEngine:
         self.s_dh32 = self._e(T, D, dtype=f32)
         self.s_do = self._e(T, D)
         self.s_dqkv = self._e(T, 3 * D)
-        self.s_dy = self._e(R, D)
+        import os
+        self._keep_dy = os.environ.get("M3_KEEP_DY") == "1"            # diagnostic A/B switch
+        self.s_dy = self._e(R, D) if (self.ep_world > 1 or self._keep_dy) else None   # local experts read score * d x straight from d x
         self.s_dxe = self._e(R, D)
         self.s_dscore = self._e(T, self.k, dtype=f32)
         self.s_dpatch = self._e(self.B * self.np_, D)
@@ -196,7 +202,12 @@ class BackboneEngine:
         cs = max(int(ops.lib().m3_colsum_ws_elems(T, 3 * D, 1)), int(ops.lib().m3_colsum_ws_elems(T, self.Hd, 1)),
                  int(ops.lib().m3_colsum_ws_elems(R, max(self.Hm, D), self.E)))
         self.ws_colsum = self._e(cs, dtype=f32)
-        self.ws_ln = self._e(2 * ops.lib().m3_ln_bwd_blocks(T) * D, dtype=f32)
+        # LayerNorm parameter-gradient partials: one slot per LayerNorm (2 * block + {0: norm1, 1: norm2}), reduced by ONE
+        # launch per backward_blocks() call instead of one 24-workgroup launch behind every LayerNorm backward
+        self.ln_nblk = int(ops.lib().m3_ln_bwd_blocks(T, D))
+        self.ws_ln = self._e(2 * self.depth, 2, self.ln_nblk, D, dtype=f32)
+        self.ln_table = ops.LnGradTable([(self.grads[f"blocks.{i}.{n}.weight"], self.grads[f"blocks.{i}.{n}.bias"])
+                                         for i in range(self.depth) for n in ("norm1", "norm2")], self.dev)
         need_dq = int(ops.lib().m3_attention_bwd_ws_elems(self.B, self.N, self.heads, self.dh))
         self.ws_dq = self._e(need_dq, dtype=f32) if need_dq else None
         self.ws_gate_dw = self._e(ops.lib().m3_gate_dw_blocks(T) * self.cfg_d_gate() * self.E, dtype=f32)
@@ -365,7 +376,7 @@ class BackboneEngine:
                              noise=noise, noise_std=std, dense=True, loss_acc=loss_acc)
             a["gate"] = g
             if self.ep_world > 1:
-                self._experts_fwd_ep(i, a, g)
+                self._experts_fwd_ep(i, a, g, recompute=loss_acc is None)
             else:
                 r = ops.route_build(g["idx32"], self.E)
                 a["route"] = r
@@ -425,14 +436,26 @@ class BackboneEngine:
                                group=self.ep_group)
         return out
 
-    def _experts_fwd_ep(self, i, a, g):
+    def _experts_fwd_ep(self, i, a, g, recompute=False):
         """EP forward of one MoE layer: ONE count exchange + ONE row exchange each way (m3vit_amd/ep.py has
         the same logic for the module API).  Rows are routed by GLOBAL expert id, so the expert-major send
         buffer is already grouped by destination rank; received rows are regrouped from (src, expert) to
-        (expert, src) order for the local grouped GEMMs."""
+        (expert, src) order for the local grouped GEMMs.
+        recompute (checkpoint mode, called from backward_blocks): the gate has just been re-run on the same input, so the
+        routing is the forward's; the plan, the received rows and the returned outputs a["y"] were kept - only FC1 of the
+        local experts is run again (its hidden activations are what the backward needs), no collective."""
         import torch.distributed as dist
         b = f"blocks.{i}."
         p, k, D, dev = self.params, self.k, self.D, self.dev
+        if recompute:
+            ep = a["ep"]
+            n = ep["n"]
+            if n > 0:
+                ep["hid_pre"], ep["hid"] = self._e(n, self.Hm), self._e(n, self.Hm)
+                ops.gemm_nt(ep["x_recv"], self.wc[b + "mlp.experts.htoh4"], ep["hid"], M=n,
+                            bias=p[b + "mlp.experts.htoh4.bias"], act=M3_ACT_GELU, pre_out=ep["hid_pre"],
+                            a_row_idx=ep["rg"], a_row_div=1, group_offsets=ep["offsets"], tile_starts=ep["tile_starts"])
+            return
         r = ops.route_build(g["idx32"], self.E, want_counts64=True)
         a["route"] = r
         x_send = self._e(self.R, D)
@@ -458,6 +481,8 @@ class BackboneEngine:
                         c_row_idx=ep["rg"], group_offsets=ep["offsets"], tile_starts=ep["tile_starts"])
         y_send = self._a2a(y_recv, plan.out_splits, plan.in_splits)
         ops.gather_rows(y_send, r.pos, a["y"])                       # back to token-major [T*k, D]
+        if self.checkpoint:                                          # local hidden activations: recomputed in backward
+            ep["hid_pre"] = ep["hid"] = None
         a["ep"] = ep
 
     def _experts_bwd_ep(self, i, a):
@@ -580,20 +605,46 @@ class BackboneEngine:
                 dh2 = self.s_dh
             else:
                 g, r = a["gate"], a["route"]
-                self._before_write("dy")
-                ops.combine_bwd(dx, a["y"], a["score_s"] if sm is not None else g["score"], self.s_dy, self.s_dscore)
-                if sm is not None:
-                    self.s_dscore.mul_(a["sm_tok"])         # d score = scale * d(scale * score)
-                if self.ep_world > 1:
-                    self._experts_bwd_ep(i, a)
+                score = a["score_s"] if sm is not None else g["score"]
+                if self.ep_world > 1 or self._keep_dy:
+                    self._before_write("dy")
+                    ops.combine_bwd(dx, a["y"], score, self.s_dy, self.s_dscore)
+                    if sm is not None:
+                        self.s_dscore.mul_(a["sm_tok"])         # d score = scale * d(scale * score)
+                    if self.ep_world > 1:
+                        self._experts_bwd_ep(i, a)
+                    else:       # diagnostic path (M3_KEEP_DY=1): the materialised d y of rounds 1-2
+                        dhp = self.s_dpre[: R * self.Hm].view(R, self.Hm)
+                        self._wgrad(self.s_dy, a["hid"], b + "mlp.experts.h4toh.weight", M=R, c_row_idx=r.row_of_slot,
+                                    group_offsets=r.offsets, bias=b + "mlp.experts.h4toh.bias", reads=("dy",))
+                        self._before_write("dpre")
+                        ops.gemm_nt(self.s_dy, self.wt[b + "mlp.experts.h4toh"], dhp, M=R, gelu_grad_pre=a["hid_pre"],
+                                    a_row_idx=r.row_of_slot, a_row_div=1, group_offsets=r.offsets, tile_starts=r.tile_starts)
+                        self._wgrad(dhp, a["h2"], b + "mlp.experts.htoh4.weight", M=R, a_row_idx=r.row_of_slot,
+                                    a_row_div=k, group_offsets=r.offsets, bias=b + "mlp.experts.htoh4.bias", reads=("dpre",))
+                        ops.gemm_nt(dhp, self.wt[b + "mlp.experts.htoh4"], self.s_dxe, M=R, c_row_idx=r.row_of_slot,
+                                    group_offsets=r.offsets, tile_starts=r.tile_starts)
                 else:
+                    # The combine's backward d y[t*k+j] = score[t,j] * d x[t] is a row scaling, and a row scaling commutes
+                    # with the expert GEMMs behind it: FC2's input-gradient GEMM gathers its rows from d x (activation
+                    # dtype copy, [T, D]) through row_of_slot / k and applies the score in its epilogue; FC2's weight
+                    # gradient takes the same rows and multiplies by the score where they enter LDS.  The [T*k, D] copy
+                    # d y is never written (one 2*R*D-byte store and two such reads less per MoE block); the combine
+                    # backward only produces d score.
+                    if not have_dx_t:
+                        self._before_write("dx_t")
+                        ops.cast_f32(dx, self.s_dx_t)
+                    ops.combine_bwd(dx, a["y"], score, None, self.s_dscore)
+                    if sm is not None:
+                        self.s_dscore.mul_(a["sm_tok"])         # d score = scale * d(scale * score)
                     dhp = self.s_dpre[: R * self.Hm].view(R, self.Hm)
-                    self._wgrad(self.s_dy, a["hid"], b + "mlp.experts.h4toh.weight", M=R, c_row_idx=r.row_of_slot,
-                                group_offsets=r.offsets, bias=b + "mlp.experts.h4toh.bias", reads=("dy",))
+                    self._wgrad(self.s_dx_t, a["hid"], b + "mlp.experts.h4toh.weight", M=R, c_row_idx=r.row_of_slot,
+                                c_row_div=k, c_row_scale=score, group_offsets=r.offsets,
+                                bias=b + "mlp.experts.h4toh.bias", reads=("dx_t",))
                     self._before_write("dpre")
-                    ops.gemm_nt(self.s_dy, self.wt[b + "mlp.experts.h4toh"], dhp, M=R, gelu_grad_pre=a["hid_pre"],
-                                a_row_idx=r.row_of_slot, a_row_div=1, group_offsets=r.offsets,
-                                tile_starts=r.tile_starts)
+                    ops.gemm_nt(self.s_dx_t, self.wt[b + "mlp.experts.h4toh"], dhp, M=R, gelu_grad_pre=a["hid_pre"],
+                                a_row_idx=r.row_of_slot, a_row_div=k, row_scale=score, row_scale_idx=r.row_of_slot,
+                                group_offsets=r.offsets, tile_starts=r.tile_starts)
                     self._wgrad(dhp, a["h2"], b + "mlp.experts.htoh4.weight", M=R, a_row_idx=r.row_of_slot,
                                 a_row_div=k, group_offsets=r.offsets, bias=b + "mlp.experts.htoh4.bias", reads=("dpre",))
                     ops.gemm_nt(dhp, self.wt[b + "mlp.experts.htoh4"], self.s_dxe, M=R, c_row_idx=r.row_of_slot,
@@ -623,8 +674,8 @@ class BackboneEngine:
                     self._task_feature_block_bwd(a, dl, st)
                 dh2 = self.s_dh32
             self._before_write("dx_t")
-            ops.layernorm_bwd(dh2, a["x1"], a["mean2"], a["rstd2"], p[b + "norm2.weight"], dx, other,
-                              gr[b + "norm2.weight"], gr[b + "norm2.bias"], beta=1, ws=self.ws_ln,
+            ops.layernorm_bwd(dh2, a["x1"], a["mean2"], a["rstd2"], p[b + "norm2.weight"], dx, other, None, None,
+                              ws=self.ws_ln[2 * i + 1],
                               dx_act=self.s_dx_t if sa is None else None)     # also emits the activation-dtype copy
             dx, other = other, dx                                        # dx = d x1
             if sa is not None:
@@ -636,14 +687,20 @@ class BackboneEngine:
                               dq_ws=self.ws_dq)
             self._wgrad(self.s_dqkv, a["h1"], b + "attn.qkv.weight", bias=b + "attn.qkv.bias", reads=("dqkv",))
             ops.gemm_nt(self.s_dqkv, self.wt[b + "attn.qkv"], self.s_dh)
-            nxt_dense = i > 0 and not self.is_moe[i - 1] and self.act[i - 1].get("ps") is None   # the block below consumes dx_t directly
-            if nxt_dense:
+            # does the block below consume the activation-dtype copy of d x directly?  (a dense block without DropPath: fc2's
+            # backward GEMMs; an MoE block with local experts: FC2's backward GEMMs, which apply the gate score themselves)
+            nxt_dx_t = i > 0 and ((self.is_moe[i - 1] and self.ep_world == 1) or
+                                  (not self.is_moe[i - 1] and self.act[i - 1].get("ps") is None))
+            if nxt_dx_t:
                 self._before_write("dx_t")
-            ops.layernorm_bwd(self.s_dh, a["x_in"], a["mean1"], a["rstd1"], p[b + "norm1.weight"], dx, other,
-                              gr[b + "norm1.weight"], gr[b + "norm1.bias"], beta=1, ws=self.ws_ln,
-                              dx_act=self.s_dx_t if nxt_dense else None)
+            ops.layernorm_bwd(self.s_dh, a["x_in"], a["mean1"], a["rstd1"], p[b + "norm1.weight"], dx, other, None, None,
+                              ws=self.ws_ln[2 * i],
+                              dx_act=self.s_dx_t if nxt_dx_t else None)
             dx, other = other, dx
-            have_dx_t = nxt_dense
+            have_dx_t = nxt_dx_t
+        # norm weight / bias gradients of the blocks just done, all in one launch (their partial slots are contiguous)
+        if hi >= lo:
+            ops.layernorm_bwd_reduce(self.ws_ln, self.ln_nblk, self.D, self.ln_table, 2 * lo, 2 * (hi - lo + 1), beta=1)
         st.update(dx=dx, other=other, have_dx_t=have_dx_t)
 
     def backward_sync_wgrad(self):

@@ -187,7 +187,7 @@ def ep_plan(send_counts64, recv_counts64, world: int, e_loc: int, regroup_buf: t
 # ----------------------------------------------------------------------------- GEMM
 def gemm_nt(A, B, C, *, M=None, bias=None, act=M3_ACT_NONE, pre_out=None, gelu_grad_pre=None, residual=None,
             a_row_idx=None, a_row_div=1, c_row_idx=None, group_offsets=None, tile_starts=None, row_scale=None,
-            row_scale_div=1):
+            row_scale_div=1, row_scale_idx=None):
     """C[m,n] = epi(sum_k A[arow(m),k] B[g][n,k]).  A [rows,K]; B [N,K] or [G,N,K]; C [rows,N] (f32 or A.dtype)."""
     _req(A, name="A"); _req(B, A.dtype, "B"); _req(C, name="C")
     G = 1 if B.dim() == 2 else B.shape[0]
@@ -211,6 +211,10 @@ def gemm_nt(A, B, C, *, M=None, bias=None, act=M3_ACT_NONE, pre_out=None, gelu_g
         _req(row_scale, torch.float32, "row_scale")
     a.row_scale = row_scale.data_ptr() if row_scale is not None else None
     a.row_scale_div = row_scale_div
+    if row_scale_idx is not None:
+        _req(row_scale_idx, torch.int32, "row_scale_idx")
+        assert row_scale is not None
+    a.row_scale_idx = row_scale_idx.data_ptr() if row_scale_idx is not None else None
     if M is None:
         M = a_row_idx.numel() if a_row_idx is not None else A.shape[0]
     a.M = M; a.N = N; a.K = K; a.G = G
@@ -281,14 +285,15 @@ def ffn_fwd(X, W1, W2p, Y, *, b1=None, b2=None, M=None, residual=None, x_row_idx
 
 
 def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None, a_row_idx=None, a_row_div=1,
-             group_offsets=None, db=None, beta_db=None):
+             group_offsets=None, db=None, beta_db=None, c_row_div=1, c_row_scale=None):
     """dW[g][n,k] (+)= sum_m dC[crow(m),n] A[arow(m),k].  dW f32 [N,K] or [G,N,K].
-    db (optional, f32 [N] / [G,N]): bias gradient = column sums of dC, fused into the same pass."""
+    db (optional, f32 [N] / [G,N]): bias gradient = column sums of dC, fused into the same pass.
+    c_row_div / c_row_scale (with c_row_idx): slot m reads c_row_scale[c_row_idx[m]] * dC[c_row_idx[m] // c_row_div]."""
     _req(dC, name="dC"); _req(A, dC.dtype, "A"); _req(dW, torch.float32, "dW")
     G = 1 if dW.dim() == 2 else dW.shape[0]
     N, K = dW.shape[-2], dW.shape[-1]
     if M is None:
-        M = dC.shape[0]
+        M = c_row_idx.numel() if c_row_idx is not None else dC.shape[0]
     if splits is None:
         splits = default_wgrad_splits(M, N, K, G, dC.dtype)
     balanced = group_offsets is not None
@@ -300,6 +305,11 @@ def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None,
     a = WgradArgs()
     a.dC = dC.data_ptr(); a.lddc = dC.stride(0)
     a.c_row_idx = c_row_idx.data_ptr() if c_row_idx is not None else None
+    a.c_row_div = c_row_div
+    if c_row_scale is not None:
+        _req(c_row_scale, torch.float32, "c_row_scale")
+        assert c_row_idx is not None
+    a.c_row_scale = c_row_scale.data_ptr() if c_row_scale is not None else None
     a.A = A.data_ptr(); a.lda = A.stride(0)
     a.a_row_idx = a_row_idx.data_ptr() if a_row_idx is not None else None
     a.a_row_div = a_row_div
@@ -412,6 +422,7 @@ def combine_fwd(y, score, residual, out):
 
 
 def combine_bwd(dout, y, score, dy, dscore):
+    """dy (may be None: d score only) [T*k, D] = score * dout ; dscore [T, k] = <dout, y>"""
     T, k = score.shape
     D = y.shape[-1]
     check(lib().m3_combine_bwd(_p(dout), _p(y), dt_code(y.dtype), _p(score), T, k, D, _p(dy), _p(dscore), _stream()),
@@ -432,13 +443,36 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps=1e-6):
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx_res, dx, dgamma, dbeta, beta=0, ws=None, dx_act=None):
+    """dgamma = dbeta = None: the parameter-gradient partials stay in ws (fp32 [2, ln_bwd_blocks(T), D]) for a later
+    batched layernorm_bwd_reduce."""
     T, D = x.shape
-    nblk = lib().m3_ln_bwd_blocks(T)
+    nblk = lib().m3_ln_bwd_blocks(T, D)
     if ws is None:
         ws = torch.empty(2 * nblk * D, dtype=torch.float32, device=x.device)
     check(lib().m3_layernorm_bwd(_p(dy), dt_code(dy.dtype), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx_res), T, D,
                                  _p(dx), _p(ws), _p(dgamma), _p(dbeta), beta, _p(dx_act),
                                  dt_code(dx_act.dtype) if dx_act is not None else M3_F32, _stream()), "m3_layernorm_bwd")
+
+
+class LnGradTable:
+    """device-resident (dgamma, dbeta) pointer pairs of a model's LayerNorms, in workspace-slot order"""
+
+    def __init__(self, pairs, device):
+        import struct
+        self.keep = pairs
+        for g, b in pairs:
+            _req(g, torch.float32, "dgamma"); _req(b, torch.float32, "dbeta")
+        raw = b"".join(struct.pack("QQ", g.data_ptr(), b.data_ptr()) for g, b in pairs)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.n = len(pairs)
+
+
+def layernorm_bwd_reduce(ws, nblk, D, table: LnGradTable, first, count, beta=1):
+    """dgamma / dbeta of LayerNorms first .. first+count-1 from their partial slots ws[j] (fp32 [n, 2, nblk, D])"""
+    _req(ws, torch.float32, "ws")
+    assert ws.dim() == 4 and ws.shape[1] == 2 and ws.shape[2] == nblk and ws.shape[3] == D and first + count <= table.n
+    check(lib().m3_layernorm_bwd_reduce(_p(ws), ws.stride(0), nblk, D, _p(table.table), first, count, beta, _stream()),
+          "m3_layernorm_bwd_reduce")
 
 
 # ------------------------------------------------------------------------ attention

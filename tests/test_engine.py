@@ -149,6 +149,28 @@ def test_config4_vit_base_ratio4_nyud_resolution_f16():
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float16, F16_TOL)])
+def test_config2_vit_small_task_conditioned_pascal_resolution(dtype, tol):
+    """BASELINE configs[2] at its own shape: ViT-Small width (D=384, 12 heads of 32), 512x512 PASCAL images (N=1025:
+    the streaming dh=32 attention kernels), ONE shared gate per MoE block fed cat(token, tsf) with
+    gate_task_specific_dim = 64 (gate_dim 389 = 384 + 5 tasks as the configs write it; the gate's input width is
+    D + gtsd = 448: custom_moe_layer.py:143-150,161-181), E=16, k=4, two of the five PASCAL task passes (the first and
+    the last: one-hot columns 0 and 4 of the task embedding, vision_transformer_moe.py:793-797) accumulated; depth cut
+    to 2 and one image so that the float64 oracle finishes in seconds.  Tokens, cv loss and every gradient, including
+    the task rows w_gate[D:] and the gate_task_represent MLP."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import ref_torch as R
+    cfg = R.BackboneCfg(img_size=(512, 512), embed_dim=384, depth=2, num_heads=12, mlp_ratio=4.0, moe_mlp_ratio=1.0,
+                        moe_experts=16, moe_top_k=4, gate_dim=389, multi_gate=False, gate_task_specific_dim=64)
+    assert cfg.num_tokens == 1025 and cfg.num_tasks == 5
+    eng = _check_backbone(cfg, dtype, tol, tasks=(0, 4), B=1, seed=11, follow_routing=dtype == torch.float16)
+    assert eng.dh == 32 and eng.cfg_d_gate() == 448
+    for n in ("gate_task_represent.fc1.weight", "gate_task_represent.fc2.weight", "gate_task_represent.norm.weight"):
+        assert float(eng.grads[n].abs().max()) > 0.0, n
+    assert float(eng.grads["blocks.1.mlp.gate.w_gate"][384:].abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float16, F16_TOL)])
 def test_engine_drop_path_matches_oracle(dtype, tol):
     """Stochastic depth in the fused executor (vision_transformer_moe.py:167-185,441,450; the AMP trainer's config has
     drop_path 0.1, pretrain/configs/deit_moe_small.yaml:51): the caller draws the per-sample factors floor(keep + U) / keep

@@ -198,3 +198,72 @@ def test_expert_parallel_step_with_interleaved_task_streams_two_ranks_one_gpu():
     for p in procs:
         p.join(timeout=30)
     assert all(r[1] == "ok" for r in res), res
+
+
+def _ep_ckpt_worker(rank, world, port, q):
+    """expert parallel x activation checkpointing (the reference's default combination: train_fastmoe.py:178 with sharded
+    experts): the recompute of a block in backward repeats no collective - the exchange plan, the received rows and the
+    returned expert outputs are kept - and the gradients are those of the keep-everything expert-parallel engine, bit for
+    bit (same kernels on the same inputs)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from m3vit_amd.config import BackboneConfig, init_params
+        from m3vit_amd.engine import BackboneEngine
+        torch.cuda.set_device(0)
+        cfg = BackboneConfig(img_size=(32, 48), embed_dim=64, depth=4, num_heads=2, moe_experts=4, moe_top_k=2,
+                             gate_dim=66, multi_gate=True)
+        P = init_params(cfg, seed=3, zero_bias=False)
+        B = 3
+        g = torch.Generator().manual_seed(90 + rank)
+        img = torch.randn(B, 3, 32, 48, generator=g).cuda()
+        dtok = (torch.randn(B, cfg.num_tokens, 64, generator=g) * 0.1).cuda()
+        for dtype in (torch.float32, torch.float16):
+            keep = BackboneEngine(cfg, P, batch=B, dtype=dtype, ep_world=world, ep_rank=rank)
+            ck = BackboneEngine(cfg, P, batch=B, dtype=dtype, ep_world=world, ep_rank=rank, checkpoint=True)
+            calls = []
+            orig = dist.all_to_all_single
+
+            def counted(*a, **kw):
+                calls.append(1)
+                return orig(*a, **kw)
+            for task in (0, 1):
+                t0, c0 = keep.forward(img, task)
+                keep.backward(dtok, cv_weight=0.01)
+                t1, c1 = ck.forward(img, task)
+                dist.all_to_all_single = counted            # from here on only the backward's own exchanges may run
+                try:
+                    n0 = len(calls)
+                    ck.backward(dtok, cv_weight=0.01)
+                    n_bwd = len(calls) - n0
+                finally:
+                    dist.all_to_all_single = orig
+                assert torch.equal(t0, t1) and torch.equal(c0, c1), (dtype, task)
+                # backward of an MoE layer: d y out + d x back = 2 row exchanges; the recompute adds none
+                assert n_bwd == 2 * sum(ck.is_moe), (n_bwd, sum(ck.is_moe))
+            torch.cuda.synchronize()
+            assert torch.equal(keep.flat_grads, ck.flat_grads), (dtype, rel(ck.flat_grads, keep.flat_grads))
+            assert float(ck.flat_grads.abs().max()) > 0
+        q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_expert_parallel_with_activation_checkpointing_two_ranks_one_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ep_ckpt_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert all(r[1] == "ok" for r in res), res

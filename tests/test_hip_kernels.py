@@ -156,6 +156,60 @@ def test_grouped_gemm_gather_scatter(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_expert_backward_takes_the_combine_gradient_unmaterialised(ops, dtype):
+    """The backward of the combine bmm(gate_score, moe_outp) (custom_moe_layer.py:298-305) is the row scaling
+    d y[t*k+j] = score[t,j] * d out[t].  FC2's input-gradient GEMM and weight-gradient GEMM take it straight from
+    d out [T, D]: gathered through the slot -> routed-entry map (div k) and scaled by the entry's score in the GEMM epilogue
+    (row_scale_idx) / at the weight-gradient kernel's LDS store (c_row_scale) - against the same products on the
+    materialised d y, in fp64."""
+    T, k, D, H, E = 650, 4, 384, 384, 16
+    g = torch.Generator().manual_seed(31)
+    idx = torch.stack([torch.randperm(E, generator=g)[:k] for _ in range(T)]).to(torch.int32).to(dev())
+    idx[:40] = torch.tensor([0, 1, 2, 3], dtype=torch.int32)                   # ragged groups
+    r = ops.route_build(idx, E)
+    R = T * k
+    ros = r.row_of_slot.long()
+    e_of_slot = idx.flatten().long()[ros]
+    dout32 = rnd(T, D, seed=32)
+    dout = dout32.to(dtype)
+    score = torch.rand(T, k, generator=g).to(dev()) * 0.5 + 0.05
+    y = rnd(R, D, dtype=dtype, seed=33)
+    hid = rnd(R, H, dtype=dtype, seed=34)                                      # expert-major rows
+    pre = rnd(R, H, dtype=dtype, seed=35)
+    W2t = rnd(E, H, D, dtype=dtype, scale=0.05, seed=36)                       # [E, K = D -> N = H] operand of the dgrad
+    # d score only (no d y written)
+    dsc = torch.full((T, k), float("nan"), device=dev())
+    ops.combine_bwd(dout32, y, score, None, dsc)
+    assert rel(dsc, torch.einsum("td,tjd->tj", dout32.double(), y.double().view(T, k, D))) < TOL[dtype]
+    dy_tm = (score.double().view(T, k, 1) * dout.double().view(T, 1, D)).view(R, D)       # token-major d y, fp64
+    # FC2 input gradient: dhp[m] = gelu'(pre[m]) * score[e(m)] * (dout[t(m)] @ W2[g])
+    dhp = torch.full((R, H), float("nan"), dtype=dtype, device=dev())
+    ops.gemm_nt(dout, W2t, dhp, M=R, gelu_grad_pre=pre, a_row_idx=r.row_of_slot, a_row_div=k, row_scale=score,
+                row_scale_idx=r.row_of_slot, group_offsets=r.offsets, tile_starts=r.tile_starts)
+    ref = torch.einsum("rd,rhd->rh", dy_tm[ros], W2t.double()[e_of_slot]) * gelu_grad64(pre.double())
+    assert rel(dhp, ref) < TOL[dtype]
+    # FC2 weight + bias gradient: dW2[g] = sum_m (score * dout)[m]^T hid[m]
+    dW = torch.zeros(E, D, H, device=dev()); db = torch.zeros(E, D, device=dev())
+    ops.wgrad_tn(dout, hid, dW, M=R, beta=1, c_row_idx=r.row_of_slot, c_row_div=k, c_row_scale=score,
+                 group_offsets=r.offsets, db=db)
+    ref_dw = torch.zeros(E, D, H, dtype=torch.float64, device=dev())
+    ref_dw.index_add_(0, e_of_slot, torch.einsum("rd,rh->rdh", dy_tm[ros], hid.double()))
+    ref_db = torch.zeros(E, D, dtype=torch.float64, device=dev())
+    ref_db.index_add_(0, e_of_slot, dy_tm[ros])
+    # the factor is applied in the activation dtype (fp16: one extra rounding per element, the one a stored d y has)
+    assert rel(dW, ref_dw) < TOL[dtype]
+    assert rel(db, ref_db) < max(TOL[dtype], 1e-4)
+    # and with a gather on the A side too (the weight gradient of a layer whose input rows are routed copies)
+    x = rnd(T, H, dtype=dtype, seed=37)
+    dW3 = torch.zeros(E, D, H, device=dev())
+    ops.wgrad_tn(dout, x, dW3, M=R, c_row_idx=r.row_of_slot, c_row_div=k, c_row_scale=score, a_row_idx=r.row_of_slot,
+                 a_row_div=k, group_offsets=r.offsets)
+    ref3 = torch.zeros(E, D, H, dtype=torch.float64, device=dev())
+    ref3.index_add_(0, e_of_slot, torch.einsum("rd,rh->rdh", dy_tm[ros], x.double()[ros // k]))
+    assert rel(dW3, ref3) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_wgrad_dense_and_colsum(ops, dtype):
     M, N, K = 2000, 384, 256
     dC, A = rnd(M, N, dtype=dtype, seed=21), rnd(M, K, dtype=dtype, seed=22)
