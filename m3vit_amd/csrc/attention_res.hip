@@ -283,9 +283,19 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
   __syncthreads();
   ATTN_STAMP(2);                                   // operands staged
 
-  const float c1 = scale * AR_LOG2E;
+  const float c1 = scale * AR_LOG2E, inv_c1 = 1.0f / c1;
   const int nkc = NP >> 5;                       // 32-key chunks of the dQ contraction
   const int nsteps = NP >> 5;
+  // K^T fragments of this wave's dQ piece (dt fixed per wave): the same in every step - read once, kept in registers
+  typename Mma<T>::frag ka[AR_MAXN / 32];
+  {
+    const int dt = wave % NDT;
+#pragma unroll
+    for (int c = 0; c < AR_MAXN / 32; ++c) {
+      const int cc = c < nkc ? c : nkc - 1;
+      ka[c] = tr_frag<T, DH>(sK, cc * 32, dt * 16, li, lg);
+    }
+  }
   for (int st = 0; st < nsteps; ++st) {
     const int qs = st * 32;
     char *dsb = sdS + (st & 1) * NP * 64;
@@ -299,14 +309,20 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
         qfr[ch] = row_frag<T, DH>(sQ, qs + qt * 16, ch, li, lg);
         dof[ch] = row_frag<T, DH>(sdO, qs + qt * 16, ch, li, lg);
       }
-      float l2[4], dl[4];
+      // Row constants ride in as the MFMA chains' initial accumulators: S' = Q K^T - lse / (scale log2 e) and
+      // dP' = dO V^T - delta leave the chains ready, so P = exp2(c1 S') and dS = P dP' are two multiplies and one exp2
+      // per element instead of fma + exp2 + sub + mul (this phase is VALU-bound: N^2 elements per head)
+      f32x4 s0, dp0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { l2[r] = sLse[qs + qt * 16 + 4 * lg + r]; dl[r] = sDelta[qs + qt * 16 + 4 * lg + r]; }
+      for (int r = 0; r < 4; ++r) {
+        s0[r] = -sLse[qs + qt * 16 + 4 * lg + r] * inv_c1;
+        dp0[r] = -sDelta[qs + qt * 16 + 4 * lg + r];
+      }
 #pragma unroll
       for (int kt = 0; kt < KTW; ++kt) {
         const int tix = kt * NW + wave;
         if (tix < nkt) {
-          f32x4 s = zero4, dp = zero4;
+          f32x4 s = s0, dp = dp0;
 #pragma unroll
           for (int ch = 0; ch < NCH; ++ch) {
             s = Mma<T>::mma(qfr[ch], kf[kt][ch], s);
@@ -314,11 +330,11 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
           }
           f32x4 pv;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r] * c1 - l2[r]);
+          for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r] * c1);
           if (tix == nkt - 1 && tix * 16 + li >= N) pv = zero4;          // keys past N live in the last tile only
           pt[qt][kt] = pv;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dst[qt][kt][r] = pv[r] * (dp[r] - dl[r]);
+          for (int r = 0; r < 4; ++r) dst[qt][kt][r] = pv[r] * dp[r];
         } else {
           pt[qt][kt] = zero4;
           dst[qt][kt] = zero4;
@@ -360,18 +376,21 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
     // ---- dQ^T[d = 16*dt + 4*lg + r][q = 16*qt + li] = K^T dS^T, one (qt, dt) piece per wave
     {
       const int qt = wave / NDT, dt = wave - qt * NDT;
-      // all fragment reads first (clamped chunk index: always inside the images), then the dependent MFMA chain
-      typename Mma<T>::frag ka[AR_MAXN / 32], da[AR_MAXN / 32];
+      // all fragment reads first (clamped chunk index: always inside the images), then the MFMA chain - two interleaved
+      // accumulators, so that a product does not wait for its predecessor's result
+      typename Mma<T>::frag da[AR_MAXN / 32];
 #pragma unroll
       for (int c = 0; c < AR_MAXN / 32; ++c) {
         const int cc = c < nkc ? c : nkc - 1;
-        ka[c] = tr_frag<T, DH>(sK, cc * 32, dt * 16, li, lg);
         da[c] = tr_frag<T, 32>(dsb, cc * 32, qt * 16, li, lg);
       }
-      f32x4 acc = zero4;
+      f32x4 acc = zero4, acc2 = zero4;
 #pragma unroll
-      for (int c = 0; c < AR_MAXN / 32; ++c)
+      for (int c = 0; c < AR_MAXN / 32; c += 2) {
         if (c < nkc) acc = Mma<T>::mma(ka[c], da[c], acc);
+        if (c + 1 < nkc) acc2 = Mma<T>::mma(ka[c + 1], da[c + 1], acc2);
+      }
+      acc += acc2;
       const int qr = qs + qt * 16 + li;
       if (qr < N) Vec4<T>::store(dqbase + (int64_t)qr * ld + dt * 16 + 4 * lg, acc * scale);
     }
@@ -645,7 +664,7 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
   }
   __syncthreads();
 
-  const float c1 = scale * AR_LOG2E;
+  const float c1 = scale * AR_LOG2E, inv_c1 = 1.0f / c1;
   const int nsteps = (N + 31) >> 5;
   for (int st = 0; st < nsteps; ++st) {
     const int qs = st * 32, buf = st & 1;
@@ -664,14 +683,17 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
         qfr[ch] = row_frag<T, DH>(cQ, qt * 16, ch, li, lg);
         dof[ch] = row_frag<T, DH>(cdO, qt * 16, ch, li, lg);
       }
-      float l2[4], dl[4];
+      f32x4 s0, dp0;                             // row constants as the chains' initial accumulators (see attention_bwd_res_kernel)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { l2[r] = sLse[buf * 32 + qt * 16 + 4 * lg + r]; dl[r] = sDelta[buf * 32 + qt * 16 + 4 * lg + r]; }
+      for (int r = 0; r < 4; ++r) {
+        s0[r] = -sLse[buf * 32 + qt * 16 + 4 * lg + r] * inv_c1;
+        dp0[r] = -sDelta[buf * 32 + qt * 16 + 4 * lg + r];
+      }
 #pragma unroll
       for (int kt = 0; kt < KTW; ++kt) {
         const int tix = kt * NW + wave;
         if (tix < nkt) {
-          f32x4 s = zero4, dp = zero4;
+          f32x4 s = s0, dp = dp0;
 #pragma unroll
           for (int ch = 0; ch < NCH; ++ch) {
             s = Mma<T>::mma(qfr[ch], kf[kt][ch], s);
@@ -679,11 +701,11 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
           }
           f32x4 pv;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r] * c1 - l2[r]);
+          for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r] * c1);
           if (tix == nkt - 1 && tix * 16 + li >= nkeys) pv = zero4;      // keys past N live in the last tile only
           pt[qt][kt] = pv;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dst[qt][kt][r] = pv[r] * (dp[r] - dl[r]);
+          for (int r = 0; r < 4; ++r) dst[qt][kt][r] = pv[r] * dp[r];
         } else {
           pt[qt][kt] = zero4;
           dst[qt][kt] = zero4;

@@ -612,7 +612,18 @@ __global__ void wgrad_reduce_kernel(const float *ws, int splits, int64_t elems4,
   const int64_t i = blk * blockDim.x + threadIdx.x;
   if (i >= elems4) return;
   f32x4 s = beta ? ((const f32x4 *)dW)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int sp = 0; sp < splits; ++sp) s += ((const f32x4 *)ws)[(int64_t)sp * elems4 + i];
+  // eight slabs' loads in flight before the first add (a thread owns ONE 16-byte column of up to 32 slabs: issued one
+  // dependent load at a time the launch was latency-bound); the summation order is unchanged: slab 0, 1, 2 ...
+  const f32x4 *w = (const f32x4 *)ws + i;
+  int sp = 0;
+  for (; sp + 8 <= splits; sp += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = w[(int64_t)(sp + j) * elems4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  for (; sp < splits; ++sp) s += w[(int64_t)sp * elems4];
   ((f32x4 *)dW)[i] = s;
 }
 

@@ -46,6 +46,8 @@ class MultiTaskStep:
                                                    ep_world=self.world if self.use_ep else 1, ep_rank=rank if self.use_ep else 0,
                                                    wgrad_stream=wg, checkpoint=checkpoint) for _ in self.tasks[1:]]
                                     if (self.par or self.par_ep) else [])
+        # (measured and dropped in round 3, profiles/r03_stream_experiments.txt: a high-priority side stream serialises the
+        # passes - 18.6 -> 24 ms - and starting pass 1 a few forward blocks behind pass 0 only lengthens the step)
         self.streams = [torch.cuda.Stream(device=self.dev) for _ in self.engs[1:]]
         self.flat = self.eng.flat_grads
         # cutting the step only makes sense when there is a collective to hide and the passes run side by side
