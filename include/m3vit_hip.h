@@ -223,6 +223,15 @@ int m3_ffn_fwd(const m3_ffn_args *args, void *stream);
  * Deterministic split over rows: `splits` partial slabs in ws (fp32
  * [splits][G][N][K]) then m3_wgrad_reduce sums them in order (beta = 1 accumulates
  * into dW, as the joint multi-task backward does: train/train_utils.py:449-457). */
+/* A slab reduction that has not been launched yet (the arguments of m3_wgrad_reduce, or with chunk_rows > 0 of
+ * m3_wgrad_reduce_grouped): the next m3_wgrad_tn call of the stream can carry it out in front of its own work
+ * (m3_wgrad_args.prev), which saves one launch per weight-gradient GEMM. */
+typedef struct m3_wgrad_reduce_desc {
+  const float *ws; int32_t splits; int64_t elems;
+  const int32_t *group_offsets; int32_t G; int32_t chunk_rows;
+  float *dW; int32_t beta;
+  const float *bias_ws; int64_t bias_elems; float *db; int32_t beta_db;
+} m3_wgrad_reduce_desc;
 typedef struct {
   const void *dC; int64_t lddc; const int32_t *c_row_idx;
   const void *A; int64_t lda; const int32_t *a_row_idx; int32_t a_row_div;
@@ -248,6 +257,9 @@ typedef struct {
                                       the slot -> routed-entry map with div = k and scaled by the entry's gate score - the
                                       combine backward d moe_outp[t*k+j] = score[t,j] * d out[t]
                                       (custom_moe_layer.py:298-305) without materialising the [T*k, N] copy */
+  const m3_wgrad_reduce_desc *prev; /* optional (host pointer, read during the call): the PREVIOUS call's slab reduction, whose
+                                      slabs must live in another buffer than `ws`; its blocks run first in this launch.  The
+                                      caller reduces the last call of a sequence itself (m3_wgrad_reduce*). */
 } m3_wgrad_args;
 int m3_wgrad_tn(const m3_wgrad_args *args, void *stream);
 /* The output tile (n x k) m3_wgrad_tn uses for a shape - 128 x 128, or, with the wide tiles switched on, for fp16

@@ -42,6 +42,15 @@ class GemmArgs(Structure):
     ]
 
 
+class WgradReduceDesc(Structure):
+    _fields_ = [
+        ("ws", c_void_p), ("splits", c_int32), ("elems", c_int64),
+        ("group_offsets", c_void_p), ("G", c_int32), ("chunk_rows", c_int32),
+        ("dW", c_void_p), ("beta", c_int32),
+        ("bias_ws", c_void_p), ("bias_elems", c_int64), ("db", c_void_p), ("beta_db", c_int32),
+    ]
+
+
 class WgradArgs(Structure):
     _fields_ = [
         ("dC", c_void_p), ("lddc", c_int64), ("c_row_idx", c_void_p),
@@ -54,6 +63,7 @@ class WgradArgs(Structure):
         ("bias_ws", c_void_p),
         ("chunk_rows", c_int32), ("units", c_int32),
         ("c_row_div", c_int32), ("c_row_scale", c_void_p),
+        ("prev", POINTER(WgradReduceDesc)),
     ]
 
 

@@ -51,14 +51,18 @@ template <typename T, int W> __device__ __forceinline__ typename Mma<T>::frag tr
 // (MFMA through Mma<T>::mma: v_mfma_f32_16x16x32_f16 or _bf16)
 
 // ------------------------------------------------------------------------------ forward
-template <typename T, int DH>
-__global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_res_kernel(const T *__restrict__ qkv, int N, int heads,
+// NKT: key tiles, rounded up to a multiple of 4 - a TEMPLATE constant, so that the loops over the key tiles are
+// straight-line code (with a run-time `if (kt < nkt)` every key tile was its own basic block and the 13 independent
+// S^T products + running max of N = 197 ran strictly one after the other).  Keys past the sequence (only in the last four
+// tiles) are masked to -inf; the K / V images are zero-padded to NKT * 16 rows.
+template <typename T, int DH, int NKT>
+__global__ __launch_bounds__(AR_THREADS, DH == 32 ? 4 : 2) void attention_fwd_res_kernel(const T *__restrict__ qkv, int N, int heads,
                                                                            T *__restrict__ o,
                                                                            float *__restrict__ lse, float scale) {
   constexpr int RBY = DH * 2, CPR = RBY / 16, NCH = DH / 32, NDT = DH / 16;
+  constexpr int NKEY = NKT * 16, NQW = NKT / 4;            // padded keys; query tiles per wave (q tiles == key tiles)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int NP = (N + 31) & ~31;
-  char *sK = smem, *sV = smem + NP * RBY;
+  char *sK = smem, *sV = smem + NKEY * RBY;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -70,9 +74,9 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_res_kernel(const 
 
   // this wave's query tiles {wave, wave + 4, ...}: Q fragments straight from global, all issued up front
   const int nkt = (N + 15) >> 4;                 // key tiles == query tiles
-  typename Mma<T>::frag qfs[AR_MAXN / 64][NCH];
+  typename Mma<T>::frag qfs[NQW][NCH];
 #pragma unroll
-  for (int i = 0; i < AR_MAXN / 64; ++i) {
+  for (int i = 0; i < NQW; ++i) {
     const int qrow = (i * 4 + wave) * 16 + li;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_res_kernel(const 
   // K / V images: ALL loads of the thread are issued before the first LDS store (a rolled loop waits for each
   // iteration's loads in turn: in-kernel stamps showed a third of a workgroup's life in this phase)
   {
-    constexpr int SIT = AR_MAXN * CPR / AR_THREADS, SB = SIT < 4 ? SIT : 4;      // batches of <= 4 iterations (registers)
+    constexpr int SIT = NKEY * CPR / AR_THREADS, SB = SIT < 4 ? SIT : 4;      // batches of <= 4 iterations (registers)
 #pragma unroll
     for (int it0 = 0; it0 < SIT; it0 += SB) {
       u32x4 kv[SB], vv[SB];
@@ -99,54 +103,46 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_res_kernel(const 
 #pragma unroll
       for (int it = 0; it < SB; ++it) {
         const int q = (it0 + it) * AR_THREADS + tid, row = q / CPR, c = q % CPR;
-        if (row < NP) {
-          *(u32x4 *)(sK + swo<DH>(row, c * 16)) = kv[it];
-          *(u32x4 *)(sV + swo<DH>(row, c * 16)) = vv[it];
-        }
+        *(u32x4 *)(sK + swo<DH>(row, c * 16)) = kv[it];             // (row < NKEY by construction)
+        *(u32x4 *)(sV + swo<DH>(row, c * 16)) = vv[it];
       }
     }
   }
   __syncthreads();
 
   const float c1 = scale * AR_LOG2E;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < AR_MAXN / 64; ++i) {
+  for (int i = 0; i < NQW; ++i) {
     const int qt = i * 4 + wave;
     if (qt >= nkt) break;
     const int qrow = qt * 16 + li;
-    // S^T tiles: st[kt][r] = S[q = li][key = 16*kt + 4*lg + r]; only the last key tile can hold keys >= N
-    f32x4 st[AR_MAXN / 16];
-    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    // S^T tiles: st[kt][r] = S[q = li][key = 16*kt + 4*lg + r]; keys >= N can only sit in the last four tiles
+    f32x4 st[NKT];
     float mx = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < AR_MAXN / 16; ++kt) {
-      if (kt < nkt) {
-        f32x4 sv = zero4;
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4 sv = zero4;
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) sv = Mma<T>::mma(row_frag<T, DH>(sK, kt * 16, ch, li, lg), qfs[i][ch], sv);
-        if (kt == nkt - 1) {
+      for (int ch = 0; ch < NCH; ++ch) sv = Mma<T>::mma(row_frag<T, DH>(sK, kt * 16, ch, li, lg), qfs[i][ch], sv);
+      if (kt >= NKT - 4) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sv[r] = (kt * 16 + 4 * lg + r < N) ? sv[r] : -INFINITY;
-        }
-        mx = fmaxf(fmaxf(mx, fmaxf(sv[0], sv[1])), fmaxf(sv[2], sv[3]));
-        st[kt] = sv;
-      } else {
-        st[kt] = zero4;
+        for (int r = 0; r < 4; ++r) sv[r] = (kt * 16 + 4 * lg + r < N) ? sv[r] : -INFINITY;
       }
+      mx = fmaxf(fmaxf(mx, fmaxf(sv[0], sv[1])), fmaxf(sv[2], sv[3]));
+      st[kt] = sv;
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mc = mx * c1;
     float psum = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < AR_MAXN / 16; ++kt) {
-      if (kt < nkt) {
+    for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(st[kt][r] * c1 - mc);      // exp(scale * (s - max))
-          st[kt][r] = p;
-          psum += p;
-        }
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(st[kt][r] * c1 - mc);      // exp(scale * (s - max)); exp2(-inf) = 0 for masked keys
+        st[kt][r] = p;
+        psum += p;
       }
     }
     psum += __shfl_xor(psum, 16, 64);
@@ -156,12 +152,10 @@ __global__ __launch_bounds__(AR_THREADS, 2) void attention_fwd_res_kernel(const 
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) oacc[dt] = zero4;
 #pragma unroll
-    for (int cc = 0; cc < AR_MAXN / 32; ++cc) {
-      if (cc * 2 < nkt) {
-        const typename Mma<T>::frag pf = Mma<T>::from_tiles(&st[cc * 2]);
+    for (int cc = 0; cc < NKT / 2; ++cc) {
+      const typename Mma<T>::frag pf = Mma<T>::from_tiles(&st[cc * 2]);
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) oacc[dt] = Mma<T>::mma(tr_frag<T, DH>(sV, cc * 32, dt * 16, li, lg), pf, oacc[dt]);
-      }
+      for (int dt = 0; dt < NDT; ++dt) oacc[dt] = Mma<T>::mma(tr_frag<T, DH>(sV, cc * 32, dt * 16, li, lg), pf, oacc[dt]);
     }
     if (qrow < N) {
       const float inv = 1.0f / psum;
@@ -187,19 +181,27 @@ __device__ unsigned long long g_attn_stamps[ASTAMP_WGS][ASTAMP_N];
 #endif
 
 // ----------------------------------------------------------------------------- backward
-// NW waves; wave owns key tiles {w, w + NW, ...} (KTW = 16 / NW of them); dQ pieces (2 query tiles x NDT d tiles) = NW
-template <typename T, int DH>
+// NW waves; wave owns key tiles {w, w + NW, ...}, KTE of them - a TEMPLATE constant (ceil(number of key tiles / NW)):
+// every loop over key tiles, dQ chunks and query sub-tiles is then straight-line code without a branch.  (With run-time
+// `if (tile < nkt)` guards every (query tile, key tile) pair was its own basic block: the MFMA -> exp2 -> multiply chains
+// of the pairs ran one after the other, 2400 cycles for 16 MFMAs and 32 exp2 per step.)  Key tiles past the sequence have
+// all-zero K / V fragments and zeroed probabilities - they only ever sit in a wave's LAST tile, and the workgroup is paced
+// by the wave whose last tile is real anyway.  K image and dS^T images cover KTE * NW * 16 keys (zero padded).
+// dQ pieces (2 query tiles x NDT d tiles) = NW.
+template <typename T, int DH, int KTE>
 __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attention_bwd_res_kernel(
     const T *__restrict__ qkv, const T *__restrict__ o, const T *__restrict__ d_o,
     const float *__restrict__ lse, int N, int heads, T *__restrict__ dqkv, float scale) {
   constexpr int RBY = DH * 2, CPR = RBY / 16, NCH = DH / 32, NDT = DH / 16;
-  constexpr int NW = DH == 32 ? 4 : 8, NT = NW * 64, KTW = (AR_MAXN / 16) / NW;
+  constexpr int NW = DH == 32 ? 4 : 8, NT = NW * 64;
+  constexpr int NKEY = KTE * NW * 16, NKC = NKEY / 32;      // keys covered by the wave tiles; 32-key chunks of the dQ contraction
   static_assert(2 * NDT == NW, "one dQ piece per wave");
+  static_assert(NKEY <= AR_MAXN, "at most 256 keys");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int NP = (N + 31) & ~31;
-  char *sQ = smem, *sdO = sQ + NP * RBY, *sK = sdO + NP * RBY;
-  char *sdS = sK + NP * RBY;                           // two [NP keys][32 q] images (64-byte rows)
-  float *sLse = (float *)(sdS + 2 * NP * 64);          // lse * log2(e); +inf-like for the padded rows
+  const int NP = (N + 31) & ~31;                       // query rows, padded to the 32-row steps (NP <= NKEY)
+  char *sQ = smem, *sdO = sQ + NP * RBY, *sK = sdO + NP * RBY;        // sK: [NKEY keys][RBY], rows >= N zero
+  char *sdS = sK + NKEY * RBY;                         // two [NKEY keys][32 q] images (64-byte rows)
+  float *sLse = (float *)(sdS + 2 * NKEY * 64);        // lse * log2(e); +inf-like for the padded rows
   float *sDelta = sLse + NP;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
   // the first LDS store (stamps: the rolled loop, which waits for each iteration's four loads in turn, was 34 % of
   // a workgroup's life)
   {
-    constexpr int SIT = AR_MAXN * CPR / NT;
+    constexpr int SIT = NKEY * CPR / NT;
     u32x4 qv[SIT], dv[SIT], kv[SIT], ov[SIT];
     float lv[SIT];
 #pragma unroll
@@ -244,10 +246,10 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
       for (int j = 0; j < 8; ++j) sd += (float)dh8[j] * (float)oh8[j];
 #pragma unroll
       for (int m = 1; m < CPR; m <<= 1) sd += __shfl_xor(sd, m, 64);
+      *(u32x4 *)(sK + swo<DH>(row, c * 16)) = kv[it];               // (row < NKEY by construction)
       if (row < NP) {
         *(u32x4 *)(sQ + swo<DH>(row, c * 16)) = qv[it];
         *(u32x4 *)(sdO + swo<DH>(row, c * 16)) = dv[it];
-        *(u32x4 *)(sK + swo<DH>(row, c * 16)) = kv[it];
         if (c == 0) {
           sDelta[row] = sd;
           sLse[row] = lv[it];
@@ -255,13 +257,10 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
       }
     }
   }
-  // rows of the dS^T images that no wave writes (key tiles past the last valid one) must read as zero
-  for (int q = tid; q < 2 * NP * 4; q += NT) *(u32x4 *)(sdS + q * 16) = u32x4{0u, 0u, 0u, 0u};
-  // this wave's key tiles: K / V fragments (B operands) straight from global
-  const int nkt = (N + 15) >> 4;
-  typename Mma<T>::frag kf[KTW][NCH], vf[KTW][NCH];
+  // this wave's key tiles: K / V fragments (B operands) straight from global; keys >= N are zero rows
+  typename Mma<T>::frag kf[KTE][NCH], vf[KTE][NCH];
 #pragma unroll
-  for (int kt = 0; kt < KTW; ++kt) {
+  for (int kt = 0; kt < KTE; ++kt) {
     const int key = (kt * NW + wave) * 16 + li;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
@@ -274,33 +273,31 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
     }
   }
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 dkt[NDT][KTW], dvt[NDT][KTW];
+  f32x4 dkt[NDT][KTE], dvt[NDT][KTE];
 #pragma unroll
   for (int a = 0; a < NDT; ++a)
 #pragma unroll
-    for (int c = 0; c < KTW; ++c) { dkt[a][c] = zero4; dvt[a][c] = zero4; }
+    for (int c = 0; c < KTE; ++c) { dkt[a][c] = zero4; dvt[a][c] = zero4; }
   ATTN_STAMP(1);                                   // loads issued, LDS stores queued
   __syncthreads();
   ATTN_STAMP(2);                                   // operands staged
 
   const float c1 = scale * AR_LOG2E, inv_c1 = 1.0f / c1;
-  const int nkc = NP >> 5;                       // 32-key chunks of the dQ contraction
   const int nsteps = NP >> 5;
+  // keys past the sequence can only sit in a wave's LAST tile: its probabilities are zeroed by this lane's flag
+  const bool last_key_ok = ((KTE - 1) * NW + wave) * 16 + li < N;
   // K^T fragments of this wave's dQ piece (dt fixed per wave): the same in every step - read once, kept in registers
-  typename Mma<T>::frag ka[AR_MAXN / 32];
-  {
-    const int dt = wave % NDT;
+  const int dq_qt = wave / NDT, dq_dt = wave - dq_qt * NDT;
+  typename Mma<T>::frag ka[NKC];
 #pragma unroll
-    for (int c = 0; c < AR_MAXN / 32; ++c) {
-      const int cc = c < nkc ? c : nkc - 1;
-      ka[c] = tr_frag<T, DH>(sK, cc * 32, dt * 16, li, lg);
-    }
-  }
+  for (int c = 0; c < NKC; ++c) ka[c] = tr_frag<T, DH>(sK, c * 32, dq_dt * 16, li, lg);
   for (int st = 0; st < nsteps; ++st) {
     const int qs = st * 32;
-    char *dsb = sdS + (st & 1) * NP * 64;
-    // ---- S, dP -> P, dS (unscaled) for this wave's key tiles;  D[q = 4*lg + r][key = li]
-    f32x4 pt[2][KTW], dst[2][KTW];
+    char *dsb = sdS + (st & 1) * NKEY * 64;
+    // ---- S, dP -> P, dS (unscaled) for this wave's key tiles;  D[q = 4*lg + r][key = li].  Row constants ride in as
+    // the MFMA chains' initial accumulators: S' = Q K^T - lse / (scale log2 e) and dP' = dO V^T - delta leave the chains
+    // ready, so P = exp2(c1 S') and dS = P dP' are two multiplies and one exp2 per element
+    f32x4 pt[2][KTE], dst[2][KTE];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       typename Mma<T>::frag qfr[NCH], dof[NCH];
@@ -309,36 +306,25 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
         qfr[ch] = row_frag<T, DH>(sQ, qs + qt * 16, ch, li, lg);
         dof[ch] = row_frag<T, DH>(sdO, qs + qt * 16, ch, li, lg);
       }
-      // Row constants ride in as the MFMA chains' initial accumulators: S' = Q K^T - lse / (scale log2 e) and
-      // dP' = dO V^T - delta leave the chains ready, so P = exp2(c1 S') and dS = P dP' are two multiplies and one exp2
-      // per element instead of fma + exp2 + sub + mul (this phase is VALU-bound: N^2 elements per head)
-      f32x4 s0, dp0;
+      const f32x4 l4 = *(const f32x4 *)(sLse + qs + qt * 16 + 4 * lg), d4 = *(const f32x4 *)(sDelta + qs + qt * 16 + 4 * lg);
+      const f32x4 s0 = l4 * (-inv_c1), dp0 = -d4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s0[r] = -sLse[qs + qt * 16 + 4 * lg + r] * inv_c1;
-        dp0[r] = -sDelta[qs + qt * 16 + 4 * lg + r];
-      }
+      for (int kt = 0; kt < KTE; ++kt) {
+        f32x4 s = s0, dp = dp0;
 #pragma unroll
-      for (int kt = 0; kt < KTW; ++kt) {
-        const int tix = kt * NW + wave;
-        if (tix < nkt) {
-          f32x4 s = s0, dp = dp0;
-#pragma unroll
-          for (int ch = 0; ch < NCH; ++ch) {
-            s = Mma<T>::mma(qfr[ch], kf[kt][ch], s);
-            dp = Mma<T>::mma(dof[ch], vf[kt][ch], dp);
-          }
-          f32x4 pv;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r] * c1);
-          if (tix == nkt - 1 && tix * 16 + li >= N) pv = zero4;          // keys past N live in the last tile only
-          pt[qt][kt] = pv;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) dst[qt][kt][r] = pv[r] * dp[r];
-        } else {
-          pt[qt][kt] = zero4;
-          dst[qt][kt] = zero4;
+        for (int ch = 0; ch < NCH; ++ch) {
+          s = Mma<T>::mma(qfr[ch], kf[kt][ch], s);
+          dp = Mma<T>::mma(dof[ch], vf[kt][ch], dp);
         }
+        f32x4 pv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r] * c1);
+        if (kt == KTE - 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pv[r] = last_key_ok ? pv[r] : 0.f;
+        }
+        pt[qt][kt] = pv;
+        dst[qt][kt] = pv * dp;
       }
     }
     ATTN_STAMP(3 + 4 * st);                          // S, dP, P, dS of the step
@@ -351,22 +337,20 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
         ado[dt] = tr_frag<T, DH>(sdO, qs, dt * 16, li, lg);
       }
 #pragma unroll
-      for (int kt = 0; kt < KTW; ++kt) {
-        if (kt * NW + wave < nkt) {
-          f32x4 tp[2] = {pt[0][kt], pt[1][kt]}, td[2] = {dst[0][kt], dst[1][kt]};
-          const typename Mma<T>::frag pf = Mma<T>::from_tiles(tp), dsf = Mma<T>::from_tiles(td);
+      for (int kt = 0; kt < KTE; ++kt) {
+        f32x4 tp[2] = {pt[0][kt], pt[1][kt]}, td[2] = {dst[0][kt], dst[1][kt]};
+        const typename Mma<T>::frag pf = Mma<T>::from_tiles(tp), dsf = Mma<T>::from_tiles(td);
 #pragma unroll
-          for (int dt = 0; dt < NDT; ++dt) {
-            dvt[dt][kt] = Mma<T>::mma(ado[dt], pf, dvt[dt][kt]);
-            dkt[dt][kt] = Mma<T>::mma(aq[dt], dsf, dkt[dt][kt]);
-          }
-          // dS^T[key][q]: this lane holds 4 consecutive q of one key per (qt, kt) -> one 8-byte store
-          const int krow = (kt * NW + wave) * 16 + li;
+        for (int dt = 0; dt < NDT; ++dt) {
+          dvt[dt][kt] = Mma<T>::mma(ado[dt], pf, dvt[dt][kt]);
+          dkt[dt][kt] = Mma<T>::mma(aq[dt], dsf, dkt[dt][kt]);
+        }
+        // dS^T[key][q]: this lane holds 4 consecutive q of one key per (qt, kt) -> one 8-byte store (zeros for padding keys)
+        const int krow = (kt * NW + wave) * 16 + li;
 #pragma unroll
-          for (int qt = 0; qt < 2; ++qt) {
-            typename Vec4<T>::type v = typename Vec4<T>::type{(T)dst[qt][kt][0], (T)dst[qt][kt][1], (T)dst[qt][kt][2], (T)dst[qt][kt][3]};
-            *(typename Vec4<T>::type *)(dsb + swo<32>(krow, (qt * 16 + 4 * lg) * 2)) = v;
-          }
+        for (int qt = 0; qt < 2; ++qt) {
+          typename Vec4<T>::type v = typename Vec4<T>::type{(T)dst[qt][kt][0], (T)dst[qt][kt][1], (T)dst[qt][kt][2], (T)dst[qt][kt][3]};
+          *(typename Vec4<T>::type *)(dsb + swo<32>(krow, (qt * 16 + 4 * lg) * 2)) = v;
         }
       }
     }
@@ -375,31 +359,27 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
     ATTN_STAMP(5 + 4 * st);                          // barrier passed
     // ---- dQ^T[d = 16*dt + 4*lg + r][q = 16*qt + li] = K^T dS^T, one (qt, dt) piece per wave
     {
-      const int qt = wave / NDT, dt = wave - qt * NDT;
-      // all fragment reads first (clamped chunk index: always inside the images), then the MFMA chain - two interleaved
-      // accumulators, so that a product does not wait for its predecessor's result
-      typename Mma<T>::frag da[AR_MAXN / 32];
+      // all fragment reads first, then the MFMA chain - two interleaved accumulators, so that a product does not wait
+      // for its predecessor's result
+      typename Mma<T>::frag da[NKC];
 #pragma unroll
-      for (int c = 0; c < AR_MAXN / 32; ++c) {
-        const int cc = c < nkc ? c : nkc - 1;
-        da[c] = tr_frag<T, 32>(dsb, cc * 32, qt * 16, li, lg);
-      }
+      for (int c = 0; c < NKC; ++c) da[c] = tr_frag<T, 32>(dsb, c * 32, dq_qt * 16, li, lg);
       f32x4 acc = zero4, acc2 = zero4;
 #pragma unroll
-      for (int c = 0; c < AR_MAXN / 32; c += 2) {
-        if (c < nkc) acc = Mma<T>::mma(ka[c], da[c], acc);
-        if (c + 1 < nkc) acc2 = Mma<T>::mma(ka[c + 1], da[c + 1], acc2);
+      for (int c = 0; c < NKC; c += 2) {
+        acc = Mma<T>::mma(ka[c], da[c], acc);
+        if (c + 1 < NKC) acc2 = Mma<T>::mma(ka[c + 1], da[c + 1], acc2);
       }
       acc += acc2;
-      const int qr = qs + qt * 16 + li;
-      if (qr < N) Vec4<T>::store(dqbase + (int64_t)qr * ld + dt * 16 + 4 * lg, acc * scale);
+      const int qr = qs + dq_qt * 16 + li;
+      if (qr < N) Vec4<T>::store(dqbase + (int64_t)qr * ld + dq_dt * 16 + 4 * lg, acc * scale);
     }
     ATTN_STAMP(6 + 4 * st);                          // dQ piece of the step stored
   }
 
   // ---- dK, dV rows of this wave's keys
 #pragma unroll
-  for (int kt = 0; kt < KTW; ++kt) {
+  for (int kt = 0; kt < KTE; ++kt) {
     const int key = (kt * NW + wave) * 16 + li;
     if (key < N) {
 #pragma unroll
@@ -808,22 +788,29 @@ static int launch_attention_bwd_stream_t(const void *qkv, const void *o, const v
   return check_launch("m3_attention_bwd");
 }
 
-size_t attn_res_fwd_lds(int N, int dh) { return (size_t)2 * ((N + 31) & ~31) * dh * 2; }
+static inline int attn_res_fwd_nkt(int N) { return ((N + 15) / 16 + 3) / 4 * 4; }      // key tiles rounded up to 4, 8, 12, 16
+size_t attn_res_fwd_lds(int N, int dh) { return (size_t)2 * attn_res_fwd_nkt(N) * 16 * dh * 2; }
+// tiles per wave of the short-sequence backward for N keys: ceil(key tiles / waves); LDS of that instance
+static inline int attn_res_bwd_kte(int N, int dh) { const int nw = dh == 32 ? 4 : 8; return ((N + 15) / 16 + nw - 1) / nw; }
 size_t attn_res_bwd_lds(int N, int dh) {
   const size_t np = (N + 31) & ~31;
-  return 3 * np * dh * 2 + 2 * np * 64 + 2 * np * sizeof(float);
+  const size_t nkey = (size_t)attn_res_bwd_kte(N, dh) * (dh == 32 ? 4 : 8) * 16;
+  return 2 * np * dh * 2 + nkey * dh * 2 + 2 * nkey * 64 + 2 * np * sizeof(float);
 }
 
 template <typename T>
 static int launch_attention_fwd_res_t(const void *qkv, int B, int N, int heads, int dh, void *o, float *lse, float scale,
                              hipStream_t s) {
   const size_t lds = attn_res_fwd_lds(N, dh);
-  if (dh == 32)
-    hipLaunchKernelGGL((attention_fwd_res_kernel<T, 32>), dim3(B * heads), dim3(AR_THREADS), lds, s, (const T *)qkv, N, heads,
-                       (T *)o, lse, scale);
-  else
-    hipLaunchKernelGGL((attention_fwd_res_kernel<T, 64>), dim3(B * heads), dim3(AR_THREADS), lds, s, (const T *)qkv, N, heads,
-                       (T *)o, lse, scale);
+  const int nkt = attn_res_fwd_nkt(N);
+#define M3_AF_GO(DH_, NK_) hipLaunchKernelGGL((attention_fwd_res_kernel<T, DH_, NK_>), dim3(B * heads), dim3(AR_THREADS), lds, s, \
+                                             (const T *)qkv, N, heads, (T *)o, lse, scale)
+  if (dh == 32) {
+    if (nkt == 4) M3_AF_GO(32, 4); else if (nkt == 8) M3_AF_GO(32, 8); else if (nkt == 12) M3_AF_GO(32, 12); else M3_AF_GO(32, 16);
+  } else {
+    if (nkt == 4) M3_AF_GO(64, 4); else if (nkt == 8) M3_AF_GO(64, 8); else if (nkt == 12) M3_AF_GO(64, 12); else M3_AF_GO(64, 16);
+  }
+#undef M3_AF_GO
   return check_launch("m3_attention_fwd");
 }
 
@@ -831,20 +818,23 @@ template <typename T>
 static int launch_attention_bwd_res_t(const void *qkv, const void *o, const void *d_o, const float *lse, int B, int N, int heads,
                              int dh, void *dqkv, float scale, hipStream_t s) {
   const size_t lds = attn_res_bwd_lds(N, dh);
+  const int kte = attn_res_bwd_kte(N, dh);
   static bool attr_set = false;
+#define M3_AB_ATTR(DH_, K_) (void)hipFuncSetAttribute((const void *)attention_bwd_res_kernel<T, DH_, K_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                      (int)attn_res_bwd_lds(K_ * (DH_ == 32 ? 64 : 128), DH_))
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)attention_bwd_res_kernel<T, 32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)attn_res_bwd_lds(AR_MAXN, 32));
-    (void)hipFuncSetAttribute((const void *)attention_bwd_res_kernel<T, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)attn_res_bwd_lds(AR_MAXN, 64));
+    M3_AB_ATTR(32, 1); M3_AB_ATTR(32, 2); M3_AB_ATTR(32, 3); M3_AB_ATTR(32, 4); M3_AB_ATTR(64, 1); M3_AB_ATTR(64, 2);
     attr_set = true;
   }
-  if (dh == 32)
-    hipLaunchKernelGGL((attention_bwd_res_kernel<T, 32>), dim3(B * heads), dim3(256), lds, s, (const T *)qkv,
-                       (const T *)o, (const T *)d_o, lse, N, heads, (T *)dqkv, scale);
-  else
-    hipLaunchKernelGGL((attention_bwd_res_kernel<T, 64>), dim3(B * heads), dim3(512), lds, s, (const T *)qkv,
-                       (const T *)o, (const T *)d_o, lse, N, heads, (T *)dqkv, scale);
+#undef M3_AB_ATTR
+#define M3_AB_GO(DH_, K_, NT_) hipLaunchKernelGGL((attention_bwd_res_kernel<T, DH_, K_>), dim3(B * heads), dim3(NT_), lds, s, (const T *)qkv, \
+                                                 (const T *)o, (const T *)d_o, lse, N, heads, (T *)dqkv, scale)
+  if (dh == 32) {
+    if (kte == 1) M3_AB_GO(32, 1, 256); else if (kte == 2) M3_AB_GO(32, 2, 256); else if (kte == 3) M3_AB_GO(32, 3, 256); else M3_AB_GO(32, 4, 256);
+  } else {
+    if (kte == 1) M3_AB_GO(64, 1, 512); else M3_AB_GO(64, 2, 512);
+  }
+#undef M3_AB_GO
   return check_launch("m3_attention_bwd");
 }
 

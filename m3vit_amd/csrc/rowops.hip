@@ -243,6 +243,27 @@ __global__ __launch_bounds__(256) void cast_batch_kernel(const CastDesc *__restr
   const int r0 = (rest / tcols) * 32, c0 = (rest % tcols) * 32;
   const int64_t goff = (int64_t)g * d.rows * d.cols;
   const float *src = d.src + goff;
+  if (((d.rows | d.cols) & 3) == 0) {
+    // rows and columns multiples of 4 (every weight of the model): one 16-byte load per thread (8 threads x 32 rows), 8-byte
+    // stores for the plain copy and - through the LDS tile - for the transposed one.  M3_CAST_PERM32 moves whole groups
+    // of four (source group 4b + a of an aligned 32 -> position group 2a + b), so it acts on the group index.
+    const int tr = threadIdx.x >> 3, tg = threadIdx.x & 7;
+    const int tgp = 2 * (tg & 3) + (tg >> 2);
+    const int r = r0 + tr, c = c0 + 4 * tg;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (r < d.rows && c < d.cols) v = *(const f32x4 *)(src + (int64_t)r * d.cols + c);
+    if (d.dst && r < d.rows && c < d.cols)
+      Vec4<T>::store((T *)d.dst + goff + (int64_t)r * d.cols + c0 + 4 * ((d.flags & 1) ? tgp : tg), v);
+    tile[tr][4 * tg + 0] = v[0]; tile[tr][4 * tg + 1] = v[1]; tile[tr][4 * tg + 2] = v[2]; tile[tr][4 * tg + 3] = v[3];
+    if (!d.dst_t) return;
+    __syncthreads();
+    const int cc = c0 + tr, rg = r0 + 4 * tg;                        // dst_t[cc][rg .. rg + 3] = src[rg .. rg + 3][cc]
+    if (cc < d.cols && rg < d.rows) {
+      const f32x4 w = f32x4{tile[4 * tg + 0][tr], tile[4 * tg + 1][tr], tile[4 * tg + 2][tr], tile[4 * tg + 3][tr]};
+      Vec4<T>::store((T *)d.dst_t + goff + (int64_t)cc * d.rows + r0 + 4 * ((d.flags & 2) ? tgp : tg), w);
+    }
+    return;
+  }
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
   // M3_CAST_PERM32: source index q = 16b + 4a + c of an aligned 32-group goes to position 8a + 4b + c
   const int txp = ((tx >> 2) & 3) * 8 + (tx >> 4) * 4 + (tx & 3);
@@ -516,26 +537,40 @@ extern "C" int m3_assemble_tokens(const float *patch, const float *cls, const fl
 // ---- backward of assemble_tokens: dpatch (act dtype) = dtok[:,1:,:] ; dpos (+)= sum_b dtok ;
 // dcls (+)= sum_b dtok[:,0,:]
 namespace m3 {
+// thread (e, bl): 16-byte element e of a [N, D] token image, batch lane bl of TB_BL: images bl, bl + TB_BL, ... summed in that
+// order, then the lanes' sums added in lane order through LDS (fixed order: deterministic).  (One thread per element
+// walking all B images by itself - 74 workgroups for ViT-S - ran at 1 TB/s.)
+constexpr int TB_BL = 8, TB_EL = 32;                 // batch lanes x elements per 256-thread workgroup
 template <typename T>
-__global__ void tokens_bwd_kernel(const float *__restrict__ dtok, int B, int np_, int D, T *__restrict__ dpatch,
+__global__ __launch_bounds__(TB_BL * TB_EL) void tokens_bwd_kernel(const float *__restrict__ dtok, int B, int np_, int D, T *__restrict__ dpatch,
                                   float *__restrict__ dpos, float *__restrict__ dcls, int beta) {
+  __shared__ f32x4 part[TB_BL][TB_EL];
   const int N = np_ + 1;
   const int64_t total4 = (int64_t)N * D / 4;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total4) return;
-  const int64_t e = i * 4;
-  const int n = (int)(e / D), d = (int)(e - (int64_t)n * D);
+  const int el = threadIdx.x % TB_EL, bl = threadIdx.x / TB_EL;
+  const int64_t i = (int64_t)blockIdx.x * TB_EL + el;
   f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int b = 0; b < B; ++b) {
-    const f32x4 g = *(const f32x4 *)(dtok + ((int64_t)b * N + n) * D + d);
-    s += g;
-    if (n > 0 && dpatch) Vec4<T>::store(dpatch + ((int64_t)b * np_ + (n - 1)) * D + d, g);
+  int n = 0, d = 0;
+  if (i < total4) {
+    const int64_t e = i * 4;
+    n = (int)(e / D); d = (int)(e - (int64_t)n * D);
+    for (int b = bl; b < B; b += TB_BL) {
+      const f32x4 g = *(const f32x4 *)(dtok + ((int64_t)b * N + n) * D + d);
+      s += g;
+      if (n > 0 && dpatch) Vec4<T>::store(dpatch + ((int64_t)b * np_ + (n - 1)) * D + d, g);
+    }
   }
-  f32x4 *pp = (f32x4 *)(dpos + e);
-  *pp = beta ? (*pp + s) : s;
-  if (n == 0) {
-    f32x4 *pc = (f32x4 *)(dcls + d);
-    *pc = beta ? (*pc + s) : s;
+  part[bl][el] = s;
+  __syncthreads();
+  if (bl == 0 && i < total4) {
+#pragma unroll
+    for (int j = 1; j < TB_BL; ++j) s += part[j][el];
+    f32x4 *pp = (f32x4 *)(dpos + i * 4);
+    *pp = beta ? (*pp + s) : s;
+    if (n == 0) {
+      f32x4 *pc = (f32x4 *)(dcls + d);
+      *pc = beta ? (*pc + s) : s;
+    }
   }
 }
 }  // namespace m3
@@ -545,7 +580,7 @@ extern "C" int m3_tokens_bwd(const float *dtok, int B, int np_, int D, void *dpa
   M3_REQUIRE(dtok && dpos && dcls && D % 4 == 0, "m3_tokens_bwd: bad args");
   M3_REQUIRE(dtype_ok(dtype), "m3_tokens_bwd: bad dtype");
   const int64_t total4 = (int64_t)(np_ + 1) * D / 4;
-  const dim3 grid((unsigned)((total4 + 255) / 256)), block(256);
+  const dim3 grid((unsigned)((total4 + m3::TB_EL - 1) / m3::TB_EL)), block(m3::TB_BL * m3::TB_EL);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == M3_F16) hipLaunchKernelGGL(m3::tokens_bwd_kernel<m3::half_t>, grid, block, 0, s, dtok, B, np_, D, (m3::half_t *)dpatch, dpos, dcls, beta);
   else if (dtype == M3_BF16) hipLaunchKernelGGL(m3::tokens_bwd_kernel<m3::bf16_t>, grid, block, 0, s, dtok, B, np_, D, (m3::bf16_t *)dpatch, dpos, dcls, beta);

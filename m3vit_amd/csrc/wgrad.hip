@@ -37,6 +37,14 @@ struct WgradDev {
   float *bias_ws;                  // optional [splits][G][N]: column sums of dC (bias grads), fused
   int32_t tiles_k;
   int32_t chunk_rows;              // > 0: balanced grouped mode - a work unit is `chunk_rows` rows of ONE group
+  // The slab reduction of the PREVIOUS weight-gradient call of the stream, done by this launch's leading blocks
+  // (m3_wgrad_args.prev): rd_blocks > 0 switches it on; layouts as m3_wgrad_reduce / m3_wgrad_reduce_grouped take them
+  int32_t rd_blocks, rd_zslices;   // reduce blocks (flattened x, group) and the grid z slices they occupy
+  int32_t rd_nbx, rd_nbw;          // blocks per group (weight + bias part), of those for the weight elements
+  const float *rd_ws; int32_t rd_splits; int64_t rd_e4;
+  const int32_t *rd_off; int32_t rd_G, rd_chunk;
+  float *rd_dW; int32_t rd_beta;
+  const float *rd_bws; int64_t rd_b4; float *rd_db; int32_t rd_beta_db;
 };
 
 // balanced grouped mode: units are dealt to the groups in order, n_g = ceil(rows_g / chunk) each, a group's rows
@@ -127,6 +135,35 @@ __device__ __forceinline__ f32x4 read_tr_frag<float>(const char *base, int rb, i
   return f;
 }
 
+__device__ __forceinline__ void wgrad_reduce_block(int64_t blk, int tid, const float *ws, int splits, int64_t elems4, float *dW,
+                                                   int beta, int nb_w, const float *bias_ws, int64_t belems4, float *db, int beta_db);
+__device__ __forceinline__ void wgrad_reduce_grouped_block(int64_t blk, int g, int tid, const float *ws, const int32_t *off, int G,
+                                                           int chunk, int64_t elems4, float *dW, int beta, int nb_w,
+                                                           const float *bias_ws, int64_t belems4, float *db, int beta_db);
+// The previous call's slab reduction riding in front of a weight-gradient launch: the grid's first rd_zslices z slices
+// are reduce blocks (dispatched first; a few microseconds of streaming), the rest is the launch proper with its z index
+// shifted down.  Returns true for a reduce block (which is then done).  What it replaces: one extra launch per
+// weight-gradient GEMM (110 per step) whose ~8 us were mostly launch boundary and ramp.
+__device__ __forceinline__ bool wgrad_ride_along(const WgradDev &p, int tid, int &bz, int &gz) {
+  bz = blockIdx.z; gz = gridDim.z;
+  if (p.rd_blocks <= 0) return false;
+  if (bz < p.rd_zslices) {
+    const int rid = blockIdx.x + (int)gridDim.x * (blockIdx.y + (int)gridDim.y * bz);
+    if (rid < p.rd_blocks) {
+      const int g = rid / p.rd_nbx, bx = rid - g * p.rd_nbx;
+      if (p.rd_chunk)
+        wgrad_reduce_grouped_block(bx, g, tid, p.rd_ws, p.rd_off, p.rd_G, p.rd_chunk, p.rd_e4, p.rd_dW, p.rd_beta, p.rd_nbw,
+                                   p.rd_bws, p.rd_b4, p.rd_db, p.rd_beta_db);
+      else
+        wgrad_reduce_block(bx, tid, p.rd_ws, p.rd_splits, p.rd_e4, p.rd_dW, p.rd_beta, p.rd_nbw, p.rd_bws, p.rd_b4, p.rd_db,
+                           p.rd_beta_db);
+    }
+    return true;
+  }
+  bz -= p.rd_zslices; gz -= p.rd_zslices;
+  return false;
+}
+
 // a 16-byte chunk of T times a per-row factor (the gate score of a routed row: the combine's backward d y = score * d out
 // applied where the row enters the LDS image, so that the scaled [T*k, D] copy never exists in memory)
 template <typename T> __device__ __forceinline__ u32x4 scale_chunk(u32x4 v, float s);
@@ -170,7 +207,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
   // needed by tiles_k resp. tiles_n workgroups), so they are given consecutive logical ids, which the
   // remap places on one XCD: the re-reads hit that XCD's L2 instead of the fabric.
   const int tiles = gridDim.x;
-  const int lin = blockIdx.x + tiles * (blockIdx.y + gridDim.y * blockIdx.z);
+  int bz, gz;
+  if (wgrad_ride_along(p, tid, bz, gz)) return;
+  const int lin = blockIdx.x + tiles * (blockIdx.y + gridDim.y * bz);
   int tile, gs, g, sp, nst;
   int64_t r0, r1, s_begin;
   if (p.chunk_rows) {                          // gs = work unit; its slab is ws[gs]
@@ -178,7 +217,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
     sp = gs; s_begin = 0;
     nst = (int)((r1 - r0 + ROWS - 1) / ROWS);
   } else {
-    const int log_id = xcd_remap(lin, tiles * gridDim.y * gridDim.z);
+    const int log_id = xcd_remap(lin, tiles * gridDim.y * gz);
     tile = log_id % tiles; gs = log_id / tiles;
     g = gs % (int)gridDim.y; sp = gs / (int)gridDim.y;
     if (p.group_offsets) { r0 = p.group_offsets[g]; r1 = p.group_offsets[g + 1]; }
@@ -603,13 +642,12 @@ __global__ __launch_bounds__(WW_THREADS, 2) void wgrad_wide_kernel(const WgradDe
 }
 
 // slabs -> dW (blocks [0, nb_w)) and, in the same launch, bias slabs -> db (blocks [nb_w, ...)); splits in order
-__global__ void wgrad_reduce_kernel(const float *ws, int splits, int64_t elems4, float *dW, int beta, int nb_w,
-                                    const float *bias_ws, int64_t belems4, float *db, int beta_db) {
-  int64_t blk = blockIdx.x;
+__device__ __forceinline__ void wgrad_reduce_block(int64_t blk, int tid, const float *ws, int splits, int64_t elems4, float *dW,
+                                                   int beta, int nb_w, const float *bias_ws, int64_t belems4, float *db, int beta_db) {
   if (blk >= nb_w) {
     blk -= nb_w; ws = bias_ws; elems4 = belems4; dW = db; beta = beta_db;
   }
-  const int64_t i = blk * blockDim.x + threadIdx.x;
+  const int64_t i = blk * 256 + tid;
   if (i >= elems4) return;
   f32x4 s = beta ? ((const f32x4 *)dW)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
   // eight slabs' loads in flight before the first add (a thread owns ONE 16-byte column of up to 32 slabs: issued one
@@ -626,26 +664,33 @@ __global__ void wgrad_reduce_kernel(const float *ws, int splits, int64_t elems4,
   for (; sp < splits; ++sp) s += w[(int64_t)sp * elems4];
   ((f32x4 *)dW)[i] = s;
 }
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *ws, int splits, int64_t elems4, float *dW, int beta, int nb_w,
+                                                           const float *bias_ws, int64_t belems4, float *db, int beta_db) {
+  wgrad_reduce_block(blockIdx.x, threadIdx.x, ws, splits, elems4, dW, beta, nb_w, bias_ws, belems4, db, beta_db);
+}
 
-// balanced grouped mode: dW[g] (+)= sum of the slabs of group g's units, in unit order; blockIdx.y = group,
+// balanced grouped mode: dW[g] (+)= sum of the slabs of group g's units, in unit order; g = group,
 // blocks [0, nb_w) the weight elements, [nb_w, ..) the bias elements
-__global__ void wgrad_reduce_grouped_kernel(const float *ws, const int32_t *off, int G, int chunk, int64_t elems4,
-                                            float *dW, int beta, int nb_w, const float *bias_ws, int64_t belems4,
-                                            float *db, int beta_db) {
-  int64_t blk = blockIdx.x;
+__device__ __forceinline__ void wgrad_reduce_grouped_block(int64_t blk, int g, int tid, const float *ws, const int32_t *off, int G,
+                                                           int chunk, int64_t elems4, float *dW, int beta, int nb_w,
+                                                           const float *bias_ws, int64_t belems4, float *db, int beta_db) {
   if (blk >= nb_w) {
     blk -= nb_w; ws = bias_ws; elems4 = belems4; dW = db; beta = beta_db;
   }
-  const int64_t i = blk * blockDim.x + threadIdx.x;
-  const int g = blockIdx.y;
+  const int64_t i = blk * 256 + tid;
   int rows, n, first;
-  wgrad_unit_scan(off, G, chunk, threadIdx.x & 63, rows, n, first);       // all lanes take part in the scan
+  wgrad_unit_scan(off, G, chunk, tid & 63, rows, n, first);       // all lanes take part in the scan
   n = __shfl(n, g, 64); first = __shfl(first, g, 64);
   if (i >= elems4) return;
   f32x4 *out = (f32x4 *)dW + (int64_t)g * elems4 + i;
   f32x4 s = beta ? *out : f32x4{0.f, 0.f, 0.f, 0.f};
   for (int u = first; u < first + n; ++u) s += ((const f32x4 *)ws)[(int64_t)u * elems4 + i];
   *out = s;
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const float *ws, const int32_t *off, int G, int chunk, int64_t elems4,
+                                                                   float *dW, int beta, int nb_w, const float *bias_ws, int64_t belems4,
+                                                                   float *db, int beta_db) {
+  wgrad_reduce_grouped_block(blockIdx.x, blockIdx.y, threadIdx.x, ws, off, G, chunk, elems4, dW, beta, nb_w, bias_ws, belems4, db, beta_db);
 }
 
 // ------------------------------------------------------------------ column sums
@@ -761,7 +806,32 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   // wide tiles (fp16): the shapes m3_wgrad_tile() names; the caller sized `splits` / `units` for that tile count
   int tn_w = 0, tk_w = 0;
   m3_wgrad_tile(a->N, a->K, a->dtype, &tn_w, &tk_w);
-  if ((tn_w != WG_T || tk_w != WG_T) && (d.a_row_div & (d.a_row_div - 1)) == 0 && !d.c_row_scale && d.c_row_div == 1) {
+  const bool wide = (tn_w != WG_T || tk_w != WG_T) && (d.a_row_div & (d.a_row_div - 1)) == 0 && !d.c_row_scale && d.c_row_div == 1;
+  // the previous call's slab reduction (a->prev): in front of this launch (128 x 128 kernel), or as its own launch
+  d.rd_blocks = 0; d.rd_zslices = 0;
+  if (a->prev) {
+    const m3_wgrad_reduce_desc *r = a->prev;
+    M3_REQUIRE(r->ws && r->dW && r->elems >= 0 && r->elems % 4 == 0 && (r->chunk_rows == 0 ? r->splits >= 1 : (r->group_offsets && r->G >= 1 && r->G <= 64)),
+               "m3_wgrad_tn: bad prev reduce descriptor");
+    M3_REQUIRE(!r->bias_ws || (r->db && r->bias_elems > 0 && r->bias_elems % 4 == 0), "m3_wgrad_tn: prev bias slabs need db");
+    M3_REQUIRE(r->ws != a->ws, "m3_wgrad_tn: prev slabs and this call's slabs must be different buffers");
+    if (r->elems > 0) {
+      if (wide || a->M == 0) {
+        int rc = r->chunk_rows ? m3_wgrad_reduce_grouped(r->ws, r->group_offsets, r->G, r->chunk_rows, r->elems, r->dW, r->beta, r->bias_ws,
+                                                         r->bias_elems, r->db, r->beta_db, stream)
+                               : m3_wgrad_reduce(r->ws, r->splits, r->elems, r->dW, r->beta, r->bias_ws, r->bias_elems, r->db, r->beta_db, stream);
+        if (rc) return rc;
+      } else {
+        const int64_t e4 = r->elems / 4, b4 = r->bias_ws ? r->bias_elems / 4 : 0;
+        d.rd_nbw = (int)((e4 + 255) / 256);
+        d.rd_nbx = d.rd_nbw + (int)((b4 + 255) / 256);
+        d.rd_blocks = d.rd_nbx * (r->chunk_rows ? r->G : 1);
+        d.rd_ws = r->ws; d.rd_splits = r->splits; d.rd_e4 = e4; d.rd_off = r->group_offsets; d.rd_G = r->G; d.rd_chunk = r->chunk_rows;
+        d.rd_dW = r->dW; d.rd_beta = r->beta; d.rd_bws = r->bias_ws; d.rd_b4 = b4; d.rd_db = r->db; d.rd_beta_db = r->beta_db;
+      }
+    }
+  }
+  if (wide) {
     constexpr int WR = M3_WGRAD_WIDE_ROWS;
     const bool wide_k = tk_w == 384;
     d.tiles_k = a->K / tk_w;
@@ -784,7 +854,12 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   }
   const int tiles_n = (a->N + WG_T - 1) / WG_T;
   d.tiles_k = (a->K + WG_T - 1) / WG_T;
-  const dim3 grid(tiles_n * d.tiles_k, a->chunk_rows ? a->units : a->G, a->chunk_rows ? 1 : a->splits), block(WG_THREADS);
+  dim3 grid(tiles_n * d.tiles_k, a->chunk_rows ? a->units : a->G, a->chunk_rows ? 1 : a->splits), block(WG_THREADS);
+  if (d.rd_blocks > 0) {                         // leading z slices for the previous call's reduce blocks
+    const int per_slice = (int)(grid.x * grid.y);
+    d.rd_zslices = (d.rd_blocks + per_slice - 1) / per_slice;
+    grid.z += d.rd_zslices;
+  }
   M3_REQUIRE(a->N * es >= 16 && a->K * es >= 16, "m3_wgrad_tn: N, K too small");
   const size_t lds16 = 4 * WgLds<half_t>::ROWS * WgLds<half_t>::STRIDE, lds32 = 4 * WgLds<float>::ROWS * WgLds<float>::STRIDE;
   const bool sc = a->c_row_scale != nullptr;

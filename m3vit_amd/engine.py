@@ -198,7 +198,11 @@ class BackboneEngine:
                              (R, self.Hm, D, self.E), (R, D, self.Hm, self.E), (self.B * self.np_, D, Kp, 1),
                              (T, D, self.E, 1)]:
             wg = max(wg, ops.wgrad_ws_elems(M, N, K, G, grouped=G > 1, dtype=self.dt))
-        self.ws_wgrad = self._e(wg, dtype=f32)
+        # weight-gradient slab reductions ride in front of the NEXT weight-gradient launch of the pass (ops.WgradQueue: two
+        # slab workspaces used in turn); with a wgrad side stream every call reduces for itself (its launches are not in
+        # one stream order with flush())
+        self.wq = ops.WgradQueue(wg, self.dev) if self.wg_stream is None else None
+        self.ws_wgrad = self._e(wg, dtype=f32) if self.wq is None else None
         cs = max(int(ops.lib().m3_colsum_ws_elems(T, 3 * D, 1)), int(ops.lib().m3_colsum_ws_elems(T, self.Hd, 1)),
                  int(ops.lib().m3_colsum_ws_elems(R, max(self.Hm, D), self.E)))
         self.ws_colsum = self._e(cs, dtype=f32)
@@ -558,7 +562,7 @@ class BackboneEngine:
 
     def _wgrad(self, dC, A, name, M=None, bias=None, reads=(), **kw):
         """weight grad (+ fused bias grad) accumulated into self.grads"""
-        self._fork(reads, lambda: ops.wgrad_tn(dC, A, self.grads[name], M=M, beta=1, ws=self.ws_wgrad,
+        self._fork(reads, lambda: ops.wgrad_tn(dC, A, self.grads[name], M=M, beta=1, ws=self.ws_wgrad, queue=self.wq,
                                                db=self.grads[bias] if bias is not None else None, **kw))
 
     def backward(self, d_tokens: torch.Tensor, cv_weight: float = 0.0):
@@ -665,7 +669,7 @@ class BackboneEngine:
                         dl_t, wg_t = dl, wg
                     else:
                         dl_t, wg_t = ops.cast_f32(dl, self.s_dl_t), self.wgate_c[a["wname"]][:D]
-                    self._fork(("dl",), lambda: ops.wgrad_tn(a["h2"], dl_t, dwg, beta=1, ws=self.ws_wgrad))
+                    self._fork(("dl",), lambda: ops.wgrad_tn(a["h2"], dl_t, dwg, beta=1, ws=self.ws_wgrad, queue=self.wq))
                     ops.gemm_nt(dl_t, wg_t, self.s_dh32, residual=self.s_dh32)
                 else:
                     ops.gate_bwd_params(a["h2"], wg, dl, d_w_gate=dwg, beta_dw=1, dx=self.s_dh32,
@@ -698,6 +702,9 @@ class BackboneEngine:
                               dx_act=self.s_dx_t if nxt_dx_t else None)
             dx, other = other, dx
             have_dx_t = nxt_dx_t
+        # the last weight-gradient call's slabs (a data-parallel step all-reduces these blocks' slice next)
+        if self.wq is not None:
+            self.wq.flush()
         # norm weight / bias gradients of the blocks just done, all in one launch (their partial slots are contiguous)
         if hi >= lo:
             ops.layernorm_bwd_reduce(self.ws_ln, self.ln_nblk, self.D, self.ln_table, 2 * lo, 2 * (hi - lo + 1), beta=1)
@@ -714,8 +721,10 @@ class BackboneEngine:
         # patch embedding / cls / pos
         ops.tokens_bwd(dx, B, self.np_, D, self.s_dpatch, gr["pos_embed"].view(self.N, D), gr["cls_token"].view(D), beta=1)
         gw = gr["patch_embed.proj.weight"].view(D, -1)
-        self._fork((), lambda: ops.wgrad_tn(self.s_dpatch, self.rows, gw, beta=1, ws=self.ws_wgrad,
+        self._fork((), lambda: ops.wgrad_tn(self.s_dpatch, self.rows, gw, beta=1, ws=self.ws_wgrad, queue=self.wq,
                                             db=gr["patch_embed.proj.bias"]))
+        if self.wq is not None:
+            self.wq.flush()
         self._join_wgrad()
         if self._tsf is not None:
             self._task_feature_bwd(self._bw.get("d_tsf"))

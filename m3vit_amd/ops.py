@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import M3_ACT_GELU, M3_ACT_NONE, M3_BF16, M3_F16, M3_F32, GemmArgs, WgradArgs, check, lib
+from ._lib import M3_ACT_GELU, M3_ACT_NONE, M3_BF16, M3_F16, M3_F32, GemmArgs, WgradArgs, WgradReduceDesc, check, lib
 
 _DT = {torch.float32: M3_F32, torch.float16: M3_F16, torch.bfloat16: M3_BF16}      # bf16: every entry point except the opt-in fused m3_ffn_fwd
 
@@ -284,23 +284,60 @@ def ffn_fwd(X, W1, W2p, Y, *, b1=None, b2=None, M=None, residual=None, x_row_idx
     return Y
 
 
+class WgradQueue:
+    """Weight-gradient calls of ONE stream whose slab reductions ride in front of the next call's launch
+    (m3_wgrad_args.prev) instead of being launched by themselves: two slab workspaces used in turn, the reduction of the
+    latest call pending until the next wgrad_tn(.., queue=self) or flush().  Whoever reads the gradients (an all-reduce,
+    the optimizer, a test) calls flush() first."""
+
+    def __init__(self, ws_elems: int, device):
+        self.ws = [torch.empty(ws_elems, dtype=torch.float32, device=device) for _ in range(2)]
+        self.i = 0
+        self.pending = None          # (WgradReduceDesc, tensors it points at)
+
+    def flush(self):
+        if self.pending is None:
+            return
+        d, _keep = self.pending
+        self.pending = None
+        if d.elems == 0:
+            return
+        if d.chunk_rows:
+            check(lib().m3_wgrad_reduce_grouped(d.ws, d.group_offsets, d.G, d.chunk_rows, d.elems, d.dW, d.beta, d.bias_ws,
+                                                d.bias_elems, d.db, d.beta_db, _stream()), "m3_wgrad_reduce_grouped")
+        else:
+            check(lib().m3_wgrad_reduce(d.ws, d.splits, d.elems, d.dW, d.beta, d.bias_ws, d.bias_elems, d.db, d.beta_db,
+                                        _stream()), "m3_wgrad_reduce")
+
+
 def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None, a_row_idx=None, a_row_div=1,
-             group_offsets=None, db=None, beta_db=None, c_row_div=1, c_row_scale=None):
+             group_offsets=None, db=None, beta_db=None, c_row_div=1, c_row_scale=None, queue: Optional[WgradQueue] = None):
     """dW[g][n,k] (+)= sum_m dC[crow(m),n] A[arow(m),k].  dW f32 [N,K] or [G,N,K].
     db (optional, f32 [N] / [G,N]): bias gradient = column sums of dC, fused into the same pass.
-    c_row_div / c_row_scale (with c_row_idx): slot m reads c_row_scale[c_row_idx[m]] * dC[c_row_idx[m] // c_row_div]."""
+    c_row_div / c_row_scale (with c_row_idx): slot m reads c_row_scale[c_row_idx[m]] * dC[c_row_idx[m] // c_row_div].
+    queue: this call's slab reduction is left pending in the queue (dW is complete only after the queue's next call or
+    flush()) and the queue's previous pending reduction runs in front of this launch."""
     _req(dC, name="dC"); _req(A, dC.dtype, "A"); _req(dW, torch.float32, "dW")
     G = 1 if dW.dim() == 2 else dW.shape[0]
     N, K = dW.shape[-2], dW.shape[-1]
     if M is None:
         M = c_row_idx.numel() if c_row_idx is not None else dC.shape[0]
+    if M == 0:                                   # nothing to contract over: no launch (an empty tensor has no address)
+        if not beta:
+            dW.zero_()
+        if db is not None and not (beta if beta_db is None else beta_db):
+            db.zero_()
+        return dW
     if splits is None:
         splits = default_wgrad_splits(M, N, K, G, dC.dtype)
     balanced = group_offsets is not None
     chunk, units = wgrad_plan(M, G, splits, balanced)
     balanced = chunk > 0
     need = units * N * K + (units * N if db is not None else 0)
-    if ws is None or ws.numel() < need:
+    if queue is not None:
+        ws = queue.ws[queue.i]
+        assert ws.numel() >= need, "WgradQueue workspace too small for this shape"
+    elif ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.float32, device=dW.device)
     a = WgradArgs()
     a.dC = dC.data_ptr(); a.lddc = dC.stride(0)
@@ -321,12 +358,31 @@ def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None,
     a.dtype = dt_code(dC.dtype)
     bias_ws = ws[units * N * K:] if db is not None else None
     a.bias_ws = bias_ws.data_ptr() if bias_ws is not None else None
-    check(lib().m3_wgrad_tn(byref(a), _stream()), "m3_wgrad_tn")
     bdb = beta if beta_db is None else beta_db
     fuse = False
     if db is not None:
         _req(db, torch.float32, "db")
         fuse = db.data_ptr() % 16 == 0 and bias_ws.data_ptr() % 16 == 0      # both slab reductions in one launch
+    if queue is not None:
+        assert db is None or fuse, "queued wgrad: db and the bias slabs must be 16-byte aligned"
+        prev = queue.pending
+        if prev is not None:
+            a.prev = ctypes.pointer(prev[0])
+        check(lib().m3_wgrad_tn(byref(a), _stream()), "m3_wgrad_tn")
+        d = WgradReduceDesc()
+        d.ws = ws.data_ptr(); d.splits = splits
+        d.elems = (N * K) if balanced else (G * N * K)
+        d.group_offsets = group_offsets.data_ptr() if balanced else None
+        d.G = G; d.chunk_rows = chunk if balanced else 0
+        d.dW = dW.data_ptr(); d.beta = beta
+        d.bias_ws = bias_ws.data_ptr() if fuse else None
+        d.bias_elems = (N if balanced else G * N) if fuse else 0
+        d.db = db.data_ptr() if fuse else None
+        d.beta_db = bdb
+        queue.pending = (d, (ws, dW, db, group_offsets))
+        queue.i ^= 1
+        return dW
+    check(lib().m3_wgrad_tn(byref(a), _stream()), "m3_wgrad_tn")
     if balanced:
         assert db is None or fuse, "balanced grouped wgrad: db and the bias slabs must be 16-byte aligned"
         check(lib().m3_wgrad_reduce_grouped(_p(ws), _p(group_offsets), G, chunk, N * K, _p(dW), beta,

@@ -209,6 +209,52 @@ def test_expert_backward_takes_the_combine_gradient_unmaterialised(ops, dtype):
     assert rel(dW3, ref3) < TOL[dtype]
 
 
+def test_wgrad_queue_rides_the_reduction_on_the_next_launch(ops):
+    """ops.WgradQueue: the slab reduction of a weight-gradient call runs as the leading blocks of the NEXT call's launch
+    (m3_wgrad_args.prev) and the last one by flush() - dense, dense + bias, balanced grouped + bias with gathers, an empty
+    call and a tiny K in one sequence; every result bit-identical to the call that reduces for itself."""
+    dt = torch.float16
+    T, k, D, H, E = 900, 4, 384, 384, 16
+    g = torch.Generator().manual_seed(61)
+    idx = torch.stack([torch.randperm(E, generator=g)[:k] for _ in range(T)]).to(torch.int32).to(dev())
+    r = ops.route_build(idx, E)
+    R = T * k
+    x = rnd(T, D, dtype=dt, seed=62); dyd = rnd(T, 3 * D, dtype=dt, seed=63); dhp = rnd(R, H, dtype=dt, seed=64)
+    dyt = rnd(R, D, dtype=dt, seed=65); hid = rnd(R, H, dtype=dt, seed=66); dl = rnd(T, E, dtype=dt, seed=67)
+    calls = [
+        dict(dC=dyd, A=x, shape=(3 * D, D), kw=dict()),                                              # qkv-like, no bias
+        dict(dC=dyd, A=x, shape=(3 * D, D), kw=dict(), bias=True),
+        dict(dC=dhp, A=x, shape=(E, H, D), kw=dict(M=R, a_row_idx=r.row_of_slot, a_row_div=k, group_offsets=r.offsets), bias=True),
+        dict(dC=dyt, A=hid, shape=(E, D, H), kw=dict(M=R, c_row_idx=r.row_of_slot, group_offsets=r.offsets), bias=True),
+        dict(dC=x, A=dl, shape=(D, E), kw=dict()),                                                   # gate: K = 16
+        dict(dC=dyd[:0], A=x[:0], shape=(3 * D, D), kw=dict(M=0), bias=True),                        # empty call
+        dict(dC=x, A=x, shape=(D, D), kw=dict(), bias=True),
+    ]
+
+    def run(queue):
+        outs = []
+        for i, c in enumerate(calls):
+            dW = rnd(*c["shape"], seed=70 + i)                     # beta = 1 accumulates onto this
+            db = rnd(*c["shape"][:-1], seed=90 + i) if c.get("bias") else None
+            ops.wgrad_tn(c["dC"], c["A"], dW, beta=1, db=db, queue=queue, **c["kw"])
+            outs.append((dW, db))
+        if queue is not None:
+            assert queue.pending is not None
+            queue.flush()
+            assert queue.pending is None
+        torch.cuda.synchronize()
+        return outs
+    want = run(None)
+    need = max(ops.wgrad_ws_elems(c["kw"].get("M", c["dC"].shape[0]), c["shape"][-2], c["shape"][-1],
+                                  c["shape"][0] if len(c["shape"]) == 3 else 1, grouped="group_offsets" in c["kw"], dtype=dt)
+               for c in calls)
+    got = run(ops.WgradQueue(need, dev()))
+    for i, ((w0, b0), (w1, b1)) in enumerate(zip(want, got)):
+        assert torch.equal(w0, w1), f"call {i}: dW differs"
+        assert b0 is None or torch.equal(b0, b1), f"call {i}: db differs"
+    assert float(want[2][0].abs().max()) > 0
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_wgrad_dense_and_colsum(ops, dtype):
     M, N, K = 2000, 384, 256
@@ -507,7 +553,11 @@ def _attn_ref(qkv, B, N, h, dh):
 @pytest.mark.parametrize("B,N,h,dh", [(2, 197, 12, 32), (1, 50, 3, 32), (1, 256, 2, 64), (2, 65, 4, 64),
                                       (1, 1025, 2, 32), (1, 1201, 2, 64), (2, 257, 3, 32),
                                       (3, 256, 2, 32), (2, 1, 2, 32), (2, 17, 3, 32), (1, 224, 5, 32), (2, 225, 1, 32),
-                                      (2, 197, 12, 64), (1, 33, 2, 64), (2, 240, 1, 64)])
+                                      (2, 197, 12, 64), (1, 33, 2, 64), (2, 240, 1, 64),
+                                      # every tiles-per-wave instance of the short-sequence backward (dh 32: 64 / 128 / 192 /
+                                      # 256 keys; dh 64: 128 / 256) at its edges
+                                      (2, 64, 2, 32), (1, 100, 3, 32), (2, 128, 1, 32), (1, 129, 2, 32), (2, 180, 2, 32),
+                                      (1, 192, 3, 32), (2, 193, 1, 32), (1, 128, 2, 64), (2, 129, 1, 64)])
 def test_attention_fwd_bwd(ops, dtype, B, N, h, dh):
     C = h * dh
     qkv = rnd(B * N, 3 * C, dtype=dtype, seed=71)

@@ -50,16 +50,16 @@ orig = {n: getattr(L, n) for names in CLASSES.values() for n in names}
 def build(skip):
     for n, f in orig.items():
         setattr(L, n, f)
-    for n in skip:
-        setattr(L, n, lambda *args: 0)
     r = MultiTaskStep(cfg, params, batch=128, dtype=torch.float16, device=str(dev), parallel_tasks=not a.serial)
     g = torch.Generator().manual_seed(1000)
     img = torch.randn(128, 3, *cfg.img_size, generator=g).to(dev)
     dtok = (torch.randn(128, cfg.num_tokens, cfg.embed_dim, generator=g) * 0.05).to(dev)
     r.bind(img, dtok)
-    r.step_eager()
-    torch.cuda.synchronize()
-    assert r.capture()
+    r.step_eager()                       # a COMPLETE step first: every buffer a skipped kernel would write keeps realistic
+    torch.cuda.synchronize()             # (stale) values - zeros or NaNs downstream would change the clock the chip holds
+    for n in skip:
+        setattr(L, n, lambda *args: 0)
+    assert r.capture()                   # (capture's own warm-up run and the captured graph lack the skipped launches)
     return r
 
 
