@@ -87,7 +87,8 @@ __global__ __launch_bounds__(AR_THREADS, DH == 32 ? 4 : 2) void attention_fwd_re
   // K / V images: ALL loads of the thread are issued before the first LDS store (a rolled loop waits for each
   // iteration's loads in turn: in-kernel stamps showed a third of a workgroup's life in this phase)
   {
-    constexpr int SIT = NKEY * CPR / AR_THREADS, SB = SIT < 4 ? SIT : 4;      // batches of <= 4 iterations (registers)
+    constexpr int SIT = NKEY * CPR / AR_THREADS;                              // (NKEY * CPR is a multiple of 256)
+    constexpr int SB = SIT % 4 == 0 ? 4 : (SIT % 3 == 0 ? 3 : (SIT % 2 == 0 ? 2 : 1));   // batches of <= 4 iterations (registers) that tile SIT exactly
 #pragma unroll
     for (int it0 = 0; it0 < SIT; it0 += SB) {
       u32x4 kv[SB], vv[SB];

@@ -376,13 +376,20 @@ constexpr int DMA_LDS_ALL = DMA_LDS + BM * 4;   // + the tile's 128 per-row epil
 
 __device__ __forceinline__ int dma_swz(int row) { return (row >> 1) & 7; }
 
-// EPI: what the epilogue reads from memory, as a template constant.  DMA_EPI_ANY keeps every option behind run-time
-// flags (each `if (p.gpre)` / `if (p.residual)` is then its own basic block: the load of a store pass is issued inside
-// the pass and its latency is paid eight times per tile, in front of the stores).  DMA_EPI_GPRE (the GELU'-fused input
-// gradients: fc2 / expert FC2 dgrad) and DMA_EPI_RES (fp32 residual add: proj, fc2 forward) request the four rows a thread
-// needs for a 64-row half BEFORE that half's staging barriers, so they arrive under the LDS transposition, and the four
-// store passes are straight-line code (rows past the group's end are clamped for the loads and predicated for the stores).
-enum { DMA_EPI_ANY = 0, DMA_EPI_GPRE = 1, DMA_EPI_RES = 2 };
+// EPI: the epilogue's kind as a template constant.  DMA_EPI_ANY keeps every option behind run-time flags: each
+// `if (p.gpre)` / `if (p.residual)` / `if (m >= m_end) break` is then a basic-block boundary, the loads of a store pass are
+// issued inside the pass and the eight passes of a tile run strictly one after the other, every one paying its memory
+// latency in front of its stores.  The four kinds below cover every 16-bit launch of the training step with straight-line
+// passes: what a thread needs from memory for a 64-row half - scatter indices, GELU' pre-activations, residual rows - is
+// requested BEFORE that half's staging barriers and arrives under the LDS transposition; the per-row factor is always
+// applied (1.0 without row_scale); rows past the group's end repeat the group's last row (the operand rows were clamped at
+// the load, so the values are that row's own: a duplicate store of identical data) - except with the fp32 residual, where
+// C may alias the residual and the store stays predicated.
+//   PLAIN  C = acc (+ bias), optional scatter                      qkv, every plain input gradient, expert FC2 forward
+//   GELU   pre_out = acc + bias ; C = GELU(pre_out)                fc1 / expert FC1 forward
+//   GPRE   C = acc * GELU'(gpre)                                   fc2 / expert FC2 input gradient
+//   RES    C(fp32) = acc (+ bias) + residual                       proj, fc2 forward
+enum { DMA_EPI_ANY = 0, DMA_EPI_GPRE = 1, DMA_EPI_RES = 2, DMA_EPI_PLAIN = 3, DMA_EPI_GELU = 4 };
 
 template <typename T, int EPI = DMA_EPI_ANY>
 __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const GemmDev p) {
@@ -515,27 +522,32 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const Gemm
   f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
   if (bias && n < p.N) { b0 = *(const f32x4 *)(bias + n); b1 = *(const f32x4 *)(bias + n + 4); }
   float *const s_rs = (float *)(smem + DMA_LDS);         // (behind the operand images: written once, read after the barriers below)
-  if (p.row_scale && tid < BM) s_rs[tid] = my_rs;
+  if (tid < BM) s_rs[tid] = my_rs;                       // 1.0 without row_scale
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     // specialised epilogues: this half's memory operands, requested ahead of the staging barriers (unconditional loads:
     // rows past the end are clamped)
     u32x4 gq[4];
     f32x4 rq[4][2];
+    int32_t crow4[4];                            // (rows fit 32 bits: the host checks the 4 GiB reach of an operand panel)
     // (fp32 residual rows are 8 registers a pass: two passes are requested here, two behind the barriers, while
     // this wave's accumulators are on their way out - all four at once did not fit the 128-register budget)
     constexpr int NPRE = EPI == DMA_EPI_RES ? 2 : 4;
     auto fetch_epi = [&](int ps) {
-      int64_t m = m_begin + h * 64 + ps * 16 + r16;
-      if (m >= m_end) m = m_end - 1;
-      if constexpr (EPI == DMA_EPI_GPRE) gq[ps] = *(const u32x4 *)((const T *)p.gpre + m * p.ld_gpre + n);
+      if constexpr (EPI == DMA_EPI_GPRE) gq[ps] = *(const u32x4 *)((const T *)p.gpre + (int64_t)crow4[ps] * p.ld_gpre + n);
       if constexpr (EPI == DMA_EPI_RES) {
-        rq[ps][0] = *(const f32x4 *)(p.residual + m * p.ld_res + n);
-        rq[ps][1] = *(const f32x4 *)(p.residual + m * p.ld_res + n + 4);
+        rq[ps][0] = *(const f32x4 *)(p.residual + (int64_t)crow4[ps] * p.ld_res + n);
+        rq[ps][1] = *(const f32x4 *)(p.residual + (int64_t)crow4[ps] * p.ld_res + n + 4);
       }
     };
     if constexpr (EPI != DMA_EPI_ANY) {
       if (n < p.N) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          int64_t m = m_begin + h * 64 + ps * 16 + r16;
+          if (m >= m_end) m = m_end - 1;
+          crow4[ps] = p.c_row_idx ? p.c_row_idx[m] : (int32_t)m;
+        }
 #pragma unroll
         for (int ps = 0; ps < NPRE; ++ps) fetch_epi(ps);
       }
@@ -559,29 +571,32 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const Gemm
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
           const int lrow = ps * 16 + r16;
-          const int64_t m = m_begin + h * 64 + lrow;
+          const int64_t crow = crow4[ps];
           const int sw = lrow & 31;
           f32x4 v0 = *(const f32x4 *)(smem + lrow * 512 + (((2 * cg) ^ sw) << 4));
           f32x4 v1 = *(const f32x4 *)(smem + lrow * 512 + (((2 * cg + 1) ^ sw) << 4));
           v0 += b0; v1 += b1;
+          if constexpr (EPI == DMA_EPI_GELU) {
+            Vec8<T>::store((T *)p.pre_out + crow * p.ld_pre + n, v0, v1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v0[j] = gelu_f(v0[j]); v1[j] = gelu_f(v1[j]); }
+          }
           if constexpr (EPI == DMA_EPI_GPRE) {
             typedef T t8 __attribute__((ext_vector_type(8)));
             const t8 pr = __builtin_bit_cast(t8, gq[ps]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { v0[j] *= gelu_grad_f((float)pr[j]); v1[j] *= gelu_grad_f((float)pr[4 + j]); }
           }
-          if (p.row_scale) {
-            const float sc = s_rs[h * 64 + lrow];
-            v0 *= sc; v1 *= sc;
-          }
+          const float sc = s_rs[h * 64 + lrow];
+          v0 *= sc; v1 *= sc;
           if constexpr (EPI == DMA_EPI_RES) {
             v0 += rq[ps][0]; v1 += rq[ps][1];
-            if (m < m_end) {
-              *(f32x4 *)((float *)p.C + m * p.ldc + n) = v0;
-              *(f32x4 *)((float *)p.C + m * p.ldc + n + 4) = v1;
+            if (m_begin + h * 64 + lrow < m_end) {          // (C may be the residual buffer: no duplicate read-modify-write)
+              *(f32x4 *)((float *)p.C + crow * p.ldc + n) = v0;
+              *(f32x4 *)((float *)p.C + crow * p.ldc + n + 4) = v1;
             }
           } else {
-            if (m < m_end) Vec8<T>::store((T *)p.C + m * p.ldc + n, v0, v1);
+            Vec8<T>::store((T *)p.C + crow * p.ldc + n, v0, v1);
           }
         }
       }
@@ -1104,18 +1119,23 @@ extern "C" int m3_gemm_nt(const m3_gemm_args *a, void *stream) {
   if (dma_mode < 0) { const char *e = getenv("M3_GEMM_DMA"); dma_mode = e ? (atoi(e) ? 1 : 0) : 2; }
   const bool dma_ok = d.vec8 && (a->K * es) % DMA_RB == 0;
   if (dma_ok && (dma_mode == 1 || (dma_mode == 2 && es == 2))) {
-    // epilogue specialisations (16-bit dtypes): GELU' multiply alone / fp32 residual add alone, rows written in place
+    // epilogue kinds (16-bit dtypes; anything else takes the generic epilogue)
     int epi = DMA_EPI_ANY;
     static int epi_mode = -1;                    // M3_GEMM_EPI=0: generic epilogue everywhere (diagnostics)
     if (epi_mode < 0) { const char *e = getenv("M3_GEMM_EPI"); epi_mode = e ? atoi(e) : 1; }
-    if (epi_mode && es == 2 && !a->c_row_idx && !a->pre_out && a->act == M3_ACT_NONE) {
-      if (a->gelu_grad_pre && !a->residual && !d.c_f32 && !a->bias) epi = DMA_EPI_GPRE;
-      else if (a->residual && !a->gelu_grad_pre && d.c_f32) epi = DMA_EPI_RES;
+    if (epi_mode && es == 2) {
+      const bool none = a->act == M3_ACT_NONE && !a->pre_out;
+      if (none && a->gelu_grad_pre && !a->residual && !d.c_f32 && !a->bias) epi = DMA_EPI_GPRE;
+      else if (none && a->residual && !a->gelu_grad_pre && d.c_f32) epi = DMA_EPI_RES;
+      else if (none && !a->gelu_grad_pre && !a->residual && !d.c_f32) epi = DMA_EPI_PLAIN;
+      else if (a->act == M3_ACT_GELU && a->pre_out && !a->gelu_grad_pre && !a->residual && !d.c_f32) epi = DMA_EPI_GELU;
     }
 #define M3_DMA_GO(TT)                                                                                                  \
     do {                                                                                                               \
       if (epi == DMA_EPI_GPRE) hipLaunchKernelGGL((gemm_nt_dma_kernel<TT, DMA_EPI_GPRE>), grid, block, DMA_LDS_ALL, s, d);  \
       else if (epi == DMA_EPI_RES) hipLaunchKernelGGL((gemm_nt_dma_kernel<TT, DMA_EPI_RES>), grid, block, DMA_LDS_ALL, s, d); \
+      else if (epi == DMA_EPI_PLAIN) hipLaunchKernelGGL((gemm_nt_dma_kernel<TT, DMA_EPI_PLAIN>), grid, block, DMA_LDS_ALL, s, d); \
+      else if (epi == DMA_EPI_GELU) hipLaunchKernelGGL((gemm_nt_dma_kernel<TT, DMA_EPI_GELU>), grid, block, DMA_LDS_ALL, s, d); \
       else hipLaunchKernelGGL((gemm_nt_dma_kernel<TT, DMA_EPI_ANY>), grid, block, DMA_LDS_ALL, s, d);                  \
     } while (0)
     if (a->dtype == M3_F16) M3_DMA_GO(half_t);

@@ -14,44 +14,89 @@ namespace m3 {
 constexpr int ROW_THREADS = 256;   // 4 waves = 4 rows per workgroup
 
 // ------------------------------------------------------------------- combine
-template <typename T>
+// KT: top-k as a template constant (1, 2, 4, 8; 0 = run-time k).  With a run-time trip count the k row loads of a token
+// are issued one dependent iteration at a time; unrolled, all k rows of a 16-byte column are in flight together.
+template <typename T, int KT>
 __global__ __launch_bounds__(ROW_THREADS) void combine_fwd_kernel(const T *__restrict__ y, const float *__restrict__ score,
                                                                   const float *__restrict__ residual, int64_t T_,
-                                                                  int k, int D, float *__restrict__ out) {
+                                                                  int k_rt, int D, float *__restrict__ out) {
+  const int k = KT ? KT : k_rt;
   const int lane = threadIdx.x & 63;
   const int64_t t = (int64_t)blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
   if (t >= T_) return;
   const float *sc = score + t * k;
-  for (int d = lane * 4; d < D; d += 256) {
-    f32x4 acc = residual ? *(const f32x4 *)(residual + t * D + d) : f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < k; ++j) {
-      const f32x4 v = Vec4<T>::load(y + (t * k + j) * D + d);
-      const float s = sc[j];
-      acc[0] = __builtin_fmaf(s, v[0], acc[0]); acc[1] = __builtin_fmaf(s, v[1], acc[1]);
-      acc[2] = __builtin_fmaf(s, v[2], acc[2]); acc[3] = __builtin_fmaf(s, v[3], acc[3]);
+  if constexpr (KT > 0) {
+    float sv[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) sv[j] = sc[j];
+    for (int d = lane * 4; d < D; d += 256) {
+      f32x4 v[KT];
+#pragma unroll
+      for (int j = 0; j < KT; ++j) v[j] = Vec4<T>::load(y + (t * KT + j) * D + d);
+      f32x4 acc = residual ? *(const f32x4 *)(residual + t * D + d) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {                       // (same order as the run-time loop: j = 0, 1, ...)
+        acc[0] = __builtin_fmaf(sv[j], v[j][0], acc[0]); acc[1] = __builtin_fmaf(sv[j], v[j][1], acc[1]);
+        acc[2] = __builtin_fmaf(sv[j], v[j][2], acc[2]); acc[3] = __builtin_fmaf(sv[j], v[j][3], acc[3]);
+      }
+      *(f32x4 *)(out + t * D + d) = acc;
     }
-    *(f32x4 *)(out + t * D + d) = acc;
+  } else {
+    for (int d = lane * 4; d < D; d += 256) {
+      f32x4 acc = residual ? *(const f32x4 *)(residual + t * D + d) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < k; ++j) {
+        const f32x4 v = Vec4<T>::load(y + (t * k + j) * D + d);
+        const float s = sc[j];
+        acc[0] = __builtin_fmaf(s, v[0], acc[0]); acc[1] = __builtin_fmaf(s, v[1], acc[1]);
+        acc[2] = __builtin_fmaf(s, v[2], acc[2]); acc[3] = __builtin_fmaf(s, v[3], acc[3]);
+      }
+      *(f32x4 *)(out + t * D + d) = acc;
+    }
   }
 }
 
-template <typename T>
+template <typename T, int KT>
 __global__ __launch_bounds__(ROW_THREADS) void combine_bwd_kernel(const float *__restrict__ dout, const T *__restrict__ y,
-                                                                  const float *__restrict__ score, int64_t T_, int k,
+                                                                  const float *__restrict__ score, int64_t T_, int k_rt,
                                                                   int D, T *__restrict__ dy, float *__restrict__ dscore) {
+  const int k = KT ? KT : k_rt;
   const int lane = threadIdx.x & 63;
   const int64_t t = (int64_t)blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
   if (t >= T_) return;
-  for (int j = 0; j < k; ++j) {
-    const float s = score[t * k + j];
-    float dot = 0.f;
+  if constexpr (KT > 0) {
+    // one pass over the token's gradient row for all k routed rows: dout is read once, the k dot products run side by side
+    float dot[KT], sv[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) { dot[j] = 0.f; sv[j] = score[t * KT + j]; }
     for (int d = lane * 4; d < D; d += 256) {
       const f32x4 g = *(const f32x4 *)(dout + t * D + d);
-      const f32x4 v = Vec4<T>::load(y + (t * k + j) * D + d);
-      dot += g[0] * v[0] + g[1] * v[1] + g[2] * v[2] + g[3] * v[3];
-      if (dy) Vec4<T>::store(dy + (t * k + j) * D + d, f32x4{s * g[0], s * g[1], s * g[2], s * g[3]});
+      f32x4 v[KT];
+#pragma unroll
+      for (int j = 0; j < KT; ++j) v[j] = Vec4<T>::load(y + (t * KT + j) * D + d);
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {
+        dot[j] += g[0] * v[j][0] + g[1] * v[j][1] + g[2] * v[j][2] + g[3] * v[j][3];
+        if (dy) Vec4<T>::store(dy + (t * KT + j) * D + d, f32x4{sv[j] * g[0], sv[j] * g[1], sv[j] * g[2], sv[j] * g[3]});
+      }
     }
-    dot = wave_sum(dot);
-    if (lane == 0) dscore[t * k + j] = dot;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+      const float s = wave_sum(dot[j]);
+      if (lane == 0) dscore[t * KT + j] = s;
+    }
+  } else {
+    for (int j = 0; j < k; ++j) {
+      const float s = score[t * k + j];
+      float dot = 0.f;
+      for (int d = lane * 4; d < D; d += 256) {
+        const f32x4 g = *(const f32x4 *)(dout + t * D + d);
+        const f32x4 v = Vec4<T>::load(y + (t * k + j) * D + d);
+        dot += g[0] * v[0] + g[1] * v[1] + g[2] * v[2] + g[3] * v[3];
+        if (dy) Vec4<T>::store(dy + (t * k + j) * D + d, f32x4{s * g[0], s * g[1], s * g[2], s * g[3]});
+      }
+      dot = wave_sum(dot);
+      if (lane == 0) dscore[t * k + j] = dot;
+    }
   }
 }
 
@@ -129,7 +174,7 @@ static int ln_rows_per_wave() {
 // NCH = ceil(D / 256): 16-byte chunks per lane (registers are sized for the row width in use: D = 384 -> 2, not 4,
 // which takes the kernel from 116 to ~70 VGPRs and from 4 to 7 waves per SIMD)
 template <typename T, typename TA, int NCH, int LNB_WAVES>
-__global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const T *__restrict__ dy, const float *__restrict__ x,
+__global__ __launch_bounds__(LNB_WAVES * 64, 4) void layernorm_bwd_kernel(const T *__restrict__ dy, const float *__restrict__ x,
                                                                     const float *__restrict__ mean,
                                                                     const float *__restrict__ rstd,
                                                                     const float *__restrict__ gamma,
@@ -142,12 +187,11 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const T *
   f32x4 dg[NCH], db[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) { dg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; db[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  for (int r = 0; r < rpw; ++r) {
-    const int64_t t = ((int64_t)blockIdx.x * LNB_WAVES + wave) * rpw + r;
-    if (t >= T_) break;
+  // A row is a dependent chain: loads -> two wave reductions -> stores.  Two rows go through it side by side (their loads
+  // in flight together, their shuffle chains interleaved); the parameter-gradient sums still take the rows in row order.
+  auto load_row = [&](int64_t t, f32x4(&gdy)[NCH], f32x4(&xh)[NCH], float &s1, float &s2) {
     const float mu = mean[t], rs = rstd[t];
-    f32x4 gdy[NCH], xh[NCH];
-    float s1 = 0.f, s2 = 0.f;
+    s1 = 0.f; s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int d = lane * 4 + i * 256;
@@ -158,11 +202,13 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const T *
         gdy[i] = dyv * g;
         s1 += gdy[i][0] + gdy[i][1] + gdy[i][2] + gdy[i][3];
         s2 += gdy[i][0] * xh[i][0] + gdy[i][1] * xh[i][1] + gdy[i][2] * xh[i][2] + gdy[i][3] * xh[i][3];
-        dg[i] += dyv * xh[i];
+        dg[i] += dyv * xh[i];                    // (rows enter the parameter-gradient sums in row order)
         db[i] += dyv;
       }
     }
-    const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+  };
+  auto finish_row = [&](int64_t t, const f32x4(&gdy)[NCH], const f32x4(&xh)[NCH], float m1, float m2) {
+    const float rs = rstd[t];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int d = lane * 4 + i * 256;
@@ -173,6 +219,35 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const T *
         if (dx_act) Vec4<TA>::store(dx_act + t * D + d, o);   // activation-dtype copy for the next GEMMs
       }
     }
+  };
+  const int64_t tw = ((int64_t)blockIdx.x * LNB_WAVES + wave) * rpw;
+  const float inv_d = 1.0f / (float)D;
+  int r = 0;
+  constexpr bool PAIRS = NCH <= 2;               // (wider rows: two rows' registers do not fit 128 - one row at a time)
+  for (; PAIRS && r + 1 < rpw && tw + r + 1 < T_; r += 2) {
+    f32x4 gA[NCH], xA[NCH], gB[NCH], xB[NCH];
+    float a1, a2, b1, b2;
+    load_row(tw + r, gA, xA, a1, a2);
+    load_row(tw + r + 1, gB, xB, b1, b2);
+    // four independent reductions, step by step side by side
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64);
+      b1 += __shfl_xor(b1, o, 64); b2 += __shfl_xor(b2, o, 64);
+    }
+    finish_row(tw + r, gA, xA, a1 * inv_d, a2 * inv_d);
+    finish_row(tw + r + 1, gB, xB, b1 * inv_d, b2 * inv_d);
+  }
+  auto one_row = [&](int64_t t) {
+    f32x4 gA[NCH], xA[NCH];
+    float a1, a2;
+    load_row(t, gA, xA, a1, a2);
+    finish_row(t, gA, xA, wave_sum(a1) * inv_d, wave_sum(a2) * inv_d);
+  };
+  if constexpr (PAIRS) {
+    if (r < rpw && tw + r < T_) one_row(tw + r);                     // odd row at the end
+  } else {
+    for (; r < rpw && tw + r < T_; ++r) one_row(tw + r);
   }
   // block partials: waves in order
 #pragma unroll
@@ -353,14 +428,11 @@ extern "C" int m3_combine_fwd(const void *y, int dtype, const float *score, cons
   M3_REQUIRE(D % 4 == 0 && D > 0 && k >= 1, "m3_combine_fwd: D must be a multiple of 4");
   if (T == 0) return M3_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == M3_F16)
-    hipLaunchKernelGGL(combine_fwd_kernel<half_t>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, (const half_t *)y,
-                       score, residual, T, k, D, out);
-  else if (dtype == M3_BF16)     hipLaunchKernelGGL(combine_fwd_kernel<bf16_t>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, (const bf16_t *)y,
-                       score, residual, T, k, D, out);
-  else
-    hipLaunchKernelGGL(combine_fwd_kernel<float>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, (const float *)y, score,
-                       residual, T, k, D, out);
+#define M3_CF(TT, KT_) hipLaunchKernelGGL((combine_fwd_kernel<TT, KT_>), dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, (const TT *)y, score, residual, T, k, D, out)
+#define M3_CF_K(TT) do { if (k == 4) M3_CF(TT, 4); else if (k == 2) M3_CF(TT, 2); else if (k == 1) M3_CF(TT, 1); else if (k == 8) M3_CF(TT, 8); else M3_CF(TT, 0); } while (0)
+  if (dtype == M3_F16) M3_CF_K(half_t); else if (dtype == M3_BF16) M3_CF_K(bf16_t); else M3_CF_K(float);
+#undef M3_CF_K
+#undef M3_CF
   return check_launch("m3_combine_fwd");
 }
 
@@ -371,14 +443,11 @@ extern "C" int m3_combine_bwd(const float *dout, const void *y, int dtype, const
   M3_REQUIRE(D % 4 == 0 && D > 0 && k >= 1, "m3_combine_bwd: D must be a multiple of 4");
   if (T == 0) return M3_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == M3_F16)
-    hipLaunchKernelGGL(combine_bwd_kernel<half_t>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, dout,
-                       (const half_t *)y, score, T, k, D, (half_t *)dy, dscore);
-  else if (dtype == M3_BF16)     hipLaunchKernelGGL(combine_bwd_kernel<bf16_t>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, dout,
-                       (const bf16_t *)y, score, T, k, D, (bf16_t *)dy, dscore);
-  else
-    hipLaunchKernelGGL(combine_bwd_kernel<float>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, dout, (const float *)y,
-                       score, T, k, D, (float *)dy, dscore);
+#define M3_CB(TT, KT_) hipLaunchKernelGGL((combine_bwd_kernel<TT, KT_>), dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, dout, (const TT *)y, score, T, k, D, (TT *)dy, dscore)
+#define M3_CB_K(TT) do { if (k == 4) M3_CB(TT, 4); else if (k == 2) M3_CB(TT, 2); else if (k == 1) M3_CB(TT, 1); else if (k == 8) M3_CB(TT, 8); else M3_CB(TT, 0); } while (0)
+  if (dtype == M3_F16) M3_CB_K(half_t); else if (dtype == M3_BF16) M3_CB_K(bf16_t); else M3_CB_K(float);
+#undef M3_CB_K
+#undef M3_CB
   return check_launch("m3_combine_bwd");
 }
 
