@@ -174,7 +174,7 @@ static int ln_rows_per_wave() {
 // NCH = ceil(D / 256): 16-byte chunks per lane (registers are sized for the row width in use: D = 384 -> 2, not 4,
 // which takes the kernel from 116 to ~70 VGPRs and from 4 to 7 waves per SIMD)
 template <typename T, typename TA, int NCH, int LNB_WAVES>
-__global__ __launch_bounds__(LNB_WAVES * 64, 4) void layernorm_bwd_kernel(const T *__restrict__ dy, const float *__restrict__ x,
+__global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const T *__restrict__ dy, const float *__restrict__ x,
                                                                     const float *__restrict__ mean,
                                                                     const float *__restrict__ rstd,
                                                                     const float *__restrict__ gamma,
@@ -187,11 +187,15 @@ __global__ __launch_bounds__(LNB_WAVES * 64, 4) void layernorm_bwd_kernel(const 
   f32x4 dg[NCH], db[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) { dg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; db[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  // A row is a dependent chain: loads -> two wave reductions -> stores.  Two rows go through it side by side (their loads
-  // in flight together, their shuffle chains interleaved); the parameter-gradient sums still take the rows in row order.
-  auto load_row = [&](int64_t t, f32x4(&gdy)[NCH], f32x4(&xh)[NCH], float &s1, float &s2) {
+  // (two rows side by side - their loads in flight together, their shuffle chains interleaved - was measured in round 3:
+  // 41.2 us against 38.0 us for this loop at T = 25 216, D = 384: the second row's registers cost more occupancy than the
+  // overlap wins)
+  for (int r = 0; r < rpw; ++r) {
+    const int64_t t = ((int64_t)blockIdx.x * LNB_WAVES + wave) * rpw + r;
+    if (t >= T_) break;
     const float mu = mean[t], rs = rstd[t];
-    s1 = 0.f; s2 = 0.f;
+    f32x4 gdy[NCH], xh[NCH];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int d = lane * 4 + i * 256;
@@ -202,13 +206,11 @@ __global__ __launch_bounds__(LNB_WAVES * 64, 4) void layernorm_bwd_kernel(const 
         gdy[i] = dyv * g;
         s1 += gdy[i][0] + gdy[i][1] + gdy[i][2] + gdy[i][3];
         s2 += gdy[i][0] * xh[i][0] + gdy[i][1] * xh[i][1] + gdy[i][2] * xh[i][2] + gdy[i][3] * xh[i][3];
-        dg[i] += dyv * xh[i];                    // (rows enter the parameter-gradient sums in row order)
+        dg[i] += dyv * xh[i];
         db[i] += dyv;
       }
     }
-  };
-  auto finish_row = [&](int64_t t, const f32x4(&gdy)[NCH], const f32x4(&xh)[NCH], float m1, float m2) {
-    const float rs = rstd[t];
+    const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int d = lane * 4 + i * 256;
@@ -219,35 +221,6 @@ __global__ __launch_bounds__(LNB_WAVES * 64, 4) void layernorm_bwd_kernel(const 
         if (dx_act) Vec4<TA>::store(dx_act + t * D + d, o);   // activation-dtype copy for the next GEMMs
       }
     }
-  };
-  const int64_t tw = ((int64_t)blockIdx.x * LNB_WAVES + wave) * rpw;
-  const float inv_d = 1.0f / (float)D;
-  int r = 0;
-  constexpr bool PAIRS = NCH <= 2;               // (wider rows: two rows' registers do not fit 128 - one row at a time)
-  for (; PAIRS && r + 1 < rpw && tw + r + 1 < T_; r += 2) {
-    f32x4 gA[NCH], xA[NCH], gB[NCH], xB[NCH];
-    float a1, a2, b1, b2;
-    load_row(tw + r, gA, xA, a1, a2);
-    load_row(tw + r + 1, gB, xB, b1, b2);
-    // four independent reductions, step by step side by side
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64);
-      b1 += __shfl_xor(b1, o, 64); b2 += __shfl_xor(b2, o, 64);
-    }
-    finish_row(tw + r, gA, xA, a1 * inv_d, a2 * inv_d);
-    finish_row(tw + r + 1, gB, xB, b1 * inv_d, b2 * inv_d);
-  }
-  auto one_row = [&](int64_t t) {
-    f32x4 gA[NCH], xA[NCH];
-    float a1, a2;
-    load_row(t, gA, xA, a1, a2);
-    finish_row(t, gA, xA, wave_sum(a1) * inv_d, wave_sum(a2) * inv_d);
-  };
-  if constexpr (PAIRS) {
-    if (r < rpw && tw + r < T_) one_row(tw + r);                     // odd row at the end
-  } else {
-    for (; r < rpw && tw + r < T_; ++r) one_row(tw + r);
   }
   // block partials: waves in order
 #pragma unroll

@@ -1,5 +1,8 @@
 # Re-creates the measurement artifacts behind profiles/ on the GPU box (copy the summaries into profiles/ afterwards):
-#   tools/refresh_profiles.sh [<commit for the traffic file's "head" field>]
+#   tools/refresh_profiles.sh [<commit for the traffic files' "head" field>]
+# f16 (headline) AND f32 (train_fastmoe.py's arithmetic): bench lines, rocprofv3 --kernel-trace --stats summaries of the
+# two-stream default and of the serial (--serial-tasks --no-graph) step, and the FETCH_SIZE / WRITE_SIZE PMC passes
+# (separate runs, --kernel-trace only, program directly after `--`).
 set -e
 R=$GRAFT_REPO_ROOT
 HEAD=${1:-unknown}
@@ -11,14 +14,20 @@ B="--no-f32 --no-cpu-baseline"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof2 -o run -- python $R/bench.py --steps 8 --warmup 2 $B > $O/prof2.json 2> $O/prof2.err
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof1 -o run -- python $R/bench.py --steps 8 --warmup 2 $B --serial-tasks --no-graph > $O/prof1.json 2> $O/prof1.err
-mkdir -p $O/fetch $O/write
-timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o run -- python $R/bench.py --steps 2 --warmup 1 $B --serial-tasks --no-graph > $O/fetch.log 2>&1
-timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o run -- python $R/bench.py --steps 2 --warmup 1 $B --serial-tasks --no-graph > $O/write.log 2>&1
-python $R/tools/pmc_traffic.py $(find $O/fetch -name "*.db" | head -1) $(find $O/write -name "*.db" | head -1) --dtype f16 --head $HEAD \
-  --merge gemm_nt_all=gemm_nt_dma,gemm_nt > $O/pmc_traffic.json
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof1f32 -o run -- python $R/bench.py --dtype f32 --steps 4 --warmup 1 --no-cpu-baseline --serial-tasks --no-graph > $O/prof1_f32.json 2> $O/prof1_f32.err
 cp $(find $O/prof2 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_two_streams.csv
 cp $(find $O/prof1 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_serial.csv
-# the databases are large: keep only the summaries in what gpurun copies back
-rm -rf $O/fetch $O/write $O/prof1 $O/prof2
+cp $(find $O/prof1f32 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_serial_f32.csv
+python $R/tools/prof_by_launch.py $(find $O/prof1 -name "*kernel_trace.csv" | head -1) --steps 14 > $O/by_launch_shape_serial.txt
+rm -rf $O/prof1 $O/prof2 $O/prof1f32
+for DT in f16 f32; do
+  mkdir -p $O/fetch_$DT $O/write_$DT
+  timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch_$DT -o run -- python $R/bench.py --dtype $DT --steps 2 --warmup 1 $B --serial-tasks --no-graph > $O/fetch_$DT.log 2>&1
+  timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write_$DT -o run -- python $R/bench.py --dtype $DT --steps 2 --warmup 1 $B --serial-tasks --no-graph > $O/write_$DT.log 2>&1
+  python $R/tools/pmc_traffic.py $(find $O/fetch_$DT -name "*.db" | head -1) $(find $O/write_$DT -name "*.db" | head -1) --dtype $DT --head $HEAD \
+    --merge gemm_nt_all=gemm_nt_dma,gemm_nt > $O/pmc_traffic_$DT.json
+  # the databases are large: keep only the summaries in what gpurun copies back
+  rm -rf $O/fetch_$DT $O/write_$DT
+done
 ls -la $O
 echo refresh done

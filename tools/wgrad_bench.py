@@ -36,8 +36,9 @@ def timeit(fn):
 
 
 # (name, N, K, grouped)
+# (the experts of configs[1] are 384 -> 384 -> 384: moe_mlp_ratio 1)
 for name, N, K, grouped in (("qkv", 1152, 384, False), ("proj", 384, 384, False), ("fc1", 1536, 384, False),
-                            ("fc2", 384, 1536, False), ("expert fc1", 1536, 384, True), ("expert fc2", 384, 1536, True)):
+                            ("fc2", 384, 1536, False), ("expert fc1", 384, 384, True), ("expert fc2", 384, 385, True)):
     if a.only and name != a.only:
         continue
     if not grouped:
@@ -58,20 +59,22 @@ for name, N, K, grouped in (("qkv", 1152, 384, False), ("proj", 384, 384, False)
         idx = torch.stack([torch.randperm(E, generator=g)[:k] for _ in range(R // k)]).to(torch.int32).to(dev)
         r = ops.route_build(idx, E)
         rows = R
-        dCs = [torch.randn(R, N, device=dev).half() for _ in range(a.ring)]
-        if K == 384:
+        gather_c = K == 385                  # "expert fc2": dC rows gathered from the token gradient with the gate score
+        K = 384
+        if not gather_c:                     # expert FC1: A = token rows gathered through the routing, dC expert-major
+            dCs = [torch.randn(R, N, device=dev).half() for _ in range(a.ring)]
             As = [torch.randn(R // k, K, device=dev).half() for _ in range(a.ring)]
             kw = dict(a_row_idx=r.row_of_slot, a_row_div=k)
         else:
+            dCs = [torch.randn(R // k, N, device=dev).half() for _ in range(a.ring)]
             As = [torch.randn(R, K, device=dev).half() for _ in range(a.ring)]
-            kw = {}
+            kw = dict(c_row_idx=r.row_of_slot, c_row_div=k, c_row_scale=torch.rand(R // k, k, device=dev))
         dW = torch.zeros(E, N, K, device=dev)
         db = torch.zeros(E, N, device=dev)
         splits = a.splits or ops.default_wgrad_splits(R, N, K, E, torch.float16)
-        _, units = ops.wgrad_plan(R, E, splits, True)
-        ws = torch.empty(units * N * (K + 1), device=dev)
+        ws = torch.empty(ops.wgrad_ws_elems(R, N, K, E, grouped=True, dtype=torch.float16), device=dev)
         fn = lambda i: ops.wgrad_tn(dCs[i % a.ring], As[i % a.ring], dW, M=R, ws=ws, db=db, group_offsets=r.offsets, splits=splits, **kw)  # noqa: E731
-        slab = units * N * K * 4
+        slab = ws.numel() * 4
     us_res = timeit(lambda i: fn(0))
     us = timeit(fn)
     byts = rows * (N + K) * 2 + 2 * slab

@@ -13,8 +13,7 @@ x = torch.randn(T, K, device=dev).half()
 xR = torch.randn(R, K, device=dev).half()
 dW = torch.zeros(E, N, K, device=dev); db = torch.zeros(E, N, device=dev)
 splits = 1
-_, units = ops.wgrad_plan(R, E, splits, True)
-ws = torch.empty(units * N * (K + 1), device=dev)
+ws = torch.empty(ops.wgrad_ws_elems(R, N, K, E, grouped=True, dtype=torch.float16), device=dev)
 ident = torch.arange(R, dtype=torch.int32, device=dev)
 def t(fn, name):
     for _ in range(3): fn()
