@@ -16,6 +16,7 @@
 //         S = Q K^T, dP = dO V^T, P = exp(S - lse), dS = P (dP - delta);  dV^T += dO^T P,
 //         dK^T += Q^T dS;  dS^T goes to a double-buffered LDS image for dQ^T = K^T dS^T.
 #include "common.h"
+#include <type_traits>
 
 namespace m3 {
 
@@ -647,6 +648,10 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
 
   const float c1 = scale * AR_LOG2E, inv_c1 = 1.0f / c1;
   const int nsteps = (N + 31) >> 5;
+  // a full key block (every block but a sequence's last) runs without the per-tile guards: straight-line MFMA chains
+  // (a uniform run-time guard is a basic-block boundary the scheduler does not move MFMAs across)
+  auto run = [&](auto full_c) {
+  constexpr bool FULL = decltype(full_c)::value;
   for (int st = 0; st < nsteps; ++st) {
     const int qs = st * 32, buf = st & 1;
     const char *cQ = sQ + buf * 32 * RBY, *cdO = sdO + buf * 32 * RBY;
@@ -673,7 +678,7 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
 #pragma unroll
       for (int kt = 0; kt < KTW; ++kt) {
         const int tix = kt * NW + wave;
-        if (tix < nkt) {
+        if (FULL || tix < nkt) {
           f32x4 s = s0, dp = dp0;
 #pragma unroll
           for (int ch = 0; ch < NCH; ++ch) {
@@ -683,7 +688,7 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
           f32x4 pv;
 #pragma unroll
           for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r] * c1);
-          if (tix == nkt - 1 && tix * 16 + li >= nkeys) pv = zero4;      // keys past N live in the last tile only
+          if (!FULL && tix == nkt - 1 && tix * 16 + li >= nkeys) pv = zero4;      // keys past N live in the last tile only
           pt[qt][kt] = pv;
 #pragma unroll
           for (int r = 0; r < 4; ++r) dst[qt][kt][r] = pv[r] * dp[r];
@@ -704,7 +709,7 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
       }
 #pragma unroll
       for (int kt = 0; kt < KTW; ++kt) {
-        if (kt * NW + wave < nkt) {
+        if (FULL || kt * NW + wave < nkt) {
           f32x4 tp[2] = {pt[0][kt], pt[1][kt]}, td[2] = {dst[0][kt], dst[1][kt]};
           const typename Mma<T>::frag pf = Mma<T>::from_tiles(tp), dsf = Mma<T>::from_tiles(td);
 #pragma unroll
@@ -730,18 +735,20 @@ __global__ __launch_bounds__(DH == 32 ? 256 : 512, DH == 32 ? 2 : 1) void attent
       typename Mma<T>::frag ka[AR_MAXN / 32], da[AR_MAXN / 32];
 #pragma unroll
       for (int c = 0; c < AR_MAXN / 32; ++c) {
-        const int cc = c < nkc ? c : nkc - 1;
+        const int cc = (FULL || c < nkc) ? c : nkc - 1;
         ka[c] = tr_frag<T, DH>(sK, cc * 32, dt * 16, li, lg);
         da[c] = tr_frag<T, 32>(dsb, cc * 32, qt * 16, li, lg);
       }
       f32x4 acc = zero4;
 #pragma unroll
       for (int c = 0; c < AR_MAXN / 32; ++c)
-        if (c < nkc) acc = Mma<T>::mma(ka[c], da[c], acc);
+        if (FULL || c < nkc) acc = Mma<T>::mma(ka[c], da[c], acc);
       const int qr = qs + qt * 16 + li;
       if (qr < N) *(f32x4 *)(dqw + (int64_t)qr * DH + dt * 16 + 4 * lg) = acc * scale;
     }
   }
+  };
+  if (nkeys == KB) run(std::true_type{}); else run(std::false_type{});
 
   // ---- dK, dV rows of this wave's keys
 #pragma unroll

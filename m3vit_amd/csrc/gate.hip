@@ -41,7 +41,8 @@ struct GateFwdDev {
 };
 
 // EW = experts per wave, NW = EPAD / EW waves per workgroup
-template <typename T, int EPAD, int EW, bool EXACT>
+// NS > 0: the row is exactly NS steps long and is fetched whole up front; NS = 0: any D, one step in flight
+template <typename T, int EPAD, int EW, bool EXACT, int NS>
 __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const GateFwdDev p) {
   constexpr int NW = EPAD / EW;
   constexpr int NT = GATE_TOK * NW;
@@ -71,9 +72,7 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
   for (int e = 0; e < EW; ++e) acc[e] = (p.bias && (EXACT || e0 + e < E)) ? p.bias[e0 + e] : 0.f;
 
   // staging: chunk q = tid + NT*i -> row q / CPR, c = q % CPR; rows past T and bytes past D read as zero
-  u32x4 pre[NCH];
-  float prew[NWE];
-  auto fetch = [&](int step) {
+  auto fetch_w = [&](int step, float (&prew)[NWE]) {
 #pragma unroll
     for (int i = 0; i < NWE; ++i) {
       const int q = tid + NT * i;                  // element (dd, e) of the slice
@@ -81,6 +80,8 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
       const int d = step * DC + dd;
       prew[i] = (q < DC * EPAD && d < D && e < E) ? p.w[(int64_t)d * E + e] : 0.f;
     }
+  };
+  auto fetch_x = [&](int step, u32x4 (&pre)[NCH]) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int q = tid + NT * i;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
       pre[i] = (tr < T_ && cb < dbytes) ? *(const u32x4 *)(p.x + tr * p.ldx_b + cb) : u32x4{0u, 0u, 0u, 0u};
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, const u32x4 (&pre)[NCH], const float (&prew)[NWE]) {
 #pragma unroll
     for (int i = 0; i < NWE; ++i) {
       const int q = tid + NT * i;
@@ -113,24 +114,47 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
       }
     }
   };
-
-  fetch(0);
-  for (int step = 0; step < nsteps; ++step) {
-    const int buf = step & 1;
-    stash(buf);
-    __syncthreads();            // one barrier per step: the other buffer is only rewritten after the next one
-    if (step + 1 < nsteps) fetch(step + 1);
+  // the step's w_gate rows come from LDS (all lanes read the same address: broadcast), x from the
+  // lane's own LDS row; per logit the fma chain runs over d in order, as the oracle's
+  auto compute = [&](int buf, int dn) {
     const float *xs = &sx[buf][lane * LDS_STRIDE];
-    const int d0 = step * DC;
-    const int dn = (D - d0 < DC) ? (D - d0) : DC;
-    // the step's w_gate rows come from LDS (all lanes read the same address: broadcast), x from the
-    // lane's own LDS row; per logit the fma chain runs over d in order, as the oracle's
     const float *ws = &sw[buf][e0];
 #pragma unroll 8
     for (int dd = 0; dd < dn; ++dd) {
       const float xv = xs[dd];
 #pragma unroll
       for (int e = 0; e < EW; ++e) acc[e] = __builtin_fmaf(xv, ws[dd * EPAD + e], acc[e]);
+    }
+  };
+
+  if constexpr (NS > 0) {
+    // rows of exactly NS steps (host-checked): every load of the workgroup's rows is issued before the first use, so
+    // the HBM latency is paid once and not once per step (the ring below pays it nsteps times: with about 1.5
+    // workgroups per CU at T = 25k there is nothing else resident to hide it behind)
+    u32x4 px[NS][NCH];
+    float pw[NS][NWE];
+#pragma unroll
+    for (int st = 0; st < NS; ++st) fetch_x(st, px[st]);
+#pragma unroll
+    for (int st = 0; st < NS; ++st) fetch_w(st, pw[st]);
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      stash(st & 1, px[st], pw[st]);
+      __syncthreads();          // one barrier per step: the other buffer is only rewritten after the next one
+      compute(st & 1, DC);
+    }
+  } else {
+    u32x4 pre[NCH];
+    float prew[NWE];
+    fetch_w(0, prew);
+    fetch_x(0, pre);
+    for (int step = 0; step < nsteps; ++step) {
+      const int buf = step & 1;
+      stash(buf, pre, prew);
+      __syncthreads();            // one barrier per step: the other buffer is only rewritten after the next one
+      if (step + 1 < nsteps) { fetch_w(step + 1, prew); fetch_x(step + 1, pre); }
+      const int d0 = step * DC;
+      compute(buf, (D - d0 < DC) ? (D - d0) : DC);
     }
   }
 
@@ -487,8 +511,11 @@ extern "C" int m3_gate_dw_blocks(int64_t T) { return (int)((T + GATE_DW_TOK - 1)
 template <typename T, int EP, int EW>
 static void launch_gate_fwd_e(bool exact, dim3 grid, hipStream_t s, const GateFwdDev &d) {
   constexpr int NT = GATE_TOK * (EP / EW);
-  if (exact) hipLaunchKernelGGL((gate_fwd_kernel<T, EP, EW, true>), grid, dim3(NT), 0, s, d);
-  else hipLaunchKernelGGL((gate_fwd_kernel<T, EP, EW, false>), grid, dim3(NT), 0, s, d);
+  const int rowb = d.D * (int)sizeof(T);
+  if (exact && rowb == 6 * GATE_ROWB) hipLaunchKernelGGL((gate_fwd_kernel<T, EP, EW, true, 6>), grid, dim3(NT), 0, s, d);
+  else if (exact && rowb == 12 * GATE_ROWB) hipLaunchKernelGGL((gate_fwd_kernel<T, EP, EW, true, 12>), grid, dim3(NT), 0, s, d);
+  else if (exact) hipLaunchKernelGGL((gate_fwd_kernel<T, EP, EW, true, 0>), grid, dim3(NT), 0, s, d);
+  else hipLaunchKernelGGL((gate_fwd_kernel<T, EP, EW, false, 0>), grid, dim3(NT), 0, s, d);
 }
 
 template <typename T>
