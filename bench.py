@@ -57,6 +57,8 @@ def parse():
                     "the hipGraph; with the default concurrent task streams the nested fork cannot be captured (ROCm 7.2 "
                     "faults in hipStreamEndCapture: tools/nested_capture_probe.py) and the step runs eagerly "
                     "(config.capture_refused says so); off under expert parallelism")
+    ap.add_argument("--share-stem", action="store_true", help="compute the task-independent stem (patch embedding + the blocks "
+                    "below the first MoE block) once per step for all task passes (MultiTaskStep share_stem)")
     ap.add_argument("--ep", action="store_true", help="N > 1: time ONLY the expert-parallel form (experts sharded over the "
                     "ranks, all-to-all over RCCL); default: expert parallel (primary, when E %% N == 0) AND data parallel")
     ap.add_argument("--dp-only", action="store_true", help="N > 1: time only the replicated-experts data-parallel form")
@@ -192,7 +194,7 @@ def main():
     # the library that really moves the bytes: backend "nccl" is RCCL on ROCm; gloo only in CPU-side rehearsals
     coll = {"nccl": "RCCL"}.get(backend, backend)
 
-    def run_mode(dtype_name, expert_parallel, want_roofline):
+    def run_mode(dtype_name, expert_parallel, want_roofline, share_stem=False):
         """One timed configuration: W untimed warm-up steps, exactly K timed steps between barriers, max over ranks.
         Returns the fields of the JSON line that depend on the mode."""
         cfg = BackboneConfig(**VIT_SMALL_MOE)
@@ -204,7 +206,7 @@ def main():
         runner = MultiTaskStep(cfg, params, batch=args.batch, dtype=dtype, device=str(dev), cv_weight=CV_WEIGHT,
                                parallel_tasks=not args.serial_tasks, graph=not args.no_graph, world=world, rank=rank,
                                expert_parallel=expert_parallel, wgrad_streams=args.wgrad_streams, dp_parts=args.dp_parts,
-                               checkpoint=args.checkpoint)
+                               checkpoint=args.checkpoint, share_stem=share_stem)
         use_ep, par_tasks, ntasks = runner.use_ep, runner.par or runner.par_ep, len(runner.tasks)
         g = torch.Generator().manual_seed(1000 + rank)          # each rank its own images
         images = torch.randn(args.batch, 3, *cfg.img_size, generator=g).to(dev)
@@ -255,7 +257,7 @@ def main():
                "wgrad_streams": sum(1 for e in runner.engs if e.wg_stream is not None),
                "capture_refused": runner.capture_refused,
                "task_passes": ntasks, "tokens_per_image": cfg.num_tokens,
-               "activation_checkpointing": bool(args.checkpoint),
+               "activation_checkpointing": bool(args.checkpoint), "shared_stem": bool(runner.share_stem),
                "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                "parallelism": "single" if world == 1 else (f"dp{world}+ep{world} (experts sharded, {coll} all-to-all + all-reduce)"
                                                             if use_ep else f"dp{world} (replicated experts, {coll} all-reduce)")}
@@ -413,7 +415,7 @@ def main():
 
     main_res = None
     if world == 1:
-        main_res = run_mode(args.dtype, False, True)
+        main_res = run_mode(args.dtype, False, True, share_stem=args.share_stem)
         if args.dtype == "f16" and not args.no_f32:
             f32 = attempt("f32", lambda: run_mode("f32", False, True))
             if f32 is not None:

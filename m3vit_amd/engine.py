@@ -119,6 +119,12 @@ class BackboneEngine:
         """first block of the 'upper half' (its gradients occupy flat_grads[:n_upper])"""
         return self.cfg.depth // 2
 
+    @property
+    def stem_blocks(self):
+        """number of leading blocks before the first MoE block: together with the patch embedding they see neither the
+        task id nor the gate, so every task pass of a step computes the same values there (MultiTaskStep share_stem)"""
+        return next((i for i in range(self.depth) if self.is_moe[i]), self.depth)
+
     @staticmethod
     def _block_of(name: str) -> int:
         return int(name.split(".")[1]) if name.startswith("blocks.") else -1
@@ -397,7 +403,8 @@ class BackboneEngine:
             ops.combine_fwd(a["y"], a["score_s"] if sm is not None else g["score"], a["x1"], a["x2"])
         return a["x2"]
 
-    def forward(self, images: torch.Tensor, task_id: Optional[int], tsf_bias=None, noises=None, path_scales=None):
+    def forward(self, images: torch.Tensor, task_id: Optional[int], tsf_bias=None, noises=None, path_scales=None,
+                stem_of: "BackboneEngine" = None):
         """Returns (tokens fp32 [B,N,D], total_cv_loss).  noises: {block: [T,E]} caller-supplied N(0,1).
         Task-conditioned configs compute the per-block logit bias tsf @ w_gate[D:] here (tsf_bias overrides
         it with a caller-supplied {block: [E]} and then no gradient flows to the task embedding).
@@ -405,28 +412,47 @@ class BackboneEngine:
         branches (stochastic depth, vision_transformer_moe.py:167-185: floor(keep + U) / keep, drawn by the caller -
         pretrain/configs/deit_moe_small.yaml:51 trains with drop_path > 0); the factor rides on the epilogue of the
         GEMM that closes the branch (proj, fc2) or on the combine scores (MoE), and on the gradient entering the
-        branch in backward."""
-        x = self.forward_begin(images, task_id, tsf_bias=tsf_bias, noises=noises, path_scales=path_scales)
-        for i in range(self.depth):
+        branch in backward.
+        stem_of: an engine (this one or another of the same step) whose forward_stem() already holds the patch embedding
+        and the blocks below the first MoE block for THESE images; this pass starts at the first MoE block from that
+        output and its backward stops there (backward_blocks(depth - 1, stem_blocks); the caller adds the passes'
+        d x and runs the stem's backward once - MultiTaskStep)."""
+        x = self.forward_begin(images, task_id, tsf_bias=tsf_bias, noises=noises, path_scales=path_scales, stem_of=stem_of)
+        for i in range(self.stem_blocks if stem_of is not None else 0, self.depth):
             x = self._block_forward(i, x, self.cv_acc)
         return self.forward_end(x)
+
+    def forward_stem(self, images: torch.Tensor):
+        """patch embedding, cls / pos and the blocks below the first MoE block (task-independent: no gate, no task id;
+        the reference's DropPath schedule gives block 0 rate 0, vision_transformer_moe.py:761).  Returns their output."""
+        self._fwd_ctx = (None, None, None, None)
+        x = self._embed(images)
+        for i in range(self.stem_blocks):
+            x = self._block_forward(i, x, None)
+        return x
+
+    def _embed(self, images):
+        ops.im2row(images, self.P, self.rows)
+        ops.gemm_nt(self.rows, self.wc["patch_embed.proj"], self.patch, bias=self.params["patch_embed.proj.bias"])
+        ops.assemble_tokens(self.patch, self.params["cls_token"], self.params["pos_embed"], self.B, self.np_, self.D, self.x0)
+        return self.x0
 
     # The forward in resumable pieces (patch embedding / one block at a time / result), so that a step runner can
     # interleave the blocks of several task passes on the host (expert parallelism: while one pass waits for its
     # exchange's split sizes, the other pass's queued kernels keep the GPU busy).
-    def forward_begin(self, images: torch.Tensor, task_id: Optional[int], tsf_bias=None, noises=None, path_scales=None):
-        P_, p = self.P, self.params
-        B, D = self.B, self.D
+    def forward_begin(self, images: torch.Tensor, task_id: Optional[int], tsf_bias=None, noises=None, path_scales=None,
+                      stem_of: "BackboneEngine" = None):
         self._tsf = None
         if self.task_cond and tsf_bias is None and task_id is not None:
             tsf_bias = self._task_feature(task_id)
-        ops.im2row(images, P_, self.rows)
-        ops.gemm_nt(self.rows, self.wc["patch_embed.proj"], self.patch, bias=p["patch_embed.proj.bias"])
-        ops.assemble_tokens(self.patch, p["cls_token"], p["pos_embed"], B, self.np_, D, self.x0)
         self.cv_acc.zero_()
         self.task_id = task_id
         self._fwd_ctx = (task_id, tsf_bias, noises, path_scales)
-        return self.x0
+        if stem_of is None:
+            return self._embed(images)
+        s = self.stem_blocks
+        assert path_scales is None or all(path_scales.get(i) is None for i in range(s)), "a shared stem takes no DropPath draw"
+        return stem_of.act[s - 1]["x2"] if s > 0 else stem_of.x0
 
     def forward_end(self, x):
         # total cv_loss = sum over MoE blocks of cv^2(importance) + cv^2(load)  (vision_transformer_moe.py:453-459,540)
@@ -702,9 +728,10 @@ class BackboneEngine:
                               dx_act=self.s_dx_t if nxt_dx_t else None)
             dx, other = other, dx
             have_dx_t = nxt_dx_t
-        # the last weight-gradient call's slabs (a data-parallel step all-reduces these blocks' slice next)
+        # the last weight-gradient call's slabs (a data-parallel step all-reduces these blocks' slice next); on the stream
+        # the weight-gradient launches went to
         if self.wq is not None:
-            self.wq.flush()
+            self._fork((), self.wq.flush)
         # norm weight / bias gradients of the blocks just done, all in one launch (their partial slots are contiguous)
         if hi >= lo:
             ops.layernorm_bwd_reduce(self.ws_ln, self.ln_nblk, self.D, self.ln_table, 2 * lo, 2 * (hi - lo + 1), beta=1)
@@ -714,17 +741,27 @@ class BackboneEngine:
         """make the current stream wait for the weight-gradient launches issued so far (no-op without a wgrad stream)"""
         self._join_wgrad()
 
-    def backward_end(self):
+    def accept_dx(self, others):
+        """shared stem: add the other task passes' gradient at the stem's output to this pass's; the stem's backward
+        then runs once on the sum (it is linear in d x)."""
+        st = self._bw
+        for o in others:
+            ops.add_f32(st["dx"].view(-1), o._bw["dx"].view(-1))
+        st["have_dx_t"] = False                       # the activation-dtype copy was this pass's d x alone
+
+    def backward_end(self, stem: bool = True):
+        """stem=False: a pass that started from another engine's stem - nothing below its first block is its own"""
         p, gr = self.params, self.grads
         B, D = self.B, self.D
         dx = self._bw["dx"]
-        # patch embedding / cls / pos
-        ops.tokens_bwd(dx, B, self.np_, D, self.s_dpatch, gr["pos_embed"].view(self.N, D), gr["cls_token"].view(D), beta=1)
-        gw = gr["patch_embed.proj.weight"].view(D, -1)
-        self._fork((), lambda: ops.wgrad_tn(self.s_dpatch, self.rows, gw, beta=1, ws=self.ws_wgrad, queue=self.wq,
-                                            db=gr["patch_embed.proj.bias"]))
+        if stem:
+            # patch embedding / cls / pos
+            ops.tokens_bwd(dx, B, self.np_, D, self.s_dpatch, gr["pos_embed"].view(self.N, D), gr["cls_token"].view(D), beta=1)
+            gw = gr["patch_embed.proj.weight"].view(D, -1)
+            self._fork((), lambda: ops.wgrad_tn(self.s_dpatch, self.rows, gw, beta=1, ws=self.ws_wgrad, queue=self.wq,
+                                                db=gr["patch_embed.proj.bias"]))
         if self.wq is not None:
-            self.wq.flush()
+            self._fork((), self.wq.flush)
         self._join_wgrad()
         if self._tsf is not None:
             self._task_feature_bwd(self._bw.get("d_tsf"))

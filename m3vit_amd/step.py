@@ -27,7 +27,7 @@ from .engine import BackboneEngine
 class MultiTaskStep:
     def __init__(self, cfg, params, batch: int, dtype=torch.float16, device="cuda:0", tasks=None, cv_weight: float = 0.01,
                  parallel_tasks: bool = True, graph: bool = True, world: int = 1, rank: int = 0, expert_parallel: bool = False,
-                 wgrad_streams: bool = False, dp_parts: int = 6, checkpoint: bool = False):
+                 wgrad_streams: bool = False, dp_parts: int = 6, checkpoint: bool = False, share_stem: bool = False):
         self.cfg, self.dev, self.world, self.cv_weight = cfg, torch.device(device), int(world), float(cv_weight)
         if tasks is None:
             tasks = list(range(cfg.num_tasks)) if (cfg.multi_gate or cfg.gate_task_specific_dim >= 0) else [None]
@@ -59,6 +59,18 @@ class MultiTaskStep:
         ends = [self.eng.grad_prefix(lo) for lo in cuts] + [self.flat.numel()]
         self.segments = list(zip([0] + ends[:-1], ends))
         self.two_parts = nparts > 1
+        # share_stem: the patch embedding and the blocks below the first MoE block see neither task id nor gate, and every
+        # pass of the step reads the same images (train/train_utils.py:248-256: model(images, single_task=...) per task), so
+        # their forward is computed once (pass 0's context, before the streams fork) and their backward once, on the sum of
+        # the passes' d x at the first MoE block's input (after the streams join) - the same gradients with one stem
+        # forward + backward instead of one per task.  Side-by-side passes without expert parallelism only.
+        self.share_stem = bool(share_stem) and self.par
+        self.stem = self.eng.stem_blocks if self.share_stem else 0
+        self.add_stream = torch.cuda.Stream(device=self.dev) if self.share_stem else None
+        self.late_names = [n for n in self.eng.params if self.eng._block_of(n) < 0 and
+                           not n.startswith(("patch_embed.", "cls_token", "pos_embed"))]
+        # the part whose block range first reaches below the stem boundary takes the other passes' d x
+        self.accept_part = next((j for j, (_, lo) in enumerate(self.block_ranges) if lo < self.stem), len(self.block_ranges) - 1)
         # hipGraph capture: expert-parallel steps read split sizes on the host (eager).  Weight-gradient streams capture
         # fine when forked from the capturing stream itself (tools/wgrad_capture_probe.py: capture + replay bit-exact),
         # but forked from a stream that is ITSELF a fork of the capturing stream (task streams x wgrad streams: a nested
@@ -100,7 +112,8 @@ class MultiTaskStep:
             ops.add_f32(self.flat[lo:hi], e.flat_grads[lo:hi])          # flat += gradients of the other passes
 
     def _forward(self, e, t):
-        e.forward(self.images, t, tsf_bias=self.logit_bias, noises=None if self.noises is None else self.noises.get(t))
+        e.forward(self.images, t, tsf_bias=self.logit_bias, noises=None if self.noises is None else self.noises.get(t),
+                  stem_of=self.eng if self.share_stem else None)
 
     def _full(self, e, t):
         self._forward(e, t)
@@ -109,18 +122,40 @@ class MultiTaskStep:
     def _part(self, j):
         hi, lo = self.block_ranges[j]
         last = j == len(self.block_ranges) - 1
+        share = self.share_stem
+        top_lo = max(lo, self.stem)                     # shared stem: the passes' own backward stops at the first MoE block
 
         def fn(e, t):
+            mine = not share or e is self.eng           # does this pass own a stem?
             if j == 0:
-                e.zero_grad()
+                if not (share and e is self.eng):       # (pass 0 zeroed its gradients before its stem forward)
+                    e.zero_grad()
                 self._forward(e, t)
                 e.backward_begin(self.dtok, cv_weight=self.cv_weight)
-            e.backward_blocks(hi, lo)
-            if last:
+            if hi >= top_lo:
+                e.backward_blocks(hi, top_lo)
+            if last and not share:
                 e.backward_end()
+            elif last and not mine:
+                e.backward_end(stem=False)
             else:
                 e.backward_sync_wgrad()
         return fn
+
+    def _stem_backward(self, j):
+        """shared stem, after the passes of part j joined on the current stream: the stem blocks of this part's range (and,
+        in the last part, the embeddings) once, on the sum of the passes' d x.  (Sending this single pass's weight-gradient
+        GEMMs to the idle task stream was measured and dropped: 17.10 -> 17.22 ms/step, profiles/r03_shared_stem.txt.)"""
+        hi, lo = self.block_ranges[j]
+        e = self.eng
+        if j == self.accept_part:
+            e.accept_dx(self.engs[1:])
+        if lo < self.stem:
+            e.backward_blocks(min(hi, self.stem - 1), lo)
+        if j == len(self.block_ranges) - 1:
+            e.backward_end()
+        else:
+            e.backward_sync_wgrad()
 
     def serial_step(self):
         """the whole step on the current stream with one engine context (reference order)"""
@@ -171,8 +206,30 @@ class MultiTaskStep:
             return self.serial_step()
         if j == 0:
             self.eng.prepare_weights()
+            if self.share_stem:
+                self.eng.zero_grad()
+                self.eng.forward_stem(self.images)
         self._run_tasks(self._part(j))
-        self._add(*self.segments[j])
+        if not self.share_stem:
+            self._add(*self.segments[j])
+            return
+        # the other passes' gradients of this part (final now; none of them below the stem boundary - those contexts never
+        # ran a stem, their slices there are zero) are added on a side stream while the stem's backward runs
+        lo, hi = self.segments[j]
+        cut = min(hi, max(lo, self.eng.grad_prefix(self.stem)))
+        main = torch.cuda.current_stream()
+        self.add_stream.wait_stream(main)
+        with torch.cuda.stream(self.add_stream):
+            if cut > lo:
+                self._add(lo, cut)
+        self._stem_backward(j)
+        if j == len(self.block_ranges) - 1:
+            # parameters outside the blocks that are NOT part of the stem (the task-embedding MLP of a task-conditioned gate):
+            # every pass has its own (small) gradient there; pass 0's was completed by the backward_end() just above
+            for n in self.late_names:
+                for e in self.engs[1:]:
+                    ops.add_f32(self.eng.grads[n].view(-1), e.grads[n].view(-1))
+        main.wait_stream(self.add_stream)
 
     def compute(self):
         for j in range(len(self.block_ranges)):

@@ -399,6 +399,73 @@ def test_multitask_step_runner_graph_and_streams_match_serial():
     assert rel(run2.flat, want2) < 1e-5
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.float16, 4e-3)])
+def test_shared_stem_step_matches_per_task_stems(dtype, tol):
+    """MultiTaskStep(share_stem=True): patch embedding + the blocks below the first MoE block are task-independent and
+    every pass reads the same images (train/train_utils.py:248-256), so their forward runs once and their backward once
+    on the summed d x.  Gradients must equal the one-full-pass-per-task step (fp32: up to summation order; fp16: the
+    stem's GEMMs see the rounded SUM of the passes' d x instead of each pass's rounded d x) - eagerly, replayed from a
+    hipGraph, cut into data-parallel parts (every slice final when its part returns), in checkpoint mode, and with a
+    task-conditioned gate.  The per-pass parameters above the stem must not change at all."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.distributed as dist
+    from m3vit_amd.step import MultiTaskStep
+    from oracle import ref_torch as R
+    torch.manual_seed(12)
+    img = torch.randn(4, 3, 64, 64).cuda()
+    for kw in (dict(gate_dim=67, multi_gate=True), dict(gate_dim=67, multi_gate=False, gate_task_specific_dim=16)):
+        cfg = R.BackboneCfg(img_size=(64, 64), embed_dim=64, depth=4, num_heads=2, mlp_ratio=4.0, moe_mlp_ratio=1.0,
+                            moe_experts=8, moe_top_k=2, **kw)
+        P = R.init_backbone_params(cfg, seed=6)
+        dtok = (torch.randn(4, cfg.num_tokens, 64) * 0.1).cuda()
+        ref = MultiTaskStep(cfg, P, batch=4, dtype=dtype, cv_weight=0.01)
+        ref.bind(img, dtok); ref.serial_step(); torch.cuda.synchronize()
+        assert ref.eng.stem_blocks == 1 and not ref.share_stem
+
+        def check(run, scale=1.0, tag=""):
+            for n, g in run.eng.grads.items():
+                want = ref.eng.grads[n] * scale
+                stem = n.startswith(("blocks.0.", "patch_embed", "cls_token", "pos_embed"))
+                assert rel(g, want) < (tol if stem else 1e-5), (tag, n)
+
+        run = MultiTaskStep(cfg, P, batch=4, dtype=dtype, cv_weight=0.01, share_stem=True)
+        assert run.share_stem and run.stem == 1 and len(run.engs) == 3
+        run.bind(img, dtok)
+        run.step(); torch.cuda.synchronize()
+        check(run, tag="eager")
+        # the other passes' contexts never ran a stem: their stem gradients stay zero
+        assert all(float(e.grads["blocks.0.attn.qkv.weight"].abs().max()) == 0 for e in run.engs[1:])
+        assert run.capture() and run.launch == "hipGraph replay"
+        for _ in range(2):
+            run.flat.fill_(5.0); run.step(); torch.cuda.synchronize()
+            check(run, tag="graph")
+        ck = MultiTaskStep(cfg, P, batch=4, dtype=dtype, cv_weight=0.01, share_stem=True, checkpoint=True)
+        ck.bind(img, dtok); ck.step(); torch.cuda.synchronize()
+        check(ck, tag="checkpoint")
+        own_group = not dist.is_initialized()
+        if own_group:
+            dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29579", rank=0, world_size=1)
+        try:
+            for parts in (2, 4):
+                dp = MultiTaskStep(cfg, P, batch=4, dtype=dtype, cv_weight=0.01, world=2, dp_parts=parts, share_stem=True)
+                dp.bind(img, dtok)
+                snap = []
+                for j in range(parts):
+                    dp.part(j); torch.cuda.synchronize()
+                    lo, hi = dp.segments[j]
+                    snap.append(dp.flat[lo:hi].clone())
+                for j, (lo, hi) in enumerate(dp.segments):
+                    assert torch.equal(dp.flat[lo:hi], snap[j]), (parts, j, "slice changed after its part returned")
+                check(dp, tag=f"parts {parts} by hand")
+                assert dp.capture() and len(dp.graphs) == parts
+                dp.flat.fill_(3.0); dp.step(); torch.cuda.synchronize()
+                check(dp, scale=0.5, tag=f"parts {parts} graph")
+        finally:
+            if own_group:
+                dist.destroy_process_group()
+
+
 def test_wgrad_streams_are_captured_into_the_graph():
     """BackboneEngine(wgrad_stream=True) forks the weight-gradient GEMMs onto a second stream by an event recorded on
     the capturing stream and joins them back with wait_stream: that pattern captures into a hipGraph and replays
