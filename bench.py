@@ -364,6 +364,7 @@ def main():
                        "task_streams": main_res["task_streams"], "wgrad_streams": main_res["wgrad_streams"],
                        "capture_refused": main_res["capture_refused"],
                        "activation_checkpointing": main_res["activation_checkpointing"],
+                       "shared_stem": main_res["shared_stem"],
                        "peak_hbm_gib": main_res["peak_hbm_gib"],
                        "parallelism": main_res["parallelism"]},
             "model_tflops": main_res["model_tflops"],
@@ -416,6 +417,15 @@ def main():
     main_res = None
     if world == 1:
         main_res = run_mode(args.dtype, False, True, share_stem=args.share_stem)
+        if not args.share_stem and not args.serial_tasks:
+            # the same step with the task-independent stem computed once for both passes (m3vit_amd/step.py share_stem):
+            # identical gradients, one block forward + backward and one patch embedding fewer than the reference's
+            # one-full-pass-per-task schedule.  Reported beside the headline, never as it: `value` keeps the reference's schedule.
+            st = attempt("shared_stem", lambda: run_mode(args.dtype, False, False, share_stem=True))
+            if st is not None:
+                extra["shared_stem"] = {"value": st["value"], "ms_per_step": st["ms_per_step"], "launch": st["launch"],
+                                        "note": "patch embedding + block 0 run once per step for both task passes, their backward "
+                                                "once on the summed d x (tests/test_engine.py::test_shared_stem_step_matches_per_task_stems)"}
         if args.dtype == "f16" and not args.no_f32:
             f32 = attempt("f32", lambda: run_mode("f32", False, True))
             if f32 is not None:
@@ -429,7 +439,7 @@ def main():
         # data parallel first: it needs one collective (all-reduce) and its line must survive whatever the expert-parallel
         # leg (count all-to-all + uneven all-to-all-v on several streams) does at its first contact with RCCL
         if want_dp:
-            results[False] = attempt("dp", lambda: run_mode(args.dtype, False, False))
+            results[False] = attempt("dp", lambda: run_mode(args.dtype, False, False, share_stem=args.share_stem))
             if results[False] is not None:
                 extra["dp"] = {k: results[False][k] for k in sub}
         if want_ep:

@@ -300,6 +300,13 @@ int m3_combine_fwd(const void *y, int dtype, const float *score, const float *re
  * m3_gemm_args.row_scale_idx / m3_wgrad_args.c_row_scale instead of reading a materialised dy. */
 int m3_combine_bwd(const float *dout, const void *y, int dtype, const float *score,
                    int64_t T, int k, int D, void *dy, float *dscore, void *stream);
+/* Input gradient at an MoE layer's branch point, in one pass:
+ *   dh[t,:] = sum_j dxe[t*k+j,:]  +  d_logits[t,:] @ w_gate[:D,:]^T
+ * the gather-sum of the k routed copies (MOEScatter.backward behind custom_moe_layer.py:254-259) and the gate's share
+ * (backward of `inp @ w_gate`, noisy_gate_vmoe.py:91).  dxe [T*k, D] act dtype (token major), d_logits fp32 [T, E],
+ * w_gate fp32 [D, E] (row-major, the parameter's own layout; E*D*4 bytes must fit 64 KB of LDS), dh fp32 [T, D]. */
+int m3_combine_gate_bwd(const void *dxe, int dtype, int64_t T, int k, int D, const float *d_logits,
+                        const float *w_gate, int E, float *dh, void *stream);
 
 /* Row movement of fastmoe's MOEScatter / MOEGather (custom_moe_layer.py:14,263-265) for
  * callers that run an arbitrary expert_fn between them (the fused path does not need it):

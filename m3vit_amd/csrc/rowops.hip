@@ -184,9 +184,20 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const T *
   extern __shared__ float sred[];   // [LNB_WAVES][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nblk = gridDim.x;
-  f32x4 dg[NCH], db[NCH];
+  f32x4 dg[NCH], db[NCH], gam[NCH];
+  // lanes past D in the last 256-column chunk read column 0 again, contribute zeros and never store: every load of a row is
+  // unconditional and issued before the first use.  (A load under `if (d < D)` is its own basic block with its own wait: the
+  // row's chunks, and the residual behind them, then cost one memory latency EACH - four per row at D = 384 - and a wave's
+  // rows run one after the other.)
+  bool on[NCH];
+  int col[NCH];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) { dg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; db[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int i = 0; i < NCH; ++i) {
+    on[i] = lane * 4 + i * 256 < D;
+    col[i] = on[i] ? lane * 4 + i * 256 : 0;
+    dg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gam[i] = *(const f32x4 *)(gamma + col[i]);
+  }
   // (two rows side by side - their loads in flight together, their shuffle chains interleaved - was measured in round 3:
   // 41.2 us against 38.0 us for this loop at T = 25 216, D = 384: the second row's registers cost more occupancy than the
   // overlap wins)
@@ -194,31 +205,41 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const T *
     const int64_t t = ((int64_t)blockIdx.x * LNB_WAVES + wave) * rpw + r;
     if (t >= T_) break;
     const float mu = mean[t], rs = rstd[t];
+    typename Vec4<T>::type dyr[NCH];
+    f32x4 xr[NCH], rr[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      dyr[i] = *(const typename Vec4<T>::type *)(dy + t * D + col[i]);
+      xr[i] = *(const f32x4 *)(x + t * D + col[i]);
+    }
+    if (dx_res) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) rr[i] = *(const f32x4 *)(dx_res + t * D + col[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) rr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 gdy[NCH], xh[NCH];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int d = lane * 4 + i * 256;
-      if (d < D) {
-        const f32x4 g = *(const f32x4 *)(gamma + d);
-        const f32x4 dyv = Vec4<T>::load(dy + t * D + d);
-        xh[i] = (*(const f32x4 *)(x + t * D + d) - mu) * rs;
-        gdy[i] = dyv * g;
-        s1 += gdy[i][0] + gdy[i][1] + gdy[i][2] + gdy[i][3];
-        s2 += gdy[i][0] * xh[i][0] + gdy[i][1] * xh[i][1] + gdy[i][2] * xh[i][2] + gdy[i][3] * xh[i][3];
-        dg[i] += dyv * xh[i];
-        db[i] += dyv;
-      }
+      f32x4 dyv = f32x4{(float)dyr[i][0], (float)dyr[i][1], (float)dyr[i][2], (float)dyr[i][3]};
+      if (!on[i]) dyv = f32x4{0.f, 0.f, 0.f, 0.f};
+      xh[i] = (xr[i] - mu) * rs;
+      gdy[i] = dyv * gam[i];
+      s1 += gdy[i][0] + gdy[i][1] + gdy[i][2] + gdy[i][3];
+      s2 += gdy[i][0] * xh[i][0] + gdy[i][1] * xh[i][1] + gdy[i][2] * xh[i][2] + gdy[i][3] * xh[i][3];
+      dg[i] += dyv * xh[i];
+      db[i] += dyv;
     }
     const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int d = lane * 4 + i * 256;
-      if (d < D) {
-        f32x4 o = (gdy[i] - m1 - xh[i] * m2) * rs;
-        if (dx_res) o += *(const f32x4 *)(dx_res + t * D + d);
-        *(f32x4 *)(dx + t * D + d) = o;
-        if (dx_act) Vec4<TA>::store(dx_act + t * D + d, o);   // activation-dtype copy for the next GEMMs
+      if (on[i]) {
+        const f32x4 o = (gdy[i] - m1 - xh[i] * m2) * rs + rr[i];
+        *(f32x4 *)(dx + t * D + col[i]) = o;
+        if (dx_act) Vec4<TA>::store(dx_act + t * D + col[i], o);   // activation-dtype copy for the next GEMMs
       }
     }
   }
@@ -392,6 +413,108 @@ __global__ void assemble_tokens_kernel(const float *__restrict__ patch, const fl
 
 using namespace m3;
 
+// Input gradient of an MoE layer's branch point: the k routed copies of a token (MOEScatter's backward: a gather-sum,
+// custom_moe_layer.py:254-259 / fmoe functions.py MOEScatter.backward) plus the gate's share d logits @ w_gate^T
+// (the backward of `inp @ w_gate`, noisy_gate_vmoe.py:91).  One wave per row; the E rows of w_gate^T live in LDS as
+// [E][D] fp32 (a lane reads its 4 columns of every expert row as one 16-byte access), the token's E logit gradients are
+// wave-uniform scalars.  Replaces a [T,k,D] -> [T,D] sum pass plus a K = E GEMM pass that re-read and re-wrote the
+// fp32 [T,D] result.
+constexpr int CG_THREADS = 512;    // 8 waves share one LDS image of w_gate^T
+constexpr int CG_ROWS = 2;         // rows per wave and pass (4: 142 VGPRs, 3 waves per SIMD)
+template <typename T, int KT, int NCH>
+__global__ __launch_bounds__(CG_THREADS) void combine_gate_bwd_kernel(const T *__restrict__ dxe, int64_t T_, int k_rt, int D,
+                                                                      const float *__restrict__ dl,
+                                                                      const float *__restrict__ wg, int E,
+                                                                      float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float s_w[];        // [E][D + 4]: the transposing fill below walks e
+  const int DP = D + 4;     // fastest, and a row stride of D (a multiple of the 32 banks) would put all 64 lanes on one bank
+  const int k = KT ? KT : k_rt;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int q = threadIdx.x * 4; q < D * E; q += CG_THREADS * 4) {    // w_gate is [D][E]: transpose on the way in
+    const f32x4 v = *(const f32x4 *)(wg + q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = (q + i) / E, e = (q + i) - d * E;
+      s_w[e * DP + d] = v[i];
+    }
+  }
+  __syncthreads();
+  constexpr int WPB = CG_THREADS / 64, RW = CG_ROWS; // RW rows per wave and pass: every LDS read of w_gate^T feeds RW rows
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  // lanes past D in the last column chunk read column 0 again and never store: every load stays unconditional (a
+  // predicated load becomes its own basic block with its own wait - the row's loads would go out one latency at a time)
+  bool on[NCH];
+  int col[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) { on[c] = c * 256 + lane * 4 < D; col[c] = on[c] ? c * 256 + lane * 4 : 0; }
+  const int64_t ngrp = (T_ + RW - 1) / RW;
+  for (int64_t gq = (int64_t)blockIdx.x * WPB + wave; gq < ngrp; gq += (int64_t)gridDim.x * WPB) {
+    const int64_t t0 = gq * RW;
+    // every load of the RW rows first (RW x k rows x NCH column chunks in flight), then the E-step fma chains side by side
+    f32x4 acc[RW][NCH];
+    if constexpr (KT > 0) {
+      typename Vec4<T>::type raw[RW][NCH][KT];                       // as loaded: converted only after all are on their way
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const int64_t t = t0 + r < T_ ? t0 + r : T_ - 1;           // (rows past T: a valid row again, never stored)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int j = 0; j < KT; ++j)
+            raw[r][c][j] = *(const typename Vec4<T>::type *)(dxe + (t * KT + j) * D + col[c]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          acc[r][c] = f32x4{(float)raw[r][c][0][0], (float)raw[r][c][0][1], (float)raw[r][c][0][2], (float)raw[r][c][0][3]};
+#pragma unroll
+          for (int j = 1; j < KT; ++j)
+            acc[r][c] = acc[r][c] + f32x4{(float)raw[r][c][j][0], (float)raw[r][c][j][1], (float)raw[r][c][j][2], (float)raw[r][c][j][3]};
+        }
+    } else {
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const int64_t t = t0 + r < T_ ? t0 + r : T_ - 1;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int j = 0; j < k; ++j) acc[r][c] = acc[r][c] + Vec4<T>::load(dxe + (t * k + j) * D + col[c]);
+        }
+      }
+    }
+    const float *u[RW];                                              // wave-uniform addresses: scalar loads
+#pragma unroll
+    for (int r = 0; r < RW; ++r) u[r] = dl + (t0 + r < T_ ? t0 + r : T_ - 1) * E;
+#pragma unroll 4
+    for (int e = 0; e < E; ++e) {
+      float ue[RW];
+#pragma unroll
+      for (int r = 0; r < RW; ++r) ue[r] = u[r][e];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const f32x4 w = *(const f32x4 *)(s_w + e * DP + col[c]);
+        const f32x2 wl = f32x2{w[0], w[1]}, wh = f32x2{w[2], w[3]};
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {                              // packed fp32 fma: two columns per instruction
+          const f32x2 uu = f32x2{ue[r], ue[r]};
+          f32x2 lo = f32x2{acc[r][c][0], acc[r][c][1]}, hi = f32x2{acc[r][c][2], acc[r][c][3]};
+          lo = __builtin_elementwise_fma(uu, wl, lo);
+          hi = __builtin_elementwise_fma(uu, wh, hi);
+          acc[r][c] = f32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        if (on[c] && t0 + r < T_) *(f32x4 *)(out + (t0 + r) * D + c * 256 + lane * 4) = acc[r][c];
+  }
+}
+
 static inline unsigned row_blocks(int64_t T) { return (unsigned)((T + 3) / 4); }
 
 extern "C" int m3_combine_fwd(const void *y, int dtype, const float *score, const float *residual, int64_t T, int k,
@@ -407,6 +530,30 @@ extern "C" int m3_combine_fwd(const void *y, int dtype, const float *score, cons
 #undef M3_CF_K
 #undef M3_CF
   return check_launch("m3_combine_fwd");
+}
+
+extern "C" int m3_combine_gate_bwd(const void *dxe, int dtype, int64_t T, int k, int D, const float *d_logits,
+                                   const float *w_gate, int E, float *dh, void *stream) {
+  M3_REQUIRE(dxe && d_logits && w_gate && dh, "m3_combine_gate_bwd: null operand");
+  M3_REQUIRE(dtype_ok(dtype), "m3_combine_gate_bwd: bad dtype");
+  M3_REQUIRE(D % 4 == 0 && D > 0 && k >= 1 && E >= 1, "m3_combine_gate_bwd: D must be a multiple of 4");
+  const size_t lds = (size_t)E * (D + 4) * sizeof(float);
+  M3_REQUIRE(lds <= 64 * 1024, "m3_combine_gate_bwd: w_gate [D=%d][E=%d] does not fit the 64 KB LDS image", D, E);
+  if (T == 0) return M3_OK;
+  hipStream_t s = (hipStream_t)stream;
+  // grid-stride over the rows: two 16-wave workgroups per CU (all 32 wave slots), each filling its LDS image of w_gate once
+  const int64_t rb = ((T + CG_ROWS - 1) / CG_ROWS + CG_THREADS / 64 - 1) / (CG_THREADS / 64);
+  const unsigned grid = (unsigned)(rb < 1024 ? rb : 1024);
+  const int nch = (D + 255) / 256;
+  M3_REQUIRE(nch <= 4 && (D * E) % 4 == 0 && ((uintptr_t)w_gate % 16) == 0, "m3_combine_gate_bwd: D <= 1024, w_gate 16-byte aligned");
+#define M3_CG(TT, KT_, NC_) hipLaunchKernelGGL((combine_gate_bwd_kernel<TT, KT_, NC_>), dim3(grid), dim3(CG_THREADS), lds, s, (const TT *)dxe, T, k, D, d_logits, w_gate, E, dh)
+#define M3_CG_N(TT, KT_) do { if (nch == 1) M3_CG(TT, KT_, 1); else if (nch == 2) M3_CG(TT, KT_, 2); else if (nch == 3) M3_CG(TT, KT_, 3); else M3_CG(TT, KT_, 4); } while (0)
+#define M3_CG_K(TT) do { if (k == 4) M3_CG_N(TT, 4); else if (k == 2) M3_CG_N(TT, 2); else M3_CG_N(TT, 0); } while (0)
+  if (dtype == M3_F16) M3_CG_K(half_t); else if (dtype == M3_BF16) M3_CG_K(bf16_t); else M3_CG_K(float);
+#undef M3_CG_K
+#undef M3_CG_N
+#undef M3_CG
+  return check_launch("m3_combine_gate_bwd");
 }
 
 extern "C" int m3_combine_bwd(const float *dout, const void *y, int dtype, const float *score, int64_t T, int k, int D,

@@ -224,6 +224,10 @@ class BackboneEngine:
         # gate backward through the MFMA GEMMs when E rows are 16-byte multiples
         es = 2 if self.dt in (torch.float16, torch.bfloat16) else 4
         self.gate_via_gemm = (self.E * es) % 16 == 0
+        # ... and the gate's share of d h2 folded into the gather-sum of the routed rows' gradients (m3_combine_gate_bwd)
+        # when w_gate^T fits its LDS image
+        import os
+        self.fused_gate_dx = self.E * (D + 4) * 4 <= 64 * 1024 and os.environ.get("M3_FUSED_GATE_DX", "1") == "1"
         # task-conditioned gate (custom_moe_layer.py:161-181): one shared w_gate [D + gtsd, E] per MoE block
         self.task_cond = self.cfg.gate_task_specific_dim >= 0 and not self.cfg.multi_gate
         self.s_dl_t = self._e(T, self.E)
@@ -679,7 +683,6 @@ class BackboneEngine:
                                 a_row_div=k, group_offsets=r.offsets, bias=b + "mlp.experts.htoh4.bias", reads=("dpre",))
                     ops.gemm_nt(dhp, self.wt[b + "mlp.experts.htoh4"], self.s_dxe, M=R, c_row_idx=r.row_of_slot,
                                 group_offsets=r.offsets, tile_starts=r.tile_starts)
-                ops.combine_fwd(self.s_dxe, self.ones_k, None, self.s_dh32)       # dh2 = sum_j dxe[t,j]
                 # gate: d score from the combine, d importance / d load from the cv loss
                 bal = cv_weight != 0.0
                 self._before_write("dl")
@@ -690,14 +693,17 @@ class BackboneEngine:
                 # token rows of w_gate ([:D]; the task-conditioned rows [D:]: _task_feature_block_bwd below)
                 wg, dwg = p[a["wname"]][:D], gr[a["wname"]][:D]
                 if self.gate_via_gemm:
-                    # d w_gate += h2^T dl (TN GEMM) ; dh2 += dl w_gate^T (NT GEMM, K = E)
-                    if self.dt == torch.float32:
-                        dl_t, wg_t = dl, wg
-                    else:
-                        dl_t, wg_t = ops.cast_f32(dl, self.s_dl_t), self.wgate_c[a["wname"]][:D]
+                    # d w_gate += h2^T dl (TN GEMM) ; dh2 = sum_j dxe[t,j] + dl w_gate^T
+                    dl_t = dl if self.dt == torch.float32 else ops.cast_f32(dl, self.s_dl_t)
                     self._fork(("dl",), lambda: ops.wgrad_tn(a["h2"], dl_t, dwg, beta=1, ws=self.ws_wgrad, queue=self.wq))
-                    ops.gemm_nt(dl_t, wg_t, self.s_dh32, residual=self.s_dh32)
+                    if self.fused_gate_dx:
+                        ops.combine_gate_bwd(self.s_dxe, k, dl, wg, self.s_dh32)     # one pass over the [T, D] result
+                    else:
+                        ops.combine_fwd(self.s_dxe, self.ones_k, None, self.s_dh32)
+                        wg_t = wg if self.dt == torch.float32 else self.wgate_c[a["wname"]][:D]
+                        ops.gemm_nt(dl_t, wg_t, self.s_dh32, residual=self.s_dh32)
                 else:
+                    ops.combine_fwd(self.s_dxe, self.ones_k, None, self.s_dh32)       # dh2 = sum_j dxe[t,j]
                     ops.gate_bwd_params(a["h2"], wg, dl, d_w_gate=dwg, beta_dw=1, dx=self.s_dh32,
                                         beta_dx=1, part_dw=self.ws_gate_dw)
                 if self._tsf is not None:

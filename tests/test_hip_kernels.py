@@ -520,6 +520,24 @@ def test_combine_fwd_bwd(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,k,D,E", [(1003, 4, 384, 16), (9001, 2, 64, 8), (130, 1, 260, 5), (77, 3, 768, 16), (4, 8, 128, 64)])
+def test_combine_gate_bwd_sums_the_routed_rows_and_adds_the_gate_share(ops, dtype, T, k, D, E):
+    """m3_combine_gate_bwd: d h2 = sum_j dxe[t*k+j] + d logits @ w_gate[:D]^T in one pass (MOEScatter.backward's gather-sum
+    + the backward of inp @ w_gate, noisy_gate_vmoe.py:91), against fp64; w_gate as a row slice of a taller parameter
+    (the task-conditioned gate's [D + gtsd, E])."""
+    dxe = rnd(T * k, D, dtype=dtype, seed=55)
+    dl = rnd(T, E, seed=56)
+    w_full = rnd(D + 7, E, seed=57)
+    out = torch.full((T, D), float("nan"), device=dev())
+    ops.combine_gate_bwd(dxe, k, dl, w_full[:D], out)
+    ref = dxe.double().view(T, k, D).sum(1) + dl.double() @ w_full[:D].double().t()
+    assert rel(out, ref) < 2e-6
+    with pytest.raises(Exception, match="LDS"):
+        ops.combine_gate_bwd(rnd(8, 1024, dtype=dtype, seed=58), 1, rnd(8, 64, seed=59), rnd(1024, 64, seed=60),
+                             torch.empty(8, 1024, device=dev()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("D", [384, 768, 192])
 def test_layernorm_fwd_bwd(ops, dtype, D):
     T = 517
