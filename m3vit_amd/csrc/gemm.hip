@@ -436,32 +436,47 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const Gemm
 
   // DMA assignment: wave w, piece j fills image rows (NPC*w + j)*RPI .. +RPI-1; lane l -> row + l / CPR,
   // LDS slot l % CPR, which holds source chunk (l % CPR) ^ swz(row).  Rows past the end are clamped (never stored).
+  // Every index load of the prologue (the NPC gathered A rows of this lane; the row of the epilogue factor) is issued
+  // before the first one is used: one memory latency in front of the first DMA instead of one per index (an index load
+  // inside the per-piece loop, with the divide behind it, becomes its own basic block with its own wait).
   const char *a_src[NPC], *b_src[NPC];
+  int64_t mrow[NPC];
+  int32_t aix[NPC];
+#pragma unroll
+  for (int j = 0; j < NPC; ++j) {
+    const int row = (NPC * wave + j) * RPI + lane / CPR;
+    int64_t m = m_begin + row;
+    if (m >= m_end) m = m_end - 1;
+    mrow[j] = m;
+  }
+  if (p.a_row_idx) {
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) aix[j] = p.a_row_idx[mrow[j]];
+  }
+  // per-row epilogue factor (DropPath scale / gate score of the routed row): thread r < 128 requests row r's factor NOW -
+  // an index load and a dependent load - so that they arrive under the K loop instead of in front of every store pass
+  const bool want_rs = p.row_scale && tid < BM;
+  const int32_t *rs_idx = p.row_scale_idx ? p.row_scale_idx : p.c_row_idx;
+  int64_t rs_m = m_begin + tid;
+  if (rs_m >= m_end) rs_m = m_end - 1;
+  int32_t rs_ix = 0;
+  if (want_rs && rs_idx) rs_ix = rs_idx[rs_m];
+  float my_rs = 1.0f;
+  if (want_rs) {
+    const int64_t srow = rs_idx ? (int64_t)rs_ix : rs_m;
+    my_rs = p.row_scale[p.row_scale_div == 1 ? srow : srow / p.row_scale_div];
+  }
 #pragma unroll
   for (int j = 0; j < NPC; ++j) {
     const int row = (NPC * wave + j) * RPI + lane / CPR;
     const int c = (lane % CPR) ^ dma_swz(row);
-    int64_t m = m_begin + row;
-    if (m >= m_end) m = m_end - 1;
-    int64_t src = m;
-    if (p.a_row_idx) src = (int64_t)div_by(p.a_row_idx[m], p.a_row_div, p.a_row_sh);
+    const int64_t src = p.a_row_idx ? (int64_t)div_by(aix[j], p.a_row_div, p.a_row_sh) : mrow[j];
     a_src[j] = p.A + src * p.lda_b + c * 16;
     int n = n0 + row;
     if (n >= p.N) n = p.N - 1;
     b_src[j] = p.B + (int64_t)g * p.b_group_b + (int64_t)n * p.ldb_b + c * 16;
   }
   const int nk = (p.K * (int)sizeof(T)) / RB;
-
-  // per-row epilogue factor (DropPath scale / gate score of the routed row): thread r < 128 requests row r's factor NOW -
-  // an index load and a dependent load - so that they arrive under the K loop instead of in front of every store pass
-  float my_rs = 1.0f;
-  if (p.row_scale && tid < BM) {
-    int64_t m = m_begin + tid;
-    if (m >= m_end) m = m_end - 1;
-    const int64_t crow = p.c_row_idx ? (int64_t)p.c_row_idx[m] : m;
-    const int64_t srow = p.row_scale_idx ? (int64_t)p.row_scale_idx[m] : crow;
-    my_rs = p.row_scale[srow / p.row_scale_div];
-  }
 
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
