@@ -25,7 +25,7 @@
 namespace m3 {
 
 constexpr int GATE_TOK = 64;       // tokens per workgroup
-constexpr int GATE_DW_TOK = 128;   // tokens per workgroup in the dW kernel
+constexpr int GATE_DW_TOK = 64;    // tokens per workgroup in the dW kernels
 constexpr int GATE_ROWB = 128;     // bytes of a token row staged per step (one cache line)
 
 __device__ __forceinline__ float normal_cdf(float z) { return 0.5f * erfcf(-z * 0.70710678118654752f); }
@@ -466,6 +466,78 @@ __global__ void gate_bwd_dw_kernel(const char *__restrict__ x, int64_t T_, int D
   }
 }
 
+// dW partials for E <= 16 (round 3): a thread owns FOUR adjacent d (one 8-byte fp16 load per token) x all E experts = 4*E
+// accumulators, RP (4, or 2 for D > 512) threads share a column group and walk the workgroup's tokens RP apart; the tokens' d_logits rows sit
+// in LDS (one 16-byte read per 4 experts).  64 FMAs per 8 bytes loaded, eight loads in flight per thread; the row-parity
+// partials meet in LDS.  The kernel above (one d per thread, a 2-byte load and E scalar loads per token, no unrolling) ran the
+// 0.3 GFLOP product at the speed of its load chain; the TN MFMA GEMM that replaced it in round 1 pads E = 16 to a 128-wide tile.
+template <typename T, int EPAD>
+__global__ __launch_bounds__(512) void gate_bwd_dw4_kernel(const char *__restrict__ x, int64_t T_, int D, int64_t ldx_b,
+                                                            const float *__restrict__ dl, int E, float *part_dw) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];        // [GATE_DW_TOK][EPAD] d_logits, then [RP][D/4][4*EPAD+1] partials
+  float *sdl = sm, *spart = sm + GATE_DW_TOK * EPAD;
+  const int CG = D / 4;
+  const int RP = blockDim.x / CG;                                    // 4 or 2
+  const int tid = threadIdx.x, rp = tid / CG, cg = tid - rp * CG;
+  const int64_t t0 = (int64_t)blockIdx.x * GATE_DW_TOK;
+  const int ntok = (int)((T_ - t0 < GATE_DW_TOK) ? T_ - t0 : GATE_DW_TOK);
+  for (int q = tid; q < GATE_DW_TOK * EPAD; q += blockDim.x) {
+    const int t = q / EPAD, e = q - t * EPAD;
+    sdl[q] = (t < ntok && e < E) ? dl[(t0 + t) * E + e] : 0.f;       // rows past the end: zeros (their x rows are clamped)
+  }
+  __syncthreads();
+  float acc[4][EPAD];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int e = 0; e < EPAD; ++e) acc[c][e] = 0.f;
+  const char *xc = x + (int64_t)cg * 4 * sizeof(T);
+  constexpr int UN = 8;                                              // tokens per thread: GATE_DW_TOK / RP, in batches of UN
+  static_assert((GATE_DW_TOK / 4) % UN == 0, "token batches");
+  const int per = GATE_DW_TOK / RP;
+  for (int i0 = 0; i0 < per; i0 += UN) {
+    typename Vec4<T>::type raw[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      int t = rp + RP * (i0 + u);
+      if (t >= ntok) t = ntok - 1;                                   // clamped: multiplied by the zero d_logits row
+      raw[u] = *(const typename Vec4<T>::type *)(xc + (t0 + t) * ldx_b);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int t = rp + RP * (i0 + u);
+      const float xv[4] = {(float)raw[u][0], (float)raw[u][1], (float)raw[u][2], (float)raw[u][3]};
+#pragma unroll
+      for (int e4 = 0; e4 < EPAD; e4 += 4) {
+        const f32x4 d4 = *(const f32x4 *)(sdl + t * EPAD + e4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          acc[c][e4 + 0] = __builtin_fmaf(xv[c], d4[0], acc[c][e4 + 0]); acc[c][e4 + 1] = __builtin_fmaf(xv[c], d4[1], acc[c][e4 + 1]);
+          acc[c][e4 + 2] = __builtin_fmaf(xv[c], d4[2], acc[c][e4 + 2]); acc[c][e4 + 3] = __builtin_fmaf(xv[c], d4[3], acc[c][e4 + 3]);
+        }
+      }
+    }
+  }
+  // every row parity leaves its partials in LDS, slab [rp][cg][4*EPAD + 1] (the odd stride keeps both the per-thread
+  // writes - lanes = column groups - and the linear read below conflict-free); then all threads add the slabs in parity
+  // order and write [D][E] in output order (coalesced)
+  constexpr int GS = 4 * EPAD + 1;
+  float *mine = spart + ((int64_t)rp * CG + cg) * GS;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int e = 0; e < EPAD; ++e) mine[c * EPAD + e] = acc[c][e];
+  __syncthreads();
+  float *out = part_dw + (int64_t)blockIdx.x * D * E;
+  for (int q = tid; q < D * EPAD; q += blockDim.x) {
+    const int g = q / (4 * EPAD), r4 = q - g * (4 * EPAD), e = r4 % EPAD, d = g * 4 + r4 / EPAD;
+    float v = 0.f;
+    for (int r = 0; r < RP; ++r) v += spart[((int64_t)r * CG + g) * GS + r4];
+    if (e < E) out[(int64_t)d * E + e] = v;
+  }
+}
+
 __global__ void gate_dw_reduce_kernel(const float *part, int nblk, int64_t elems, float *dw, int beta) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= elems) return;
@@ -622,6 +694,29 @@ extern "C" int m3_gate_bwd_params(const void *x, int x_dtype, int64_t T, int D, 
   const int ep = epad8_of(E);
   if (d_w_gate) {
     const int nblk = m3_gate_dw_blocks(T);
+    const int64_t elems = (int64_t)D * E;
+    // E <= 16, 4-column groups that fill a 1024-thread workgroup, 8-byte-aligned rows: the four-d-per-thread kernel and the
+    // two-stage row reduction (8 row lanes per column block instead of one thread walking all nblk partial rows)
+    const int rpn = (D / 4) * 4 <= 512 ? 4 : 2;
+    const size_t lds4 = ((size_t)GATE_DW_TOK * ep + (size_t)rpn * (D / 4) * (4 * ep + 1)) * sizeof(float);
+    if (ep <= 16 && D % 4 == 0 && (D / 4) * rpn <= 512 && ((uintptr_t)x % 8) == 0 && (ldx * es) % 8 == 0 &&
+        lds4 <= 144 * 1024) {
+      const dim3 grid4(nblk), block4((D / 4) * rpn);
+#define M3_DW4_CASE(TT, EP)                                                                                                  \
+  do {                                                                                                                       \
+    static bool attr = false;                                                                                                \
+    if (!attr) { (void)hipFuncSetAttribute((const void *)gate_bwd_dw4_kernel<TT, EP>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); attr = true; } \
+    hipLaunchKernelGGL((gate_bwd_dw4_kernel<TT, EP>), grid4, block4, lds4, s, (const char *)x, T, D, ldx * es, d_logits, E, part_dw); \
+  } while (0)
+      if (x_dtype == M3_F16) { if (ep == 8) M3_DW4_CASE(half_t, 8); else M3_DW4_CASE(half_t, 16); }
+      else if (x_dtype == M3_BF16) { if (ep == 8) M3_DW4_CASE(bf16_t, 8); else M3_DW4_CASE(bf16_t, 16); }
+      else { if (ep == 8) M3_DW4_CASE(float, 8); else M3_DW4_CASE(float, 16); }
+#undef M3_DW4_CASE
+      int rc4 = check_launch("m3_gate_bwd_params(dw4)");
+      if (rc4) return rc4;
+      rc4 = launch_reduce_rows_f32(part_dw, nblk, (int)elems, 1, 0, d_w_gate, beta_dw, s);
+      if (rc4) return rc4;
+    } else {
     const dim3 grid(nblk), block(((D + 63) / 64) * 64);
 #define M3_DW_CASE(TT, EP)                                                                                     \
   hipLaunchKernelGGL((gate_bwd_dw_kernel<TT, EP>), grid, block, 0, s, (const char *)x, T, D, ldx * es, d_logits, \
@@ -639,11 +734,11 @@ extern "C" int m3_gate_bwd_params(const void *x, int x_dtype, int64_t T, int D, 
 #undef M3_DW_CASE
     int rc = check_launch("m3_gate_bwd_params(dw)");
     if (rc) return rc;
-    const int64_t elems = (int64_t)D * E;
     hipLaunchKernelGGL(gate_dw_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, part_dw, nblk,
                        elems, d_w_gate, beta_dw);
     rc = check_launch("m3_gate_bwd_params(dw reduce)");
     if (rc) return rc;
+    }
   }
   if (dx) {
     const size_t lds = (size_t)D * E * sizeof(float);

@@ -693,6 +693,9 @@ class BackboneEngine:
                 # token rows of w_gate ([:D]; the task-conditioned rows [D:]: _task_feature_block_bwd below)
                 wg, dwg = p[a["wname"]][:D], gr[a["wname"]][:D]
                 if self.gate_via_gemm:
+                    # (a dedicated VALU kernel for d w_gate - m3_gate_bwd_params, 4 columns x E accumulators per thread - was
+                    # measured in round 3: 24 us + 6 us partial reduce against 17.5 us for the padded TN GEMM whose reduce rides
+                    # along: the GEMM stays)
                     # d w_gate += h2^T dl (TN GEMM) ; dh2 = sum_j dxe[t,j] + dl w_gate^T
                     dl_t = dl if self.dt == torch.float32 else ops.cast_f32(dl, self.s_dl_t)
                     self._fork(("dl",), lambda: ops.wgrad_tn(a["h2"], dl_t, dwg, beta=1, ws=self.ws_wgrad, queue=self.wq))

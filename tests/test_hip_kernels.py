@@ -425,6 +425,23 @@ def test_gate_backward(ops, dtype):
     assert rel(dx - dx0, xr.grad) < 1e-4
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,D,E", [(1003, 384, 16), (200, 768, 16), (64, 64, 8), (129, 1024, 5), (77, 260, 16), (300, 384, 64)])
+def test_gate_weight_gradient_kernel(ops, dtype, T, D, E):
+    """d w_gate (+)= x^T d_logits through m3_gate_bwd_params alone (dx = NULL): the four-columns-per-thread kernel for E <= 16
+    (row parities 4 and, for D > 512, 2; ragged last token block; beta = 1 accumulation) and the one-column kernel for E > 16,
+    against fp64."""
+    x = rnd(T, D, dtype=dtype, seed=46)
+    dl = rnd(T, E, seed=47)
+    w = rnd(D, E, seed=48)
+    dw = rnd(D, E, seed=49)
+    dw0 = dw.clone()
+    ops.gate_bwd_params(x, w, dl, d_w_gate=dw, beta_dw=1)
+    assert rel(dw - dw0, x.double().t() @ dl.double()) < 2e-5
+    ops.gate_bwd_params(x, w, dl, d_w_gate=dw, beta_dw=0)
+    assert rel(dw, x.double().t() @ dl.double()) < 2e-6
+
+
 @pytest.mark.parametrize("E,k,T", [(16, 4, 1000), (64, 4, 333), (4, 2, 70), (5, 2, 129)])
 def test_balance_loss_count_form(ops, E, k, T):
     """cv_loss = cv^2(gates.sum(0)) + cv^2((gates > 0).sum(0)) (vision_transformer_moe.py:453-459,540)
