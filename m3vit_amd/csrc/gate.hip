@@ -47,12 +47,13 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
   constexpr int NW = EPAD / EW;
   constexpr int NT = GATE_TOK * NW;
   constexpr int DC = GATE_ROWB / (int)sizeof(T);   // d per step
-  constexpr int LDS_STRIDE = DC + 1;               // floats; odd -> conflict-free per-lane rows
+  constexpr int LDS_STRIDE = DC + 4;               // floats; 16-byte aligned rows, 17 * 16 B apart: eight consecutive lanes' 16-byte
+                                                   // accesses cover all 32 banks (conflict-free ds_read_b128 / ds_write_b128)
   constexpr int CPR = GATE_ROWB / 16;              // 16-byte chunks per row per step
   constexpr int EPC = 16 / (int)sizeof(T);         // elements per chunk
   constexpr int NCH = GATE_TOK * CPR / NT;         // chunks per thread per step
   constexpr int NWE = (DC * EPAD + NT - 1) / NT;   // w_gate slice elements per thread per step
-  __shared__ float sx[2][GATE_TOK * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float sx[2][GATE_TOK * LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) float sw[2][DC * EPAD];   // w_gate rows of the step, zero-padded to EPAD
   __shared__ float slog[NW > 1 ? GATE_TOK * (EPAD + 1) : 1];
 
@@ -105,12 +106,10 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
       if constexpr (sizeof(T) == 2) {
         typedef T t16x8 __attribute__((ext_vector_type(8)));          // fp16 or bf16 rows
         const t16x8 h = __builtin_bit_cast(t16x8, pre[i]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dst[j] = (float)h[j];
+        *(f32x4 *)dst = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        *(f32x4 *)(dst + 4) = f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
       } else {
-        const f32x4 f = __builtin_bit_cast(f32x4, pre[i]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dst[j] = f[j];
+        *(f32x4 *)dst = __builtin_bit_cast(f32x4, pre[i]);
       }
     }
   };
@@ -119,8 +118,17 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
   auto compute = [&](int buf, int dn) {
     const float *xs = &sx[buf][lane * LDS_STRIDE];
     const float *ws = &sw[buf][e0];
-#pragma unroll 8
-    for (int dd = 0; dd < dn; ++dd) {
+    // four d per 16-byte read of the lane's row (the fma chain per logit still runs over d in order)
+    int dd = 0;
+#pragma unroll 4
+    for (; dd + 4 <= dn; dd += 4) {
+      const f32x4 xv = *(const f32x4 *)(xs + dd);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < EW; ++e) acc[e] = __builtin_fmaf(xv[j], ws[(dd + j) * EPAD + e], acc[e]);
+    }
+    for (; dd < dn; ++dd) {
       const float xv = xs[dd];
 #pragma unroll
       for (int e = 0; e < EW; ++e) acc[e] = __builtin_fmaf(xv, ws[dd * EPAD + e], acc[e]);
