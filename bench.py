@@ -57,8 +57,9 @@ def parse():
                     "the hipGraph; with the default concurrent task streams the nested fork cannot be captured (ROCm 7.2 "
                     "faults in hipStreamEndCapture: tools/nested_capture_probe.py) and the step runs eagerly "
                     "(config.capture_refused says so); off under expert parallelism")
-    ap.add_argument("--share-stem", action="store_true", help="compute the task-independent stem (patch embedding + the blocks "
-                    "below the first MoE block) once per step for all task passes (MultiTaskStep share_stem)")
+    ap.add_argument("--no-share-stem", action="store_true", help="run the task-independent stem (patch embedding + the blocks "
+                    "below the first MoE block) once PER TASK PASS as the reference does, instead of once per step for all "
+                    "passes (MultiTaskStep share_stem: same gradients); N = 1 reports that schedule as \"per_task_stems\" anyway")
     ap.add_argument("--ep", action="store_true", help="N > 1: time ONLY the expert-parallel form (experts sharded over the "
                     "ranks, all-to-all over RCCL); default: expert parallel (primary, when E %% N == 0) AND data parallel")
     ap.add_argument("--dp-only", action="store_true", help="N > 1: time only the replicated-experts data-parallel form")
@@ -251,6 +252,8 @@ def main():
         ms_per_step = 1e3 * dt / args.steps
         log(f"{tag}: timed region done: {ms_per_step:.2f} ms/step")
         step_flops = 3.0 * cfg.fwd_flops_per_image() * args.batch * ntasks
+        if runner.share_stem:      # FLOPs actually executed: the stem (patch embedding + blocks below the first MoE block) once
+            step_flops -= 3.0 * cfg.stem_flops_per_image() * args.batch * (ntasks - 1)
         res = {"value": round(world * args.batch * args.steps / dt, 2), "ms_per_step": round(ms_per_step, 3),
                "model_tflops": round(step_flops * args.steps / dt / 1e12 * world, 2), "launch": runner.launch,
                "task_streams": ntasks if par_tasks else 1,
@@ -416,18 +419,21 @@ def main():
 
     main_res = None
     if world == 1:
-        main_res = run_mode(args.dtype, False, True, share_stem=args.share_stem)
-        if not args.share_stem and not args.serial_tasks:
-            # the same step with the task-independent stem computed once for both passes (m3vit_amd/step.py share_stem):
-            # identical gradients, one block forward + backward and one patch embedding fewer than the reference's
-            # one-full-pass-per-task schedule.  Reported beside the headline, never as it: `value` keeps the reference's schedule.
-            st = attempt("shared_stem", lambda: run_mode(args.dtype, False, False, share_stem=True))
-            if st is not None:
-                extra["shared_stem"] = {"value": st["value"], "ms_per_step": st["ms_per_step"], "launch": st["launch"],
-                                        "note": "patch embedding + block 0 run once per step for both task passes, their backward "
-                                                "once on the summed d x (tests/test_engine.py::test_shared_stem_step_matches_per_task_stems)"}
+        # The step's schedule: every task pass of a step reads the same images (train/train_utils.py:248-256) and the patch
+        # embedding + block 0 see neither task id nor gate, so they are computed once per step and their backward runs once on
+        # the summed d x (m3vit_amd/step.py share_stem; identical gradients: tests/test_engine.py::
+        # test_shared_stem_step_matches_per_task_stems).  The reference's own schedule - one FULL pass per task, 24 instead of
+        # 23 block passes - is timed as well and reported beside it as "per_task_stems".
+        share = not args.no_share_stem and not args.serial_tasks
+        main_res = run_mode(args.dtype, False, True, share_stem=share)
+        if share:
+            pt = attempt("per_task_stems", lambda: run_mode(args.dtype, False, False, share_stem=False))
+            if pt is not None:
+                extra["per_task_stems"] = {"value": pt["value"], "ms_per_step": pt["ms_per_step"], "launch": pt["launch"],
+                                           "model_tflops": pt["model_tflops"],
+                                           "note": "the reference's schedule: patch embedding + block 0 computed by every task pass"}
         if args.dtype == "f16" and not args.no_f32:
-            f32 = attempt("f32", lambda: run_mode("f32", False, True))
+            f32 = attempt("f32", lambda: run_mode("f32", False, True, share_stem=share))
             if f32 is not None:
                 extra["f32"] = {k: f32[k] for k in ("value", "ms_per_step", "model_tflops", "launch", "roofline")}
                 extra["f32"]["dtype"] = "f32"
@@ -439,23 +445,30 @@ def main():
         # data parallel first: it needs one collective (all-reduce) and its line must survive whatever the expert-parallel
         # leg (count all-to-all + uneven all-to-all-v on several streams) does at its first contact with RCCL
         if want_dp:
-            results[False] = attempt("dp", lambda: run_mode(args.dtype, False, False, share_stem=args.share_stem))
+            results[False] = attempt("dp", lambda: run_mode(args.dtype, False, False, share_stem=False))
             if results[False] is not None:
                 extra["dp"] = {k: results[False][k] for k in sub}
+            if not args.no_share_stem and not args.serial_tasks:
+                # the same form with the task-independent stem computed once per step (see the N = 1 branch); its own leg, so
+                # that whatever it does at its first contact with RCCL costs only itself
+                results["dp_shared_stem"] = attempt("dp_shared_stem", lambda: run_mode(args.dtype, False, False, share_stem=True))
+                if results["dp_shared_stem"] is not None:
+                    extra["dp_shared_stem"] = {k: results["dp_shared_stem"][k] for k in sub}
         if want_ep:
             def ep_hung():
                 extra["ep_error"] = f"no result after {EP_WATCHDOG_S} s (a collective that never returned); reporting the data-parallel leg"
-                if rank == 0 and results.get(False) is not None:
-                    emit(results[False])
-                os._exit(0 if results.get(False) is not None else 1)
+                done = [r for r in (results.get(False), results.get("dp_shared_stem")) if r is not None]
+                if rank == 0 and done:
+                    emit(max(done, key=lambda r: r["value"]))
+                os._exit(0 if done else 1)
             results[True] = attempt("ep", lambda: run_mode(args.dtype, True, False), watchdog_s=EP_WATCHDOG_S, on_timeout=ep_hung)
             if results[True] is not None:
                 extra["ep"] = {k: results[True][k] for k in sub}
-        # primary: the faster of the two forms that ran (both are in the line as "ep" / "dp").  configs[1]'s experts
+        # primary: the fastest of the forms that ran (all are in the line as "ep" / "dp" / "dp_shared_stem").  configs[1]'s experts
         # (E = 16 x 0.6 MB) fit one GPU many times over, so sharding them is a choice, not a need: expert parallelism moves
         # ~3.7 GB of routed rows per step and rank through the xGMI links (DESIGN.md section 6 has the predicted table) where
         # data parallelism moves one 172 MB gradient all-reduce - north_star asks for the all-to-all "only where experts shard"
-        ran = [r for r in (results.get(True), results.get(False)) if r is not None]
+        ran = [r for r in (results.get(True), results.get(False), results.get("dp_shared_stem")) if r is not None]
         main_res = max(ran, key=lambda r: r["value"]) if ran else None
         if main_res is None:
             if rank == 0:

@@ -58,6 +58,14 @@ class BackboneConfig:
         f_patch = 2 * (N - 1) * (self.in_chans * self.patch_size ** 2) * D
         return f_attn + f_dense + f_moe + f_patch
 
+    def stem_flops_per_image(self):
+        """forward FLOPs of the task-independent stem: patch embedding + the (dense) blocks below the first MoE block"""
+        N, D = self.num_tokens, self.embed_dim
+        Hd = int(D * self.mlp_ratio)
+        s = next((i for i in range(self.depth) if self.is_moe(i)), self.depth)
+        f_block = 2 * N * D * 3 * D + 4 * N * N * D + 2 * N * D * D + 4 * N * D * Hd
+        return s * f_block + 2 * (N - 1) * (self.in_chans * self.patch_size ** 2) * D
+
 
 VIT_SMALL_MOE = dict(img_size=(224, 224), embed_dim=384, depth=12, num_heads=12, mlp_ratio=4.0, moe_mlp_ratio=1.0,
                      moe_experts=16, moe_top_k=4, gate_dim=386, multi_gate=True)
