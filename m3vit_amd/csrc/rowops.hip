@@ -101,7 +101,7 @@ __global__ __launch_bounds__(ROW_THREADS) void combine_bwd_kernel(const float *_
 }
 
 // ----------------------------------------------------------------- layernorm
-template <typename T>
+template <typename T, int NCH>
 __global__ __launch_bounds__(ROW_THREADS) void layernorm_fwd_kernel(const float *__restrict__ x, int64_t T_, int D,
                                                                     const float *__restrict__ gamma,
                                                                     const float *__restrict__ beta, float eps,
@@ -111,21 +111,35 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_fwd_kernel(const float 
   const int64_t t = (int64_t)blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
   if (t >= T_) return;
   const float *xr = x + t * D;
-  // D <= 1024: at most 4 vectors per lane, kept in registers between the passes
-  f32x4 v[4];
+  // NCH = ceil(D / 256) 16-byte vectors per lane, kept in registers between the passes.  Every load of the row - and gamma /
+  // beta, which are only needed after the two reductions - is unconditional (lanes past D re-read column 0 and contribute
+  // zeros) and issued up front: a load under `if (d < D)` is its own basic block with its own wait (see layernorm_bwd_kernel).
+  f32x4 v[NCH], g[NCH], b[NCH];
+  bool on[NCH];
+  int col[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    on[i] = lane * 4 + i * 256 < D;
+    col[i] = on[i] ? lane * 4 + i * 256 : 0;
+    v[i] = *(const f32x4 *)(xr + col[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    g[i] = *(const f32x4 *)(gamma + col[i]);
+    b[i] = *(const f32x4 *)(beta + col[i]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int d = lane * 4 + i * 256;
-    v[i] = (d < D) ? *(const f32x4 *)(xr + d) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NCH; ++i) {
+    if (!on[i]) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
   }
   const float mu = wave_sum(s) / (float)D;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int d = lane * 4 + i * 256;
-    if (d < D) {
+  for (int i = 0; i < NCH; ++i) {
+    if (on[i]) {
       const f32x4 c = v[i] - mu;
       q += c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3];
     }
@@ -133,12 +147,10 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_fwd_kernel(const float 
   const float var = wave_sum(q) / (float)D;
   const float rs = 1.0f / sqrtf(var + eps);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int d = lane * 4 + i * 256;
-    if (d < D) {
-      const f32x4 g = *(const f32x4 *)(gamma + d), b = *(const f32x4 *)(beta + d);
-      const f32x4 o = (v[i] - mu) * rs * g + b;
-      Vec4<T>::store(y + t * D + d, o);
+  for (int i = 0; i < NCH; ++i) {
+    if (on[i]) {
+      const f32x4 o = (v[i] - mu) * rs * g[i] + b[i];
+      Vec4<T>::store(y + t * D + col[i], o);
     }
   }
   if (lane == 0) { mean[t] = mu; rstd[t] = rs; }
@@ -578,14 +590,12 @@ extern "C" int m3_layernorm_fwd(const float *x, int64_t T, int D, const float *g
   M3_REQUIRE(D % 4 == 0 && D > 0 && D <= 1024, "m3_layernorm_fwd: D must be a multiple of 4 and <= 1024 (got %d)", D);
   if (T == 0) return M3_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (y_dtype == M3_F16)
-    hipLaunchKernelGGL(layernorm_fwd_kernel<half_t>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, x, T, D, gamma, beta,
-                       eps, (half_t *)y, mean, rstd);
-  else if (y_dtype == M3_BF16)     hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, x, T, D, gamma, beta,
-                       eps, (bf16_t *)y, mean, rstd);
-  else
-    hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, x, T, D, gamma, beta,
-                       eps, (float *)y, mean, rstd);
+  const int nch = (D + 255) / 256;
+#define M3_LNF(TT, NC) hipLaunchKernelGGL((layernorm_fwd_kernel<TT, NC>), dim3(row_blocks(T)), dim3(ROW_THREADS), 0, s, x, T, D, gamma, beta, eps, (TT *)y, mean, rstd)
+#define M3_LNF_N(TT) do { if (nch == 1) M3_LNF(TT, 1); else if (nch == 2) M3_LNF(TT, 2); else if (nch == 3) M3_LNF(TT, 3); else M3_LNF(TT, 4); } while (0)
+  if (y_dtype == M3_F16) M3_LNF_N(half_t); else if (y_dtype == M3_BF16) M3_LNF_N(bf16_t); else M3_LNF_N(float);
+#undef M3_LNF_N
+#undef M3_LNF
   return check_launch("m3_layernorm_fwd");
 }
 
