@@ -421,15 +421,11 @@ __global__ void assemble_tokens_kernel(const float *__restrict__ patch, const fl
   }
 }
 
-}  // namespace m3
-
-using namespace m3;
-
 // Input gradient of an MoE layer's branch point: the k routed copies of a token (MOEScatter's backward: a gather-sum,
 // custom_moe_layer.py:254-259 / fmoe functions.py MOEScatter.backward) plus the gate's share d logits @ w_gate^T
-// (the backward of `inp @ w_gate`, noisy_gate_vmoe.py:91).  One wave per row; the E rows of w_gate^T live in LDS as
-// [E][D] fp32 (a lane reads its 4 columns of every expert row as one 16-byte access), the token's E logit gradients are
-// wave-uniform scalars.  Replaces a [T,k,D] -> [T,D] sum pass plus a K = E GEMM pass that re-read and re-wrote the
+// (the backward of `inp @ w_gate`, noisy_gate_vmoe.py:91).  A wave takes CG_ROWS rows per pass; the E rows of w_gate^T live
+// in LDS as [E][D + 4] fp32 (a lane reads its 4 columns of every expert row as one 16-byte access, shared by the pass's
+// rows), the tokens' E logit gradients are wave-uniform scalars.  Replaces a [T,k,D] -> [T,D] sum pass plus a K = E GEMM pass that re-read and re-wrote the
 // fp32 [T,D] result.
 constexpr int CG_THREADS = 512;    // 8 waves share one LDS image of w_gate^T
 constexpr int CG_ROWS = 2;         // rows per wave and pass (4: 142 VGPRs, 3 waves per SIMD)
@@ -526,6 +522,10 @@ __global__ __launch_bounds__(CG_THREADS) void combine_gate_bwd_kernel(const T *_
         if (on[c] && t0 + r < T_) *(f32x4 *)(out + (t0 + r) * D + c * 256 + lane * 4) = acc[r][c];
   }
 }
+
+}  // namespace m3
+
+using namespace m3;
 
 static inline unsigned row_blocks(int64_t T) { return (unsigned)((T + 3) / 4); }
 
