@@ -11,6 +11,9 @@ grand-child is joined by wait_stream (engine._join_wgrad) and the task streams a
     pooled   events come from a pool created (and already recorded once, in a warm-up run) BEFORE the capture and are
              re-recorded inside it - what BackboneEngine._event() does
     single   the single-level pattern (grand-children forked from the capturing stream itself), the known-good control
+    prefork  nested as `pooled`, but the capturing stream first forks EVERY stream (task and grand-child) itself, so that no
+             stream enters the capture through a stream that is itself a fork
+    prefork_join  `prefork`, and the grand-children are also joined straight into the capturing stream at the end
 
     python tools/nested_capture_probe.py            # runs all variants, prints one RESULT line each
 """
@@ -23,6 +26,7 @@ import torch
 def pattern(variant: str):
     dev = torch.device("cuda:0")
     nested = variant != "single"
+    prefork = variant.startswith("prefork")
     n_task = 2
     bufs = [torch.zeros(1 << 20, device=dev) for _ in range(n_task)]
     outs = [torch.zeros(1 << 20, device=dev) for _ in range(n_task)]
@@ -60,12 +64,12 @@ def pattern(variant: str):
             for i in range(n_task):
                 task_body(i)
             return
-        for st in tasks:
+        for st in tasks + (wgs if prefork else []):
             st.wait_stream(main)
         for i, st in enumerate(tasks):
             with torch.cuda.stream(st):
                 task_body(i)
-        for st in tasks:
+        for st in tasks + (wgs if variant == "prefork_join" else []):
             main.wait_stream(st)
 
     side = torch.cuda.Stream(device=dev)
@@ -93,7 +97,7 @@ if __name__ == "__main__":
         import faulthandler
         faulthandler.enable()
         sys.exit(0 if pattern(sys.argv[1]) else 4)
-    for v in ("single", "fresh", "pooled"):
+    for v in ("single", "fresh", "pooled", "prefork", "prefork_join"):
         r = subprocess.run([sys.executable, __file__, v], capture_output=True, text=True, timeout=300)
         tail = (r.stdout + r.stderr).strip().splitlines()[-12:]
         print(f"RESULT {v}: exit code {r.returncode}" + (" (signal)" if r.returncode < 0 else ""), flush=True)
