@@ -133,33 +133,51 @@ constexpr int EP_MAX_BLOCKS = 64 * 64;       // W * E_loc (sources x local exper
 __global__ __launch_bounds__(256) void ep_plan_kernel(const int64_t *send, const int64_t *recv, int W, int E_loc,
                                                       int64_t *splits, int32_t *rg, int64_t rg_cap, int32_t *offsets,
                                                       int32_t *tile_starts) {
-  __shared__ int32_t src_start[EP_MAX_BLOCKS];    // [s * E_loc + e]: first received row of block (s, e)
+  __shared__ int32_t src_start[EP_MAX_BLOCKS + 1]; // [s * E_loc + e]: first received row of block (s, e)
   __shared__ int32_t em_start[EP_MAX_BLOCKS + 1]; // [e * W + s]: first expert-major slot of block (e, s)
-  const int nb = W * E_loc;
-  if (threadIdx.x == 0) {
-    int32_t o = 0;
-    for (int b = 0; b < nb; ++b) { src_start[b] = o; o += (int32_t)recv[b]; }
-    o = 0;
-    int32_t ts = 0;
-    for (int e = 0; e < E_loc; ++e) {
-      if (blockIdx.x == 0) { offsets[e] = o; tile_starts[e] = ts; }
-      const int32_t o0 = o;
-      for (int s = 0; s < W; ++s) { em_start[e * W + s] = o; o += (int32_t)recv[s * E_loc + e]; }
-      ts += (o - o0 + 127) / 128;
+  __shared__ int32_t part[256];
+  const int nb = W * E_loc, tid = threadIdx.x;
+  // both prefix sums by the whole workgroup (a contiguous run of blocks per thread + a 256-wide scan of the run sums): with
+  // W * E_loc up to 4096 one thread walking 2 x nb dependent global loads in every workgroup was the critical path in front of
+  // the host's read of the split sizes
+  const int per = (nb + 255) / 256;
+  const int b0 = tid * per < nb ? tid * per : nb, b1 = b0 + per < nb ? b0 + per : nb;
+  auto scan = [&](auto get, int32_t *out) {          // out[b] = sum_{b' < b} get(b'), out[nb] = total
+    int32_t sum = 0;
+    for (int q = b0; q < b1; ++q) sum += get(q);
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const int32_t v = tid >= off ? part[tid - off] : 0;
+      __syncthreads();
+      part[tid] += v;
+      __syncthreads();
     }
-    em_start[nb] = o;
-    if (blockIdx.x == 0) {
-      offsets[E_loc] = o;
-      tile_starts[E_loc] = ts;
-      for (int d = 0; d < W; ++d) {
-        int64_t a = 0, b = 0;
-        for (int e = 0; e < E_loc; ++e) { a += send[d * E_loc + e]; b += recv[d * E_loc + e]; }
-        splits[d] = a;            // rows this rank sends to rank d
-        splits[W + d] = b;        // rows this rank receives from rank d
+    int32_t o = part[tid] - sum;
+    for (int q = b0; q < b1; ++q) { out[q] = o; o += get(q); }
+    if (tid == 255) out[nb] = part[255];
+    __syncthreads();
+  };
+  scan([&](int q) { return (int32_t)recv[q]; }, src_start);                                   // order (s, e); src_start[nb] unused
+  scan([&](int q) { const int e = q / W, sr = q - e * W; return (int32_t)recv[sr * E_loc + e]; }, em_start);   // order (e, s)
+  if (blockIdx.x == 0) {
+    if (tid == 0) {
+      int32_t ts = 0;
+      for (int e = 0; e < E_loc; ++e) {
+        offsets[e] = em_start[e * W];
+        tile_starts[e] = ts;
+        ts += (em_start[(e + 1) * W] - em_start[e * W] + 127) / 128;
       }
+      offsets[E_loc] = em_start[nb];
+      tile_starts[E_loc] = ts;
+    }
+    for (int d = tid; d < W; d += 256) {
+      int64_t a_ = 0, b_ = 0;
+      for (int e = 0; e < E_loc; ++e) { a_ += send[d * E_loc + e]; b_ += recv[d * E_loc + e]; }
+      splits[d] = a_;            // rows this rank sends to rank d
+      splits[W + d] = b_;        // rows this rank receives from rank d
     }
   }
-  __syncthreads();
   const int64_t n = em_start[nb] < rg_cap ? em_start[nb] : rg_cap;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     int lo = 0, hi = nb - 1;                      // last block with em_start <= i

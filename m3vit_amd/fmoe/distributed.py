@@ -3,8 +3,11 @@ wraps a module, forwards *args/**kwargs, and `.allreduce_params()` averages the 
 parameter whose dp_comm is not "none" over the data-parallel group - one flat RCCL all-reduce per
 dtype (xGMI is point-to-point: a few large collectives beat many small ones).  The flat buffer is laid out ONCE:
 every such parameter's .grad becomes a view of it, autograd then accumulates in place and the collective runs on
-the buffer directly - no gather / scatter passes over the gradients per step (a .grad that was re-created, e.g. by
-zero_grad(set_to_none=True), is copied into its view once and re-pointed)."""
+the buffer directly - no gather / scatter passes over the gradients per step, PROVIDED the .grad attributes survive between
+steps: call this wrapper's `zero_grad()` (it zeroes the flat buffers and keeps the views installed) or the optimizer's
+`zero_grad(set_to_none=False)`.  After torch's default `zero_grad(set_to_none=True)`, as the reference trainer calls it, every
+.grad is re-created by autograd; `allreduce_params` then gathers them with ONE `torch.cat` into the flat buffer (the pass it
+was written to avoid, but not hundreds of small copies) and re-points the .grad attributes at the views again."""
 import torch
 import torch.nn as nn
 
@@ -81,11 +84,41 @@ class DistributedGroupedDataParallel(nn.Module):
             ent = (ids, flat, views)
             self._flat[key] = ent
         _, flat, views = ent
-        for q, v in zip(params, views):
-            if q.grad.data_ptr() != v.data_ptr():                     # first time, or the trainer dropped the old .grad
-                v.copy_(q.grad)
+        foreign = [i for i, (q, v) in enumerate(zip(params, views)) if q.grad.data_ptr() != v.data_ptr()]
+        if len(foreign) * 2 > len(params):
+            # first time, or the trainer dropped the .grad attributes (zero_grad(set_to_none=True)): one gather pass
+            torch.cat([q.grad.reshape(-1) for q in params], out=flat)
+            for q, v in zip(params, views):
                 q.grad = v
+        else:
+            for i in foreign:                                         # a few stragglers
+                views[i].copy_(params[i].grad)
+                params[i].grad = views[i]
         return flat, views
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Zero the gradients WITHOUT dropping the flat-buffer views (one memset per bucket); parameters outside the buckets
+        (dp_comm "none", or not yet seen by allreduce_params) are zeroed / dropped the torch way."""
+        bucketed = set()
+        for _, flat, views in getattr(self, "_flat", {}).values():
+            flat.zero_()
+        for ids, _, views in getattr(self, "_flat", {}).values():
+            bucketed.update(ids)
+        for q in self.module.parameters():
+            if id(q) in bucketed:
+                continue
+            if q.grad is not None:
+                if set_to_none:
+                    q.grad = None
+                else:
+                    q.grad.zero_()
+        # re-install the views on parameters whose .grad was replaced meanwhile
+        for ids, _, views in getattr(self, "_flat", {}).values():
+            by_id = {id(q): q for q in self.module.parameters()}
+            for pid, v in zip(ids, views):
+                q = by_id.get(pid)
+                if q is not None and (q.grad is None or q.grad.data_ptr() != v.data_ptr()):
+                    q.grad = v
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)

@@ -121,6 +121,16 @@ def _dgdp_worker(rank, world, port, q):
         w.allreduce_params()
         assert m["dense"].weight.grad.data_ptr() == ptr
         assert torch.allclose(m["dense"].weight.grad, torch.full((3, 4), 3.0))    # mean of 2 rows x (1 | 2) = (2 + 4) / 2
+        # the wrapper's own zero_grad keeps the views installed (one memset): the next backward accumulates straight into the
+        # flat buffer and allreduce_params moves nothing; the expert (dp_comm "none") gradients are zeroed the torch way
+        w.zero_grad()
+        assert m["dense"].weight.grad.data_ptr() == ptr and float(flat.abs().sum()) == 0.0
+        assert float(m["experts"].weight.grad.abs().sum()) == 0.0
+        m["dense"](x).sum().backward()
+        assert m["dense"].weight.grad.data_ptr() == ptr                       # autograd accumulated in place
+        w.allreduce_params()
+        assert m["dense"].weight.grad.data_ptr() == ptr
+        assert torch.allclose(m["dense"].weight.grad, torch.full((3, 4), 3.0))
         q.put((rank, "ok"))
     except Exception:                                # pragma: no cover
         import traceback

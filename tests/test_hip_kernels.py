@@ -352,7 +352,8 @@ def test_ep_plan_kernel_matches_the_host_plan(ops):
     configs[1] (W = 8, 2 experts per rank, 100 864 rows per rank) and configs[3] (W = 8, 8 per rank) sizes."""
     from m3vit_amd.ep import ExchangePlan
     g = torch.Generator().manual_seed(5)
-    cases = [(1, 4, 40), (2, 2, 40), (4, 4, 300), (8, 8, 200), (3, 5, 17), (8, 2, 12608), (8, 8, 1576), (64, 1, 50)]
+    cases = [(1, 4, 40), (2, 2, 40), (4, 4, 300), (8, 8, 200), (3, 5, 17), (8, 2, 12608), (8, 8, 1576), (64, 1, 50),
+             (16, 40, 30), (64, 64, 12)]          # 640 and 4096 (source, expert) blocks: several per thread of the scan
     for world, e_loc, hi in cases:
         for trial in range(3):
             send = torch.randint(0, hi, (world * e_loc,), generator=g)
