@@ -23,8 +23,12 @@ from .functional import LayerNormFn
 class VisionTransformerUpHead(nn.Module):
     def __init__(self, img_size=(480, 640), patch_size=16, embed_dim=384, num_classes=40, num_conv=4,
                  num_upsampe_layer=4, conv3x3_conv1x1=True, align_corners=False, sync_bn=False,
-                 act_dtype=torch.float32, channels=256, multi_level=False, tam=False):
+                 act_dtype=torch.float32, channels=256, multi_level=False, tam=False, amp=False):
+        """amp: run the conv / BN / resize stages under fp16 autocast on the GPU, as the reference does under its AMP step
+        (pretrain/engine/train_one_epoch.py:35-61): at 480 x 640 (8 images, 40 classes) forward + backward 33.4 -> 13.9 ms,
+        MIOpen's fp16 3x3 convolutions running at 406-475 TFLOP/s (tools/head_bench.py)."""
         super().__init__()
+        self.amp = bool(amp)
         self.multi_level, self.tam = bool(multi_level), bool(tam)       # p['multi_level'], p['model_kwargs']['tam'] (:96-105)
         if (num_conv, num_upsampe_layer) not in ((4, 4), (2, 2), (2, 1)):
             raise NotImplementedError("supported stacks: num_conv / num_upsampe_layer = 4/4, 2/2, 2/1")
@@ -64,6 +68,12 @@ class VisionTransformerUpHead(nn.Module):
             x = LayerNormFn.apply(x.contiguous().float(), self.norm.weight, self.norm.bias, self.norm.eps,
                                   self.act_dtype).float()
             x = x.transpose(1, 2).reshape(n, c, self.h, self.w)
+        if self.amp and x.is_cuda:
+            with torch.autocast("cuda", dtype=torch.float16):
+                return self._stages(x)
+        return self._stages(x)
+
+    def _stages(self, x):
         if self.num_conv == 2:
             x = F.relu(self.syncbn_fc_0(self.conv_0(x)))
             if self.num_upsampe_layer == 2:

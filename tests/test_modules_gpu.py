@@ -489,6 +489,33 @@ def test_origin_convention_matches_ckpt_convention(std):
     assert float(collect_noisy_gating_loss(b, 1.0)) == 0.0
 
 
+def test_head_amp_option_matches_fp32_head():
+    """VisionTransformerUpHead(amp=True): the conv / BN / resize stages under fp16 autocast (the reference's AMP step) - same
+    parameters and state_dict keys as the fp32 head, outputs and parameter gradients within fp16 rounding of it."""
+    _need_gpu()
+    from m3vit_amd.heads import VisionTransformerUpHead
+    torch.manual_seed(5)
+    kw = dict(img_size=(64, 96), embed_dim=64, num_classes=7, channels=32)
+    a = VisionTransformerUpHead(**kw).cuda().train()
+    b = VisionTransformerUpHead(amp=True, **kw).cuda().train()
+    assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+    b.load_state_dict(a.state_dict())
+    tok = torch.randn(3, 4 * 6 + 1, 64, device="cuda")
+    ta, tb = tok.clone().requires_grad_(), tok.clone().requires_grad_()
+    ya, yb = a(ta), b(tb)
+    assert ya.shape == yb.shape == (3, 7, 64, 96) and yb.dtype in (torch.float16, torch.float32)
+    assert rel(yb, ya) < 2e-2
+    d = torch.randn_like(ya)
+    (ya * d).sum().backward()
+    (yb.float() * d).sum().backward()
+    assert rel(tb.grad, ta.grad) < 1e-1          # four BN + ReLU stages on a 3-image batch: ReLU flips near zero dominate
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if n in ("conv_0.bias", "conv_1.bias", "conv_2.bias", "conv_3.bias"):
+            continue                                   # a bias in front of a batch norm: its gradient is rounding noise in both heads
+        if pa.grad is not None and float(pa.grad.norm()) > 0:
+            assert pb.grad.dtype == torch.float32 and rel(pb.grad, pa.grad) < 1e-1, n
+
+
 def test_head_multi_level_outputs_and_tam_wiring():
     """vit_up_head.py:128-131,184-214 (multi_level: a 1x1 classifier after every upsampling) and :190-206 + models/models.py:
     246-279,313-327 (tam: the heads hand their three intermediate features to one TamModule per level, whose per-task
