@@ -25,7 +25,8 @@ CASES = [
 for name, B, kw, ntasks in CASES:
     cfg = BackboneConfig(**kw)
     tasks = list(range(ntasks)) if (cfg.multi_gate or cfg.gate_task_specific_dim >= 0) else [None]
-    run = MultiTaskStep(cfg, init_params(cfg, seed=1), batch=B, dtype=torch.float16, tasks=tasks)
+    run = MultiTaskStep(cfg, init_params(cfg, seed=1), batch=B, dtype=torch.float16, tasks=tasks,
+                        share_stem="--no-share-stem" not in sys.argv)
     run.bind(torch.randn(B, 3, *cfg.img_size).cuda(), (torch.randn(B, cfg.num_tokens, cfg.embed_dim) * 0.05).cuda())
     run.step()
     torch.cuda.synchronize()
@@ -41,6 +42,6 @@ for name, B, kw, ntasks in CASES:
     dt = (time.perf_counter() - t0) / n
     fl = 3.0 * cfg.fwd_flops_per_image() * B * ntasks
     print(f"{name}: {dt * 1e3:7.1f} ms/step  {B / dt:7.0f} img/s  model {fl / dt / 1e12:5.0f} TFLOP/s  ({run.launch}, "
-          f"{len(run.engs)} stream(s))", flush=True)
+          f"{len(run.engs)} stream(s){', shared stem' if run.share_stem else ''})", flush=True)
     del run
     torch.cuda.empty_cache()
