@@ -57,9 +57,12 @@ def parse():
                     "the hipGraph; with the default concurrent task streams the nested fork cannot be captured (ROCm 7.2 "
                     "faults in hipStreamEndCapture: tools/nested_capture_probe.py) and the step runs eagerly "
                     "(config.capture_refused says so); off under expert parallelism")
-    ap.add_argument("--no-share-stem", action="store_true", help="run the task-independent stem (patch embedding + the blocks "
-                    "below the first MoE block) once PER TASK PASS as the reference does, instead of once per step for all "
-                    "passes (MultiTaskStep share_stem: same gradients); N = 1 reports that schedule as \"per_task_stems\" anyway")
+    ap.add_argument("--share-stem", action="store_true", help="make the shared-stem schedule the primary figure: the "
+                    "task-independent stem (patch embedding + the blocks below the first MoE block) computed once per step for "
+                    "all task passes instead of once per pass (MultiTaskStep share_stem: same gradients).  Without the flag "
+                    "`value` is the reference's schedule - one FULL pass per task - and the shared-stem step is timed as well and "
+                    "reported as the sub-object \"shared_stem\"")
+    ap.add_argument("--no-share-stem", action="store_true", help="do not time the shared-stem schedule at all")
     ap.add_argument("--ep", action="store_true", help="N > 1: time ONLY the expert-parallel form (experts sharded over the "
                     "ranks, all-to-all over RCCL); default: expert parallel (primary, when E %% N == 0) AND data parallel")
     ap.add_argument("--dp-only", action="store_true", help="N > 1: time only the replicated-experts data-parallel form")
@@ -419,19 +422,25 @@ def main():
 
     main_res = None
     if world == 1:
-        # The step's schedule: every task pass of a step reads the same images (train/train_utils.py:248-256) and the patch
-        # embedding + block 0 see neither task id nor gate, so they are computed once per step and their backward runs once on
-        # the summed d x (m3vit_amd/step.py share_stem; identical gradients: tests/test_engine.py::
-        # test_shared_stem_step_matches_per_task_stems).  The reference's own schedule - one FULL pass per task, 24 instead of
-        # 23 block passes - is timed as well and reported beside it as "per_task_stems".
-        share = not args.no_share_stem and not args.serial_tasks
+        # `value` is the reference's schedule: one FULL backbone pass per task.  Every task pass of a step reads the same images
+        # (train/train_utils.py:248-256) and the patch embedding + block 0 see neither task id nor gate, so they can be computed
+        # once per step with their backward on the summed d x (m3vit_amd/step.py share_stem; identical gradients:
+        # tests/test_engine.py::test_shared_stem_step_matches_per_task_stems) - 23 instead of 24 block passes.  That step is
+        # timed too and reported BESIDE the headline as "shared_stem" (or as the headline with --share-stem, then with the
+        # reference's schedule beside it as "per_task_stems").
+        can_share = not args.serial_tasks and not args.no_share_stem
+        share = bool(args.share_stem) and can_share
         main_res = run_mode(args.dtype, False, True, share_stem=share)
-        if share:
-            pt = attempt("per_task_stems", lambda: run_mode(args.dtype, False, False, share_stem=False))
-            if pt is not None:
-                extra["per_task_stems"] = {"value": pt["value"], "ms_per_step": pt["ms_per_step"], "launch": pt["launch"],
-                                           "model_tflops": pt["model_tflops"],
-                                           "note": "the reference's schedule: patch embedding + block 0 computed by every task pass"}
+        if can_share:
+            other = "per_task_stems" if share else "shared_stem"
+            ot = attempt(other, lambda: run_mode(args.dtype, False, False, share_stem=not share))
+            if ot is not None:
+                extra[other] = {"value": ot["value"], "ms_per_step": ot["ms_per_step"], "launch": ot["launch"],
+                                "model_tflops": ot["model_tflops"],
+                                "note": ("the reference's schedule: patch embedding + block 0 computed by every task pass" if share else
+                                         "patch embedding + block 0 computed once per step for both task passes, their backward once on "
+                                         "the summed d x: same gradients, 23 instead of 24 block passes (model_tflops counts the FLOPs "
+                                         "executed)")}
         if args.dtype == "f16" and not args.no_f32:
             f32 = attempt("f32", lambda: run_mode("f32", False, True, share_stem=share))
             if f32 is not None:
@@ -457,18 +466,20 @@ def main():
         if want_ep:
             def ep_hung():
                 extra["ep_error"] = f"no result after {EP_WATCHDOG_S} s (a collective that never returned); reporting the data-parallel leg"
-                done = [r for r in (results.get(False), results.get("dp_shared_stem")) if r is not None]
+                done = [r for r in (results.get(False), results.get("dp_shared_stem") if args.share_stem else None) if r is not None]
                 if rank == 0 and done:
                     emit(max(done, key=lambda r: r["value"]))
                 os._exit(0 if done else 1)
             results[True] = attempt("ep", lambda: run_mode(args.dtype, True, False), watchdog_s=EP_WATCHDOG_S, on_timeout=ep_hung)
             if results[True] is not None:
                 extra["ep"] = {k: results[True][k] for k in sub}
-        # primary: the fastest of the forms that ran (all are in the line as "ep" / "dp" / "dp_shared_stem").  configs[1]'s experts
+        # primary: the faster of the expert-parallel and data-parallel forms that ran (in the line as "ep" / "dp"; "dp_shared_stem" beside them).  configs[1]'s experts
         # (E = 16 x 0.6 MB) fit one GPU many times over, so sharding them is a choice, not a need: expert parallelism moves
         # ~3.7 GB of routed rows per step and rank through the xGMI links (DESIGN.md section 6 has the predicted table) where
         # data parallelism moves one 172 MB gradient all-reduce - north_star asks for the all-to-all "only where experts shard"
-        ran = [r for r in (results.get(True), results.get(False), results.get("dp_shared_stem")) if r is not None]
+        # (the shared-stem leg is reported, and eligible as the primary only with --share-stem: same policy as at N = 1)
+        ran = [r for r in (results.get(True), results.get(False), results.get("dp_shared_stem") if args.share_stem else None)
+               if r is not None]
         main_res = max(ran, key=lambda r: r["value"]) if ran else None
         if main_res is None:
             if rank == 0:
