@@ -191,9 +191,7 @@ class BackboneEngine:
         self.s_dh32 = self._e(T, D, dtype=f32)
         self.s_do = self._e(T, D)
         self.s_dqkv = self._e(T, 3 * D)
-        import os
-        self._keep_dy = os.environ.get("M3_KEEP_DY") == "1"            # diagnostic A/B switch
-        self.s_dy = self._e(R, D) if (self.ep_world > 1 or self._keep_dy) else None   # local experts read score * d x straight from d x
+        self.s_dy = self._e(R, D) if self.ep_world > 1 else None       # local experts read score * d x straight from d x
         self.s_dxe = self._e(R, D)
         self.s_dscore = self._e(T, self.k, dtype=f32)
         self.s_dpatch = self._e(self.B * self.np_, D)
@@ -226,8 +224,7 @@ class BackboneEngine:
         self.gate_via_gemm = (self.E * es) % 16 == 0
         # ... and the gate's share of d h2 folded into the gather-sum of the routed rows' gradients (m3_combine_gate_bwd)
         # when w_gate^T fits its LDS image
-        import os
-        self.fused_gate_dx = self.E * (D + 4) * 4 <= 64 * 1024 and os.environ.get("M3_FUSED_GATE_DX", "1") == "1"
+        self.fused_gate_dx = self.E * (D + 4) * 4 <= 64 * 1024
         # task-conditioned gate (custom_moe_layer.py:161-181): one shared w_gate [D + gtsd, E] per MoE block
         self.task_cond = self.cfg.gate_task_specific_dim >= 0 and not self.cfg.multi_gate
         self.s_dl_t = self._e(T, self.E)
@@ -640,24 +637,12 @@ class BackboneEngine:
             else:
                 g, r = a["gate"], a["route"]
                 score = a["score_s"] if sm is not None else g["score"]
-                if self.ep_world > 1 or self._keep_dy:
+                if self.ep_world > 1:
                     self._before_write("dy")
                     ops.combine_bwd(dx, a["y"], score, self.s_dy, self.s_dscore)
                     if sm is not None:
                         self.s_dscore.mul_(a["sm_tok"])         # d score = scale * d(scale * score)
-                    if self.ep_world > 1:
-                        self._experts_bwd_ep(i, a)
-                    else:       # diagnostic path (M3_KEEP_DY=1): the materialised d y of rounds 1-2
-                        dhp = self.s_dpre[: R * self.Hm].view(R, self.Hm)
-                        self._wgrad(self.s_dy, a["hid"], b + "mlp.experts.h4toh.weight", M=R, c_row_idx=r.row_of_slot,
-                                    group_offsets=r.offsets, bias=b + "mlp.experts.h4toh.bias", reads=("dy",))
-                        self._before_write("dpre")
-                        ops.gemm_nt(self.s_dy, self.wt[b + "mlp.experts.h4toh"], dhp, M=R, gelu_grad_pre=a["hid_pre"],
-                                    a_row_idx=r.row_of_slot, a_row_div=1, group_offsets=r.offsets, tile_starts=r.tile_starts)
-                        self._wgrad(dhp, a["h2"], b + "mlp.experts.htoh4.weight", M=R, a_row_idx=r.row_of_slot,
-                                    a_row_div=k, group_offsets=r.offsets, bias=b + "mlp.experts.htoh4.bias", reads=("dpre",))
-                        ops.gemm_nt(dhp, self.wt[b + "mlp.experts.htoh4"], self.s_dxe, M=R, c_row_idx=r.row_of_slot,
-                                    group_offsets=r.offsets, tile_starts=r.tile_starts)
+                    self._experts_bwd_ep(i, a)
                 else:
                     # The combine's backward d y[t*k+j] = score[t,j] * d x[t] is a row scaling, and a row scaling commutes
                     # with the expert GEMMs behind it: FC2's input-gradient GEMM gathers its rows from d x (activation
