@@ -304,9 +304,10 @@ int m3_combine_bwd(const float *dout, const void *y, int dtype, const float *sco
  *   dh[t,:] = sum_j dxe[t*k+j,:]  +  d_logits[t,:] @ w_gate[:D,:]^T
  * the gather-sum of the k routed copies (MOEScatter.backward behind custom_moe_layer.py:254-259) and the gate's share
  * (backward of `inp @ w_gate`, noisy_gate_vmoe.py:91).  dxe [T*k, D] act dtype (token major), d_logits fp32 [T, E],
- * w_gate fp32 [D, E] (row-major, the parameter's own layout; E*D*4 bytes must fit 64 KB of LDS), dh fp32 [T, D]. */
+ * w_gate fp32 [D, E] (row-major, the parameter's own layout; E*(D+4)*4 bytes must fit 64 KB of LDS), dh [T, D] stored as
+ * dh_dtype: M3_F32 or the activation dtype (the sum is formed in fp32 either way). */
 int m3_combine_gate_bwd(const void *dxe, int dtype, int64_t T, int k, int D, const float *d_logits,
-                        const float *w_gate, int E, float *dh, void *stream);
+                        const float *w_gate, int E, void *dh, int dh_dtype, void *stream);
 
 /* Row movement of fastmoe's MOEScatter / MOEGather (custom_moe_layer.py:14,263-265) for
  * callers that run an arbitrary expert_fn between them (the fused path does not need it):

@@ -142,7 +142,7 @@ SIGNATURES = {
     "m3_colsum": (c_int, [_V, _I, _L, _V, _L, _I, _I, _V, _V, _V, _I, _V]),
     "m3_combine_fwd": (c_int, [_V, _I, _V, _V, _L, _I, _I, _V, _V]),
     "m3_combine_bwd": (c_int, [_V, _V, _I, _V, _L, _I, _I, _V, _V, _V]),
-    "m3_combine_gate_bwd": (c_int, [_V, _I, _L, _I, _I, _V, _V, _I, _V, _V]),
+    "m3_combine_gate_bwd": (c_int, [_V, _I, _L, _I, _I, _V, _V, _I, _V, _I, _V]),
     "m3_gather_rows": (c_int, [_V, _I, _V, _I, _L, _I, _I, _V, _V]),
     "m3_layernorm_fwd": (c_int, [_V, _L, _I, _V, _V, _F, _V, _I, _V, _V, _V]),
     "m3_ln_bwd_blocks": (c_int, [_L, _I]),

@@ -429,11 +429,11 @@ __global__ void assemble_tokens_kernel(const float *__restrict__ patch, const fl
 // fp32 [T,D] result.
 constexpr int CG_THREADS = 512;    // 8 waves share one LDS image of w_gate^T
 constexpr int CG_ROWS = 2;         // rows per wave and pass (4: 142 VGPRs, 3 waves per SIMD)
-template <typename T, int KT, int NCH>
+template <typename T, typename TO, int KT, int NCH>
 __global__ __launch_bounds__(CG_THREADS) void combine_gate_bwd_kernel(const T *__restrict__ dxe, int64_t T_, int k_rt, int D,
                                                                       const float *__restrict__ dl,
                                                                       const float *__restrict__ wg, int E,
-                                                                      float *__restrict__ out) {
+                                                                      TO *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];        // [E][D + 4]: the transposing fill below walks e
   const int DP = D + 4;     // fastest, and a row stride of D (a multiple of the 32 banks) would put all 64 lanes on one bank
   const int k = KT ? KT : k_rt;
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(CG_THREADS) void combine_gate_bwd_kernel(const T *_
     for (int r = 0; r < RW; ++r)
 #pragma unroll
       for (int c = 0; c < NCH; ++c)
-        if (on[c] && t0 + r < T_) *(f32x4 *)(out + (t0 + r) * D + c * 256 + lane * 4) = acc[r][c];
+        if (on[c] && t0 + r < T_) Vec4<TO>::store(out + (t0 + r) * D + c * 256 + lane * 4, acc[r][c]);
   }
 }
 
@@ -545,9 +545,10 @@ extern "C" int m3_combine_fwd(const void *y, int dtype, const float *score, cons
 }
 
 extern "C" int m3_combine_gate_bwd(const void *dxe, int dtype, int64_t T, int k, int D, const float *d_logits,
-                                   const float *w_gate, int E, float *dh, void *stream) {
+                                   const float *w_gate, int E, void *dh, int dh_dtype, void *stream) {
   M3_REQUIRE(dxe && d_logits && w_gate && dh, "m3_combine_gate_bwd: null operand");
   M3_REQUIRE(dtype_ok(dtype), "m3_combine_gate_bwd: bad dtype");
+  M3_REQUIRE(dh_dtype == M3_F32 || dh_dtype == dtype, "m3_combine_gate_bwd: dh is fp32 or the activation dtype");
   M3_REQUIRE(D % 4 == 0 && D > 0 && k >= 1 && E >= 1, "m3_combine_gate_bwd: D must be a multiple of 4");
   const size_t lds = (size_t)E * (D + 4) * sizeof(float);
   M3_REQUIRE(lds <= 64 * 1024, "m3_combine_gate_bwd: w_gate [D=%d][E=%d] does not fit the 64 KB LDS image", D, E);
@@ -558,12 +559,15 @@ extern "C" int m3_combine_gate_bwd(const void *dxe, int dtype, int64_t T, int k,
   const unsigned grid = (unsigned)(rb < 1024 ? rb : 1024);
   const int nch = (D + 255) / 256;
   M3_REQUIRE(nch <= 4 && (D * E) % 4 == 0 && ((uintptr_t)w_gate % 16) == 0, "m3_combine_gate_bwd: D <= 1024, w_gate 16-byte aligned");
-#define M3_CG(TT, KT_, NC_) hipLaunchKernelGGL((combine_gate_bwd_kernel<TT, KT_, NC_>), dim3(grid), dim3(CG_THREADS), lds, s, (const TT *)dxe, T, k, D, d_logits, w_gate, E, dh)
-#define M3_CG_N(TT, KT_) do { if (nch == 1) M3_CG(TT, KT_, 1); else if (nch == 2) M3_CG(TT, KT_, 2); else if (nch == 3) M3_CG(TT, KT_, 3); else M3_CG(TT, KT_, 4); } while (0)
+  const bool f32out = dh_dtype == M3_F32;
+#define M3_CG(TT, TO_, KT_, NC_) hipLaunchKernelGGL((combine_gate_bwd_kernel<TT, TO_, KT_, NC_>), dim3(grid), dim3(CG_THREADS), lds, s, (const TT *)dxe, T, k, D, d_logits, w_gate, E, (TO_ *)dh)
+#define M3_CG_O(TT, KT_, NC_) do { if (f32out) M3_CG(TT, float, KT_, NC_); else M3_CG(TT, TT, KT_, NC_); } while (0)
+#define M3_CG_N(TT, KT_) do { if (nch == 1) M3_CG_O(TT, KT_, 1); else if (nch == 2) M3_CG_O(TT, KT_, 2); else if (nch == 3) M3_CG_O(TT, KT_, 3); else M3_CG_O(TT, KT_, 4); } while (0)
 #define M3_CG_K(TT) do { if (k == 4) M3_CG_N(TT, 4); else if (k == 2) M3_CG_N(TT, 2); else M3_CG_N(TT, 0); } while (0)
   if (dtype == M3_F16) M3_CG_K(half_t); else if (dtype == M3_BF16) M3_CG_K(bf16_t); else M3_CG_K(float);
 #undef M3_CG_K
 #undef M3_CG_N
+#undef M3_CG_O
 #undef M3_CG
   return check_launch("m3_combine_gate_bwd");
 }

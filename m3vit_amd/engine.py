@@ -677,6 +677,7 @@ class BackboneEngine:
                                          top_logits=g["top_logits"], noise_std=g["noise_std"], out=self.s_dl)
                 # token rows of w_gate ([:D]; the task-conditioned rows [D:]: _task_feature_block_bwd below)
                 wg, dwg = p[a["wname"]][:D], gr[a["wname"]][:D]
+                dh2_moe = self.s_dh32
                 if self.gate_via_gemm:
                     # (a dedicated VALU kernel for d w_gate - m3_gate_bwd_params, 4 columns x E accumulators per thread - was
                     # measured in round 3: 24 us + 6 us partial reduce against 17.5 us for the padded TN GEMM whose reduce rides
@@ -685,7 +686,10 @@ class BackboneEngine:
                     dl_t = dl if self.dt == torch.float32 else ops.cast_f32(dl, self.s_dl_t)
                     self._fork(("dl",), lambda: ops.wgrad_tn(a["h2"], dl_t, dwg, beta=1, ws=self.ws_wgrad, queue=self.wq))
                     if self.fused_gate_dx:
-                        ops.combine_gate_bwd(self.s_dxe, k, dl, wg, self.s_dh32)     # one pass over the [T, D] result
+                        # one pass over the [T, D] result, stored in the activation dtype like a dense block's d h2 (the sum
+                        # itself is formed in fp32): the LayerNorm backward below reads half the bytes
+                        ops.combine_gate_bwd(self.s_dxe, k, dl, wg, self.s_dh)
+                        dh2_moe = self.s_dh
                     else:
                         ops.combine_fwd(self.s_dxe, self.ones_k, None, self.s_dh32)
                         wg_t = wg if self.dt == torch.float32 else self.wgate_c[a["wname"]][:D]
@@ -696,7 +700,7 @@ class BackboneEngine:
                                         beta_dx=1, part_dw=self.ws_gate_dw)
                 if self._tsf is not None:
                     self._task_feature_block_bwd(a, dl, st)
-                dh2 = self.s_dh32
+                dh2 = dh2_moe
             self._before_write("dx_t")
             ops.layernorm_bwd(dh2, a["x1"], a["mean2"], a["rstd2"], p[b + "norm2.weight"], dx, other, None, None,
                               ws=self.ws_ln[2 * i + 1],

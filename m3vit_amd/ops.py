@@ -486,13 +486,13 @@ def combine_bwd(dout, y, score, dy, dscore):
 
 
 def combine_gate_bwd(dxe, k, d_logits, w_gate, dh):
-    """dh [T, D] fp32 = sum_j dxe[t*k+j] + d_logits [T, E] @ w_gate[:D] [D, E]^T  (one pass; m3_combine_gate_bwd)"""
+    """dh [T, D] (fp32 or dxe's dtype) = sum_j dxe[t*k+j] + d_logits [T, E] @ w_gate[:D] [D, E]^T  (one pass; m3_combine_gate_bwd)"""
     T, E = d_logits.shape
     D = dxe.shape[-1]
     assert w_gate.dtype == torch.float32 and d_logits.dtype == torch.float32 and w_gate.is_contiguous()
-    assert tuple(w_gate.shape) == (D, E) and dxe.shape[0] == T * k and tuple(dh.shape) == (T, D)
-    check(lib().m3_combine_gate_bwd(_p(dxe), dt_code(dxe.dtype), T, k, D, _p(d_logits), _p(w_gate), E, _p(dh), _stream()),
-          "m3_combine_gate_bwd")
+    assert tuple(w_gate.shape) == (D, E) and dxe.shape[0] == T * k and tuple(dh.shape) == (T, D) and dh.is_contiguous()
+    check(lib().m3_combine_gate_bwd(_p(dxe), dt_code(dxe.dtype), T, k, D, _p(d_logits), _p(w_gate), E, _p(dh), dt_code(dh.dtype),
+                                    _stream()), "m3_combine_gate_bwd")
     return dh
 
 

@@ -550,6 +550,9 @@ def test_combine_gate_bwd_sums_the_routed_rows_and_adds_the_gate_share(ops, dtyp
     ops.combine_gate_bwd(dxe, k, dl, w_full[:D], out)
     ref = dxe.double().view(T, k, D).sum(1) + dl.double() @ w_full[:D].double().t()
     assert rel(out, ref) < 2e-6
+    out_t = torch.full((T, D), float("nan"), dtype=dtype, device=dev())          # stored in the activation dtype
+    ops.combine_gate_bwd(dxe, k, dl, w_full[:D], out_t)
+    assert rel(out_t, ref) < TOL[dtype] and torch.equal(out_t, out.to(dtype))
     with pytest.raises(Exception, match="LDS"):
         ops.combine_gate_bwd(rnd(8, 1024, dtype=dtype, seed=58), 1, rnd(8, 64, seed=59), rnd(1024, 64, seed=60),
                              torch.empty(8, 1024, device=dev()))
