@@ -66,7 +66,8 @@ class MultiTaskStep:
         # forward + backward instead of one per task.  Side-by-side passes without expert parallelism only.
         self.share_stem = bool(share_stem) and self.par
         self.stem = self.eng.stem_blocks if self.share_stem else 0
-        self.add_stream = torch.cuda.Stream(device=self.dev) if self.share_stem else None
+        # the gradient add runs under the stem's backward on the (then idle) first task stream: no stream of its own
+        self.add_stream = self.streams[0] if self.share_stem else None
         self.late_names = [n for n in self.eng.params if self.eng._block_of(n) < 0 and
                            not n.startswith(("patch_embed.", "cls_token", "pos_embed"))]
         # the part whose block range first reaches below the stem boundary takes the other passes' d x
