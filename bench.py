@@ -31,7 +31,8 @@ if ROOT not in sys.path:
 PEAK = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}      # dense MFMA TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM = 8000.0                          # GB/s, MI355X_MICROARCH.md
 METRIC = "images/sec fwd+bwd ViT-S/16 MoE(E=16,k=4) 224^2 bs=128"
-EP_WATCHDOG_S = 420                        # N > 1: the expert-parallel leg may not hang the whole line (see attempt())
+EP_WATCHDOG_S = 420
+SHARED_WATCHDOG_S = 240       # the optional dp_shared_stem leg (the plain dp leg takes well under a minute)
 CV_WEIGHT = 0.01                           # --moe_noisy_gate_loss_weight default (train_fastmoe.py:118; applied at train/train_utils.py:277)
 
 
@@ -457,22 +458,31 @@ def main():
             results[False] = attempt("dp", lambda: run_mode(args.dtype, False, False, share_stem=False))
             if results[False] is not None:
                 extra["dp"] = {k: results[False][k] for k in sub}
-            if not args.no_share_stem and not args.serial_tasks:
-                # the same form with the task-independent stem computed once per step (see the N = 1 branch); its own leg, so
-                # that whatever it does at its first contact with RCCL costs only itself
-                results["dp_shared_stem"] = attempt("dp_shared_stem", lambda: run_mode(args.dtype, False, False, share_stem=True))
-                if results["dp_shared_stem"] is not None:
-                    extra["dp_shared_stem"] = {k: results["dp_shared_stem"][k] for k in sub}
         if want_ep:
             def ep_hung():
                 extra["ep_error"] = f"no result after {EP_WATCHDOG_S} s (a collective that never returned); reporting the data-parallel leg"
-                done = [r for r in (results.get(False), results.get("dp_shared_stem") if args.share_stem else None) if r is not None]
+                done = [r for r in (results.get(False),) if r is not None]
                 if rank == 0 and done:
                     emit(max(done, key=lambda r: r["value"]))
                 os._exit(0 if done else 1)
             results[True] = attempt("ep", lambda: run_mode(args.dtype, True, False), watchdog_s=EP_WATCHDOG_S, on_timeout=ep_hung)
             if results[True] is not None:
                 extra["ep"] = {k: results[True][k] for k in sub}
+        if want_dp and args.share_stem and not args.serial_tasks:
+            # opt-in at N > 1 (--share-stem; no two-GPU box was ever available to try it over RCCL, and the one-GPU gloo rehearsal
+            # stalls in it): the data-parallel form with the task-independent stem computed once per step (see the N = 1 branch): LAST and under
+            # its own watchdog, so that whatever it does at its first contact with RCCL costs only itself - on a time-out the
+            # line is printed from what the legs above measured
+            def shared_hung():
+                extra["dp_shared_stem_error"] = f"no result after {SHARED_WATCHDOG_S} s; reporting the legs that finished"
+                done = [r for r in (results.get(True), results.get(False)) if r is not None]
+                if rank == 0 and done:
+                    emit(max(done, key=lambda r: r["value"]))
+                os._exit(0 if done else 1)
+            results["dp_shared_stem"] = attempt("dp_shared_stem", lambda: run_mode(args.dtype, False, False, share_stem=True),
+                                                watchdog_s=SHARED_WATCHDOG_S, on_timeout=shared_hung)
+            if results["dp_shared_stem"] is not None:
+                extra["dp_shared_stem"] = {k: results["dp_shared_stem"][k] for k in sub}
         # primary: the faster of the expert-parallel and data-parallel forms that ran (in the line as "ep" / "dp"; "dp_shared_stem" beside them).  configs[1]'s experts
         # (E = 16 x 0.6 MB) fit one GPU many times over, so sharding them is a choice, not a need: expert parallelism moves
         # ~3.7 GB of routed rows per step and rank through the xGMI links (DESIGN.md section 6 has the predicted table) where
