@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 PEAK = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}      # dense MFMA TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM = 8000.0                          # GB/s, MI355X_MICROARCH.md
 METRIC = "images/sec fwd+bwd ViT-S/16 MoE(E=16,k=4) 224^2 bs=128"
-EP_WATCHDOG_S = 420
+EP_WATCHDOG_S = 420            # N > 1: the expert-parallel leg may not hang the whole line (see attempt())
 SHARED_WATCHDOG_S = 240       # the optional dp_shared_stem leg (the plain dp leg takes well under a minute)
 CV_WEIGHT = 0.01                           # --moe_noisy_gate_loss_weight default (train_fastmoe.py:118; applied at train/train_utils.py:277)
 
