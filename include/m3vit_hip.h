@@ -96,7 +96,10 @@ int m3_balance_loss(const float *part_importance, const int32_t *part_load, cons
  * d_score [T,k] (from the combine), d_top [T,min(k+1,E)] (w.r.t. top_logits), d_importance [E] and
  * d_load_prob [E] (from m3_balance_loss; both multiplied by balance_scale = the loss weight).
  * probs are recomputed from `noisy` [T,E]; clean / top_logits / idx_next / noise_std are only read
- * for d_load_prob (and idx_next for d_top). */
+ * for d_load_prob (and idx_next for d_top).  balance_scale_dev (may be NULL): one device-resident float that multiplies
+ * balance_scale - the upstream gradient of cv_loss when the caller is torch.autograd (the reference forms
+ * cv_loss * moe_noisy_gate_loss_weight, train/train_utils.py:277, and autograd hands the weight back as a tensor); read
+ * by the kernel, so a captured launch follows its value. */
 typedef struct m3_gate_bwd_args {
   const float *noisy; const float *clean; const float *top_logits;
   const int64_t *idx; const int32_t *idx_next;
@@ -104,6 +107,7 @@ typedef struct m3_gate_bwd_args {
   float balance_scale; float noise_std;
   int64_t T; int32_t E; int32_t k;
   float *d_logits;
+  const float *balance_scale_dev;
 } m3_gate_bwd_args;
 int m3_gate_bwd_logits(const m3_gate_bwd_args *args, void *stream);
 /* d_w_gate[D,E] (+)= x^T d_logits ; dx[T,D] (+)= d_logits w_gate^T  (noisy_gate_vmoe.py:91).

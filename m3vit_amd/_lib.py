@@ -108,7 +108,7 @@ class GateBwdArgs(Structure):
         ("d_score", c_void_p), ("d_top", c_void_p), ("d_importance", c_void_p), ("d_load_prob", c_void_p),
         ("balance_scale", c_float), ("noise_std", c_float),
         ("T", c_int64), ("E", c_int32), ("k", c_int32),
-        ("d_logits", c_void_p),
+        ("d_logits", c_void_p), ("balance_scale_dev", c_void_p),
     ]
 
 

@@ -371,6 +371,7 @@ struct GateBwdDev {
   float balance_scale; float noise_std;
   int64_t T; int E; int k;
   float *d_logits;
+  const float *balance_scale_dev;
 };
 
 template <int EPAD>
@@ -380,6 +381,9 @@ __global__ __launch_bounds__(256) void gate_bwd_logits_kernel(const GateBwdDev p
   const int E = p.E, k = p.k;
   const int kp = (k + 1 < E) ? k + 1 : E;
   const float *nzp = p.noisy + t * E;
+  // the loss weight: a launch constant, times an optional device-resident factor (the upstream gradient of the loss when the
+  // caller is an autograd graph replayed from a hipGraph: its value is not known on the host at launch time)
+  const float bscale = p.balance_scale_dev ? p.balance_scale * p.balance_scale_dev[0] : p.balance_scale;
   float pr[EPAD], dp[EPAD], g[EPAD];
   float m = nzp[0];
 #pragma unroll
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(256) void gate_bwd_logits_kernel(const GateBwdDev p
       if (e < E) {
         const bool is_in = g[e] > thr_in;
         const float z = (clp[e] - (is_in ? thr_in : thr_out)) * inv_std;
-        const float ge = p.d_load_prob[e] * p.balance_scale * normal_pdf(z) * inv_std;
+        const float ge = p.d_load_prob[e] * bscale * normal_pdf(z) * inv_std;
         g[e] = ge;
         if (is_in) d_thr_in -= ge; else d_thr_out -= ge;
       }
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(256) void gate_bwd_logits_kernel(const GateBwdDev p
   for (int j = 0; j < k; ++j) {
     const int ej = (int)p.idx[t * k + j];
     float v = (p.d_score ? p.d_score[t * k + j] : 0.f) + (p.d_top ? p.d_top[t * kp + j] : 0.f) +
-              (p.d_importance ? p.d_importance[ej] * p.balance_scale : 0.f);
+              (p.d_importance ? p.d_importance[ej] * bscale : 0.f);
     if (j == k - 1) v += d_thr_out;
 #pragma unroll
     for (int e = 0; e < EPAD; ++e)
@@ -677,6 +681,7 @@ extern "C" int m3_gate_bwd_logits(const m3_gate_bwd_args *a, void *stream) {
   d.d_score = a->d_score; d.d_top = a->d_top; d.d_importance = a->d_importance; d.d_load_prob = a->d_load_prob;
   d.balance_scale = a->balance_scale; d.noise_std = a->noise_std; d.T = a->T; d.E = a->E; d.k = a->k;
   d.d_logits = a->d_logits;
+  d.balance_scale_dev = a->balance_scale_dev;
   const dim3 grid((unsigned)((a->T + 255) / 256));
   hipStream_t s = (hipStream_t)stream;
   switch (epad_of(a->E)) {

@@ -168,8 +168,11 @@ __device__ __forceinline__ bool wgrad_ride_along(const WgradDev &p, int tid, int
 // applied where the row enters the LDS image, so that the scaled [T*k, D] copy never exists in memory)
 template <typename T> __device__ __forceinline__ u32x4 scale_chunk(u32x4 v, float s);
 template <> __device__ __forceinline__ u32x4 scale_chunk<half_t>(u32x4 v, float s) {
-  const half_t h = (half_t)s;
-  const f16x8 f = __builtin_bit_cast(f16x8, v) * f16x8{h, h, h, h, h, h, h, h};      // 4 x v_pk_mul_f16
+  // fp32 product, ONE rounding - the value the dgrad GEMM's fp32 epilogue forms for the same row (a fp16 multiply would round
+  // the score to 11 bits first: the two consumers of d y = score * d out would then see different rows)
+  f16x8 f = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (half_t)((float)f[j] * s);
   return __builtin_bit_cast(u32x4, f);
 }
 template <> __device__ __forceinline__ u32x4 scale_chunk<bf16_t>(u32x4 v, float s) {

@@ -280,6 +280,10 @@ class BackboneEngine:
 
     def zero_grad(self):
         self.flat_grads.zero_()
+        if self.wq is not None:
+            # a step that aborted between a queued weight-gradient call and flush() leaves a slab-reduction descriptor behind
+            # whose slabs were never (fully) written; it must not ride in front of THIS step's first launch
+            self.wq.reset()
 
     # ------------------------------------------------------------- checkpoints
     def state_dict(self):
@@ -592,16 +596,18 @@ class BackboneEngine:
         self._fork(reads, lambda: ops.wgrad_tn(dC, A, self.grads[name], M=M, beta=1, ws=self.ws_wgrad, queue=self.wq,
                                                db=self.grads[bias] if bias is not None else None, **kw))
 
-    def backward(self, d_tokens: torch.Tensor, cv_weight: float = 0.0):
+    def backward(self, d_tokens: torch.Tensor, cv_weight=0.0):
         """Accumulates parameter gradients of  <tokens, d_tokens> + cv_weight * total_cv_loss
-        into self.grads (beta = 1: the joint multi-task backward, train/train_utils.py:437-457)."""
+        into self.grads (beta = 1: the joint multi-task backward, train/train_utils.py:437-457).
+        cv_weight: a python float, or a 1-element fp32 device tensor (the upstream gradient of cv_loss handed over by
+        torch.autograd - read by the gate's backward kernel, so a captured backward follows its value)."""
         self.backward_begin(d_tokens, cv_weight)
         self.backward_blocks(self.depth - 1, 0)
         return self.backward_end()
 
     # The backward in three resumable pieces, so that a data-parallel trainer can all-reduce the gradients
     # of the upper blocks (complete after backward_blocks(depth-1, s)) while the lower blocks still run.
-    def backward_begin(self, d_tokens: torch.Tensor, cv_weight: float = 0.0):
+    def backward_begin(self, d_tokens: torch.Tensor, cv_weight=0.0):
         self._ev_i = 0
         dx = self.s_dxa
         dx.copy_(d_tokens.reshape(self.T, self.D))
@@ -669,10 +675,12 @@ class BackboneEngine:
                     ops.gemm_nt(dhp, self.wt[b + "mlp.experts.htoh4"], self.s_dxe, M=R, c_row_idx=r.row_of_slot,
                                 group_offsets=r.offsets, tile_starts=r.tile_starts)
                 # gate: d score from the combine, d importance / d load from the cv loss
-                bal = cv_weight != 0.0
+                cvw_dev = cv_weight if isinstance(cv_weight, torch.Tensor) else None
+                bal = cvw_dev is not None or cv_weight != 0.0
                 self._before_write("dl")
                 dl = ops.gate_bwd_logits(g["noisy"], g["idx"], self.s_dscore, g["d_importance"] if bal else None, k,
-                                         balance_scale=cv_weight, idx_next=g["idx_next"],
+                                         balance_scale=1.0 if cvw_dev is not None else cv_weight, balance_scale_dev=cvw_dev,
+                                         idx_next=g["idx_next"],
                                          d_load_prob=g["d_load_prob"] if bal else None, clean=g["clean"],
                                          top_logits=g["top_logits"], noise_std=g["noise_std"], out=self.s_dl)
                 # token rows of w_gate ([:D]; the task-conditioned rows [D:]: _task_feature_block_bwd below)

@@ -85,15 +85,16 @@ class DistributedGroupedDataParallel(nn.Module):
             self._flat[key] = ent
         _, flat, views = ent
         foreign = [i for i, (q, v) in enumerate(zip(params, views)) if q.grad.data_ptr() != v.data_ptr()]
-        if len(foreign) * 2 > len(params):
-            # first time, or the trainer dropped the .grad attributes (zero_grad(set_to_none=True)): one gather pass
+        if len(foreign) == len(params):
+            # first time, or the trainer dropped every .grad (zero_grad(set_to_none=True)): one gather pass.  Only when NO
+            # gradient aliases the buffer - torch.cat(out=flat) refuses inputs that overlap its output
             torch.cat([q.grad.reshape(-1) for q in params], out=flat)
-            for q, v in zip(params, views):
-                q.grad = v
-        else:
-            for i in foreign:                                         # a few stragglers
-                views[i].copy_(params[i].grad)
-                params[i].grad = views[i]
+        elif foreign:
+            # a mix (an optimizer whose zero_grad covers part of the parameters, re-created gradients next to kept views):
+            # gather only the foreign ones, one batched copy
+            torch._foreach_copy_([views[i] for i in foreign], [params[i].grad for i in foreign])
+        for i in foreign:
+            params[i].grad = views[i]
         return flat, views
 
     def zero_grad(self, set_to_none: bool = False):

@@ -1,0 +1,334 @@
+"""VisionTransformerMoE.forward as ONE autograd node per call, on the straight-line executor.
+
+What the reference's trainer calls (models/models.py:299-320: `self.backbone(x, task_id=...)` once per task, then one
+`loss.backward()`, train/train_utils.py:423-457) is the module API of m3vit_amd.vit.  Built from per-op autograd Functions
+(m3vit_amd.functional) that API pays per call for what the fused executor (m3vit_amd.engine.BackboneEngine) does once per
+step or not at all: operand copies of every weight, separate bias-gradient passes, materialised d y, ~700 tensor
+allocations and ~1500 Python-issued launches.  FusedBackbone puts the executor behind the same `forward(x, task_id)`:
+
+  * the module's nn.Parameters ARE the executor's fp32 masters (same storage); their `.grad` attributes are views of the
+    executor's flat gradient buffer, so `optimizer.step()`, `DistributedGroupedDataParallel.allreduce_params()`
+    (fmoe/distributed.py) and `zero_grad(set_to_none=True/False)` work as they do on any module;
+  * one forward = one torch.autograd.Function node (tokens [B, N, D] fp32 and the summed balance loss come out, d tokens
+    and d cv_loss go in); every call that is still waiting for its backward owns an executor context ("slot": activations,
+    scratch, gradient buffer, HIP stream).  Forward and backward of a slot are captured into hipGraphs at their second
+    use and replayed from then on (the upstream gradient of cv_loss reaches the gate's backward kernel as a device
+    scalar: m3_gate_bwd_args.balance_scale_dev);
+  * autograd runs a node's backward on the stream of its forward, so the task passes of a joint multi-task step
+    (all forwards, one backward) run their backward passes side by side on the GPU like m3vit_amd.step.MultiTaskStep's
+    task streams; gradient buffers of the extra slots are added into slot 0's on slot 0's stream (one writer stream
+    for the buffer the `.grad` views alias), and the stream that called forward() waits for all of it.
+
+The per-op path stays for everything the executor does not cover (see `unsupported()`).
+"""
+from __future__ import annotations
+
+import weakref
+
+import torch
+
+from . import ops
+from .config import BackboneConfig
+from .engine import BackboneEngine
+
+
+class _Slot:
+    """one executor context + stream + captured graphs; owned by one forward until its backward ran"""
+
+    def __init__(self, index, eng, device):
+        self.index = index
+        self.eng = eng
+        self.stream = torch.cuda.Stream(device=device)
+        self.busy = False
+        self.calls_f, self.calls_b = {}, {}          # per task: number of forward / backward calls seen
+        self.graphs_f, self.graphs_b = {}, {}
+        self.images = self.dtok = None               # static inputs of the graphs
+        self.dcv = torch.zeros(1, dtype=torch.float32, device=device)
+        self.noises = self.path_scales = None
+        self.add_done = None                          # event: slot 0's stream has read this slot's gradient buffer
+        self.main = None                              # the stream forward() was called on
+
+
+class _BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, fb, slot, task_id, images):
+        tok, cv = fb._run_forward(slot, task_id, images)
+        ctx.fb, ctx.slot, ctx.task_id = fb, slot, task_id
+        ctx.token = _Release(fb, slot)                # returns the slot if this node dies without a backward
+        return tok, cv
+
+    @staticmethod
+    def backward(ctx, g_tok, g_cv):
+        ctx.token.done = True
+        ctx.fb._run_backward(ctx.slot, ctx.task_id, g_tok, g_cv)
+        return None, None, None, None, None
+
+
+class _Release:
+    def __init__(self, fb, slot):
+        self.fb, self.slot, self.done = weakref.ref(fb), slot, False
+
+    def __del__(self):
+        if not self.done:
+            self.slot.busy = False
+
+
+class FusedBackbone:
+    def __init__(self, model, graph: bool = True, max_slots: int = 8):
+        self.model = weakref.ref(model)
+        self.graph = bool(graph)
+        self.max_slots = max_slots
+        self.slots = []
+        self.batch = None
+        self.sig = None
+        self.dirty = True
+        self.anchor = None
+        self.names = None
+
+    # ------------------------------------------------------------------ eligibility
+    @staticmethod
+    def unsupported(model, x, gate_inp, task_id, sem):
+        """None when this call can run on the executor, else the reason it takes the per-op path"""
+        if not x.is_cuda:
+            return "CPU tensor"
+        if gate_inp is not None:
+            return "caller-supplied gate input"
+        if not model._fused_static_ok:
+            return model._fused_static_why
+        if torch.is_grad_enabled() and not model.training:
+            return "eval mode with autograd on"
+        if x.dim() != 4 or tuple(x.shape[2:]) != tuple(model.img_size):
+            return "image size differs from the constructor's"
+        if model.multi_gate and task_id is None:
+            return "multi-gate model called without a task id"
+        for blk in model.blocks:
+            if blk.moe and (blk.mlp.gate_hook is not None or blk.mlp.mask is not None):
+                return "gate hook / expert mask installed"
+        if sem is not None and any(blk.moe and blk.mlp.sem_force for blk in model.blocks):
+            return "sem_force routing override"
+        return None
+
+    # ------------------------------------------------------------------ set-up
+    def _build(self, B, device):
+        model = self.model()
+        cfg = BackboneConfig(**model._cfg_kwargs)
+        named = dict(model.named_parameters())
+        self.names = list(named)
+        params = {n: p.detach() for n, p in named.items()}
+        eng0 = BackboneEngine(cfg, params, batch=B, dtype=model.act_dtype, device=str(device),
+                              checkpoint=bool(model.use_checkpointing))
+        for n, p in named.items():
+            if eng0.params[n].data_ptr() != p.data_ptr():
+                raise RuntimeError(f"fused backbone: parameter {n} must be a contiguous fp32 CUDA tensor")
+        self.cfg, self.batch, self.device = cfg, B, device
+        self.slots = [_Slot(0, eng0, device)]
+        self.plist = [named[n] for n in eng0.params]                 # in the flat buffer's order
+        self.views = [eng0.grads[n] for n in eng0.params]
+        self.view_ptrs = [v.data_ptr() for v in self.views]
+        self.ptrs = [p.data_ptr() for p in self.plist]
+        self.anchor = torch.zeros((), device=device, requires_grad=True)
+        self.drop = {i: float(getattr(blk.drop_path, "drop_prob", 0.0)) for i, blk in enumerate(model.blocks)}
+        self.drop = {i: p for i, p in self.drop.items() if p > 0.0}
+        self.moe_blocks = [i for i in range(cfg.depth) if cfg.is_moe(i)]
+        self.dirty = True
+
+    def _slot(self):
+        for s in self.slots:
+            if not s.busy:
+                return s
+        if len(self.slots) >= self.max_slots:
+            raise RuntimeError(f"fused backbone: {self.max_slots} forward passes are waiting for their backward; "
+                               "call backward() (or drop the outputs) before running more")
+        e0 = self.slots[0].eng
+        eng = BackboneEngine(self.cfg, None, batch=self.batch, dtype=e0.dt, device=str(self.device), share=e0,
+                             checkpoint=e0.checkpoint)
+        s = _Slot(len(self.slots), eng, self.device)
+        self.slots.append(s)
+        return s
+
+    def _check_params(self):
+        """the executor reads the parameters' storage in place: a re-allocated parameter (model.to(), p.data = ...) needs
+        new contexts; a changed value (optimizer.step(), load_state_dict()) needs fresh operand copies"""
+        if [p.data_ptr() for p in self.plist] != self.ptrs:
+            self.slots, self.batch = [], None
+            return False
+        sig = [p._version for p in self.plist]
+        if sig != self.sig:
+            self.sig, self.dirty = sig, True
+        return True
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, images, task_id):
+        model = self.model()
+        B = images.shape[0]
+        dev = images.device
+        if self.batch != B or not self.slots or not self._check_params():
+            if any(s.busy for s in self.slots):
+                raise RuntimeError("fused backbone: batch size / parameter storage changed while a forward waits for its backward")
+            self._build(B, dev)
+            self._check_params()
+        train = torch.is_grad_enabled()
+        main = torch.cuda.current_stream()
+        if self.dirty:
+            # first forward after a backward (an optimizer step came in between) or after the values changed: refresh the
+            # activation-dtype operand copies W, W^T of every Linear - one launch, ~0.1 ms (engine.prepare_weights)
+            self.slots[0].eng.prepare_weights()
+            self.dirty = False
+        slot = self._slot()
+        if not train:
+            tok, cv = self._forward_eager(slot, task_id, images.float().contiguous(), False)
+            tok = tok.clone()
+            return tok, (tok.new_zeros(()) if not model.training else cv)
+        slot.busy, slot.main = True, main
+        s = slot.stream
+        s.wait_stream(main)
+        with torch.cuda.stream(s):
+            tok, cv = _BackboneFn.apply(self.anchor, self, slot, task_id, images)
+        main.wait_stream(s)
+        tok.record_stream(main)
+        cv.record_stream(main)
+        return tok, cv
+
+    def _draw(self, slot, eng):
+        """per-step random inputs of the pass, drawn outside the graphs into the slot's static buffers: gate noise
+        (noisy_gate_vmoe.py:168: randn_like(clean) * std, training only) and DropPath factors
+        (vision_transformer_moe.py:167-185: floor(keep + U) / keep per sample and residual branch)"""
+        model = self.model()
+        noises = ps = None
+        if self.cfg.vmoe_noisy_std > 0 and model.training:
+            if slot.noises is None:
+                slot.noises = {i: torch.empty(eng.T, eng.E, device=self.device) for i in self.moe_blocks}
+            for n in slot.noises.values():
+                n.normal_()
+            noises = slot.noises
+        if self.drop and model.training:
+            if slot.path_scales is None:
+                slot.path_scales = {i: (torch.empty(self.batch, device=self.device), torch.empty(self.batch, device=self.device))
+                                    for i in self.drop}
+            for i, (sa, sm) in slot.path_scales.items():
+                keep = 1.0 - self.drop[i]
+                for t in (sa, sm):
+                    t.uniform_().add_(keep).floor_().div_(keep)
+            ps = slot.path_scales
+        return noises, ps
+
+    def _forward_eager(self, slot, task_id, images, zero):
+        eng = slot.eng
+        noises, ps = self._draw(slot, eng)
+        if zero:
+            eng.zero_grad()
+        return eng.forward(images, task_id, noises=noises, path_scales=ps)
+
+    def _run_forward(self, slot, task_id, images):
+        eng = slot.eng
+        zero = slot.index > 0                     # slot 0's buffer is what the .grad views alias: the trainer zeroes it
+        if slot.add_done is not None:             # the previous add of this slot's buffer into slot 0's has read it
+            torch.cuda.current_stream().wait_event(slot.add_done)
+        n = slot.calls_f.get(task_id, 0)
+        slot.calls_f[task_id] = n + 1
+        if not self.graph or n == 0:
+            img = images.float().contiguous()
+            img.record_stream(torch.cuda.current_stream())
+            tok, cv = self._forward_eager(slot, task_id, img, zero)      # (the backward re-reads eng.rows, not the images)
+            return tok.clone(), cv
+        if slot.images is None:
+            slot.images = torch.empty(images.shape, dtype=torch.float32, device=self.device)
+        images.record_stream(torch.cuda.current_stream())
+        slot.images.copy_(images)
+        self._draw(slot, eng)
+        g = slot.graphs_f.get(task_id)
+        if g is None:
+            noises = slot.noises if (self.cfg.vmoe_noisy_std > 0 and self.model().training) else None
+            ps = slot.path_scales if (self.drop and self.model().training) else None
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                if zero:
+                    eng.zero_grad()
+                out = eng.forward(slot.images, task_id, noises=noises, path_scales=ps)
+            slot.graphs_f[task_id] = g
+            slot.out = getattr(slot, "out", {})
+            slot.out[task_id] = out
+        g.replay()
+        tok, cv = slot.out[task_id]
+        return tok.clone(), cv.clone()
+
+    # ------------------------------------------------------------------ backward
+    def _install_grads(self):
+        """Make every parameter's .grad the view of slot 0's flat buffer, with torch's accumulation semantics: a parameter
+        whose .grad is None starts from zero, one that already holds the view accumulates in place, one that holds another
+        tensor (assigned by the trainer or another wrapper) contributes that tensor's value.  All on slot 0's stream - the
+        one stream that ever writes the buffer."""
+        plist, views, vptrs = self.plist, self.views, self.view_ptrs
+        fresh, foreign = [], []
+        for i, p in enumerate(plist):
+            g = p.grad
+            if g is None:
+                fresh.append(i)
+            elif g.data_ptr() != vptrs[i] or g.dtype != torch.float32:
+                foreign.append(i)
+        if not fresh and not foreign:
+            return
+        flat = self.slots[0].eng.flat_grads
+        gs = self.slots[0].stream
+        with torch.cuda.stream(gs):
+            if len(fresh) == len(plist):
+                flat.zero_()
+            else:
+                if fresh:
+                    torch._foreach_zero_([views[i] for i in fresh])
+                if foreign:
+                    for i in foreign:
+                        plist[i].grad.record_stream(gs)
+                    torch._foreach_copy_([views[i] for i in foreign], [plist[i].grad for i in foreign])
+        for i in fresh + foreign:
+            plist[i].grad = views[i]
+
+    def _run_backward(self, slot, task_id, g_tok, g_cv):
+        eng = slot.eng
+        cur = torch.cuda.current_stream()             # autograd: the stream of the node's forward = slot.stream
+        gs = self.slots[0].stream
+        if slot.main is not None and cur != slot.stream:
+            # (a caller that ran backward under another stream context: order this pass behind the slot's own stream)
+            cur.wait_stream(slot.stream)
+        # the trainer may have consumed / zeroed the gradients on its own stream since the last backward
+        gs.wait_stream(slot.main)
+        self._install_grads()
+        if slot.dtok is None:
+            slot.dtok = torch.zeros(eng.B, eng.N, eng.D, dtype=torch.float32, device=self.device)
+        if g_tok is None:
+            slot.dtok.zero_()
+        else:
+            g_tok.record_stream(cur)
+            slot.dtok.copy_(g_tok.reshape(slot.dtok.shape))
+        if g_cv is None:
+            slot.dcv.zero_()
+        else:
+            g_cv.record_stream(cur)
+            slot.dcv.copy_(g_cv.reshape(1))
+        n = slot.calls_b.get(task_id, 0)
+        slot.calls_b[task_id] = n + 1
+        # a backward graph reads the forward graph's tensors by address: only behind a replayed forward
+        replayed_fwd = self.graph and slot.calls_f.get(task_id, 0) >= 2
+        if not replayed_fwd:
+            eng.backward(slot.dtok, cv_weight=slot.dcv)
+        else:
+            g = slot.graphs_b.get(task_id)
+            if g is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    eng.backward(slot.dtok, cv_weight=slot.dcv)
+                slot.graphs_b[task_id] = g
+            g.replay()
+        if slot.index > 0:
+            done = torch.cuda.Event()
+            done.record(cur)
+            gs.wait_event(done)
+            with torch.cuda.stream(gs):
+                ops.add_f32(self.slots[0].eng.flat_grads, eng.flat_grads)
+                slot.add_done = torch.cuda.Event()
+                slot.add_done.record(gs)
+        elif cur != gs:
+            gs.wait_stream(cur)
+        slot.main.wait_stream(gs)
+        slot.busy = False
+        self.dirty = True

@@ -95,12 +95,16 @@ def gate_fwd(x, w_gate, k, logit_bias=None, noise=None, noise_std=0.0, dense=Tru
 
 
 def gate_bwd_logits(noisy, idx, d_score, d_importance, k, *, balance_scale=1.0, d_top=None, idx_next=None,
-                    d_load_prob=None, clean=None, top_logits=None, noise_std=0.0, out=None):
-    """d_logits [T,E] from d_score [T,k], d_top [T,k+1], balance_scale * (d_importance, d_load_prob) [E]."""
+                    d_load_prob=None, clean=None, top_logits=None, noise_std=0.0, out=None, balance_scale_dev=None):
+    """d_logits [T,E] from d_score [T,k], d_top [T,k+1], balance_scale * (d_importance, d_load_prob) [E].
+    balance_scale_dev: optional 1-element f32 device tensor multiplied onto balance_scale inside the kernel."""
     T, E = noisy.shape
     dl = torch.empty_like(noisy) if out is None else out
+    if balance_scale_dev is not None:
+        _req(balance_scale_dev, torch.float32, "balance_scale_dev")
     a = _lib.GateBwdArgs(_p(noisy), _p(clean), _p(top_logits), _p(idx), _p(idx_next), _p(d_score), _p(d_top),
-                         _p(d_importance), _p(d_load_prob), float(balance_scale), float(noise_std), T, E, k, _p(dl))
+                         _p(d_importance), _p(d_load_prob), float(balance_scale), float(noise_std), T, E, k, _p(dl),
+                         _p(balance_scale_dev))
     check(lib().m3_gate_bwd_logits(byref(a), _stream()), "m3_gate_bwd_logits")
     return dl
 
@@ -294,6 +298,11 @@ class WgradQueue:
         self.ws = [torch.empty(ws_elems, dtype=torch.float32, device=device) for _ in range(2)]
         self.i = 0
         self.pending = None          # (WgradReduceDesc, tensors it points at)
+
+    def reset(self):
+        """drop a pending reduction without running it (step boundaries: see BackboneEngine.zero_grad)"""
+        self.pending = None
+        self.i = 0
 
     def flush(self):
         if self.pending is None:

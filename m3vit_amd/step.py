@@ -294,6 +294,9 @@ class MultiTaskStep:
                   flush=True)
             self.capture_error = f"{type(exc).__name__}: {exc}"
             self.graphs = None
+            for e in self.engs:                       # launches that were only captured never ran: nothing may ride on them
+                if e.wq is not None:
+                    e.wq.reset()
             torch.cuda.synchronize()
             return False
 

@@ -188,10 +188,39 @@ class VisionTransformerMoE(nn.Module):
                  gate_dim=-1, moe_gate_type="noisy_vmoe", vmoe_noisy_std=1, gate_task_specific_dim=-1,
                  multi_gate=False, regu_experts_fromtask=False, num_experts_pertask=-1, num_tasks=-1,
                  gate_input_ahead=False, expert_prune=False, use_checkpointing=False, act_dtype=torch.float32,
-                 random_init=True, sem_force=False, convention="ckpt", **kwargs):
+                 random_init=True, sem_force=False, convention="ckpt", fused="auto", **kwargs):
+        """fused: "auto" (default) / True - forward(x, task_id) runs as ONE autograd node on the straight-line executor
+        (m3vit_amd/fused.py: hipGraph replay, the parameters' .grad are views of its flat gradient buffer) whenever the call
+        is one it covers, and through the per-op autograd Functions below otherwise (`fused_fallback_reason` says why);
+        False - always per-op.  The environment variable M3VIT_FUSED=0 forces False."""
         super().__init__()
         assert convention in ("ckpt", "origin")
         self.convention = convention
+        import os
+        self.fused = False if os.environ.get("M3VIT_FUSED", "1") == "0" else fused
+        self.use_checkpointing = bool(use_checkpointing)
+        self._fused = None
+        self.fused_fallback_reason = None
+        self._cfg_kwargs = dict(img_size=tuple(img_size) if isinstance(img_size, (tuple, list)) else (img_size, img_size),
+                                patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim, depth=depth, num_heads=num_heads,
+                                mlp_ratio=mlp_ratio, moe_mlp_ratio=moe_mlp_ratio if moe_mlp_ratio >= 0 else mlp_ratio,
+                                moe_experts=moe_experts, moe_top_k=moe_top_k, gate_dim=gate_dim if gate_dim >= 0 else embed_dim,
+                                multi_gate=bool(multi_gate), gate_task_specific_dim=gate_task_specific_dim,
+                                vmoe_noisy_std=float(vmoe_noisy_std))
+        why = None
+        if not qkv_bias:
+            why = "qkv_bias=False"
+        elif world_size != 1:
+            why = "expert parallel layer (world_size > 1)"
+        elif regu_experts_fromtask or expert_prune or gate_input_ahead:
+            why = "regu_experts_fromtask / expert_prune / gate_input_ahead routing edits"
+        elif embed_dim // num_heads not in (32, 64) or moe_experts > 64 or moe_experts < 2 or moe_top_k > moe_experts:
+            why = "head dim not 32 / 64 or expert count outside [2, 64]"
+        elif multi_gate and self._cfg_kwargs["gate_dim"] <= embed_dim:
+            why = "multi_gate without tasks"
+        elif (not multi_gate) and gate_task_specific_dim >= 0 and self._cfg_kwargs["gate_dim"] <= embed_dim:
+            why = "task-conditioned gate without tasks"
+        self._fused_static_ok, self._fused_static_why = why is None, why
         assert drop_rate == 0.0 and attn_drop_rate == 0.0, "dropout inside the fused kernels is not supported"
         dpr = [drop_path_rate * i / max(depth - 1, 1) for i in range(depth)]          # linspace(0, rate, depth), :632
         self.img_size = tuple(img_size) if isinstance(img_size, (tuple, list)) else (img_size, img_size)
@@ -244,7 +273,34 @@ class VisionTransformerMoE(nn.Module):
                 nn.init.constant_(m.bias, 0)
                 nn.init.constant_(m.weight, 1.0)
 
+    def _forward_fused(self, x, task_id):
+        from .fused import FusedBackbone
+        if self._fused is None:
+            self._fused = FusedBackbone(self)
+        tok, cv = self._fused.forward(x, task_id)
+        if self.convention != "origin":
+            return tok, cv
+        # origin convention (origin/vision_transformer_moe.py:552-563): tokens only; the trainer sums the gates' stored
+        # losses (utils/moe_utils.py:201-207) - the summed balance loss of the pass is handed to ONE gate, the others hold none
+        last = None
+        for blk in self.blocks:
+            if blk.moe:
+                gates = blk.mlp.gate if isinstance(blk.mlp.gate, nn.ModuleList) else [blk.mlp.gate]
+                for g in gates:
+                    g.set_loss(None)
+                last = blk.mlp.gate[task_id] if isinstance(blk.mlp.gate, nn.ModuleList) else blk.mlp.gate
+        if last is not None:
+            last.set_loss(cv if self.training else 0)
+        return tok
+
     def forward_features(self, x, gate_inp, task_id, sem):
+        if self.fused:
+            from .fused import FusedBackbone
+            self.fused_fallback_reason = FusedBackbone.unsupported(self, x, gate_inp, task_id, sem)
+            if self.fused_fallback_reason is None:
+                return self._forward_fused(x, task_id)
+            if self.fused is True:
+                raise RuntimeError(f"VisionTransformerMoE(fused=True): {self.fused_fallback_reason}")
         B = x.shape[0]
         x = self.patch_embed(x, self.act_dtype).float()
         x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1) + self.pos_embed

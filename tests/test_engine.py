@@ -127,7 +127,8 @@ def test_backbone_task_conditioned_matches_oracle(dtype, tol):
 def test_config3_vit_base_64_experts(dtype, tol):
     """BASELINE configs[3] shapes on one GPU: ViT-Base width (D=768, 12 heads of 64), E=64, k=4,
     moe_mlp_ratio 1, 2 tasks; depth cut to 2 and 64x64 images so the float64 oracle finishes in seconds
-    (the expert-parallel form of the same config is tests/test_ep_engine_gpu.py)."""
+    (the same layer shape with the experts sharded over two ranks: tests/test_ep_engine_gpu.py case
+    config3_vit_base_e64_f16; the full 128 x 224^2 size on one GPU: tests/test_full_size.py config3_vit_base_e64)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from oracle import ref_torch as R

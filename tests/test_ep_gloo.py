@@ -131,6 +131,27 @@ def _dgdp_worker(rank, world, port, q):
         w.allreduce_params()
         assert m["dense"].weight.grad.data_ptr() == ptr
         assert torch.allclose(m["dense"].weight.grad, torch.full((3, 4), 3.0))
+        # a MIX of kept views and re-created gradients (an optimizer whose zero_grad(set_to_none=True) covers only part of the
+        # parameters): about 60 % of the gradients are foreign, the rest still alias the flat buffer - the gather may not
+        # write the buffer through tensors that overlap it (torch.cat(out=flat) raises on that)
+        m2 = torch.nn.Sequential(*[torch.nn.Linear(4, 4) for _ in range(5)])          # 10 parameters
+        w2 = DistributedGroupedDataParallel(m2)
+        for p in m2.parameters():
+            p.grad = torch.full_like(p, float(rank + 1))
+        w2.allreduce_params()
+        ps = list(m2.parameters())
+        flat2 = w2._flat[("dp", torch.float32, ps[0].device)][1]
+        assert all(p.grad.data_ptr() == flat2.data_ptr() + 4 * o for p, o in zip(ps, [0, 16, 20, 36, 40, 56, 60, 76, 80, 96]))
+        for i, p in enumerate(ps):
+            if i % 5 < 3:                                             # 6 of 10 re-created
+                p.grad = torch.full_like(p, float(10 * (rank + 1) + i))
+            else:                                                     # 4 of 10 accumulate in place
+                p.grad.zero_(); p.grad.add_(float(rank + 1))
+        w2.allreduce_params()
+        for i, p in enumerate(ps):
+            want = (15.0 + i) if i % 5 < 3 else 1.5                   # means of (10 + i, 20 + i) and of (1, 2)
+            assert torch.allclose(p.grad, torch.full_like(p, want)), (i, p.grad.flatten()[:2])
+            assert flat2.data_ptr() <= p.grad.data_ptr() < flat2.data_ptr() + 4 * flat2.numel()
         q.put((rank, "ok"))
     except Exception:                                # pragma: no cover
         import traceback

@@ -1,0 +1,250 @@
+"""GPU: the drop-in module path - m3vit_amd.vit.VisionTransformerMoE.forward(x, task_id) as ONE autograd node on the fused
+executor (m3vit_amd/fused.py) - against the float64 oracle, against the per-op module path, and for torch's gradient
+semantics (zero_grad both ways, accumulation, foreign .grad tensors, one task at a time vs the joint backward)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = a.detach().double().cpu().flatten(); b = b.detach().double().cpu().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+KW = dict(img_size=(32, 48), embed_dim=64, depth=4, num_heads=2, moe_top_k=2, gate_dim=66, multi_gate=True)
+
+
+def _model(std=0.0, E=4, fused="auto", act_dtype=torch.float32, seed=9, model_kw=None, **over):
+    from m3vit_amd.vit import VisionTransformerMoE
+    from oracle import ref_torch as R
+    kw = dict(KW, moe_experts=E)
+    kw.update(over)
+    cfg = R.BackboneCfg(mlp_ratio=4.0, moe_mlp_ratio=1.0, vmoe_noisy_std=std, **kw)
+    P = R.init_backbone_params(cfg, seed=seed)
+    m = VisionTransformerMoE(mlp_ratio=4.0, moe_mlp_ratio=1, vmoe_noisy_std=std, fused=fused, act_dtype=act_dtype, **kw,
+                             **(model_kw or {})).cuda()
+    m.load_state_dict(P)
+    m.train()
+    return m, cfg
+
+
+@pytest.mark.parametrize("std,act_dtype,tol", [(0.0, torch.float32, 2e-4), (1.0, torch.float32, 2e-4), (0.0, torch.float16, 1e-3)])
+def test_fused_module_joint_multitask_steps_match_oracle(std, act_dtype, tol):
+    """The reference's joint multi-task step (models/models.py:299-320 + train/train_utils.py:423-457): backbone(x, task_id)
+    for every task, ONE loss.backward(), optimizer.zero_grad(set_to_none=True), a parameter update - four steps, so that the
+    eager first use, the hipGraph capture (second use) and two replays are all checked, each step with new images and
+    changed weights, against the float64 oracle on the module's current weights."""
+    _need_gpu()
+    from oracle import ref_torch as R
+    m, cfg = _model(std=std, E=8 if std else 4, act_dtype=act_dtype)
+    f16 = act_dtype == torch.float16
+    B = 3
+    for step in range(4):
+        g = torch.Generator().manual_seed(100 + step)
+        img = torch.randn(B, 3, 32, 48, generator=g)
+        dtok = torch.randn(B, cfg.num_tokens, 64, generator=g) * 0.1
+        for p in m.parameters():
+            p.grad = None                                              # optimizer.zero_grad(set_to_none=True)
+        Pr = {k: v.detach().clone().double().cpu().requires_grad_() for k, v in m.state_dict().items()}
+        loss, loss_ref = 0.0, 0.0
+        outs = []
+        for task in (0, 1):
+            tok, cv = m(img.cuda(), task_id=task)
+            assert m.fused_fallback_reason is None
+            loss = loss + (tok * dtok.cuda()).sum() + 0.01 * cv
+            outs.append((tok, cv))
+        fb = m._fused
+        assert [s.busy for s in fb.slots] == [True, True]              # two forwards wait for their backward
+        for task, (tok, cv) in zip((0, 1), outs):
+            slot = fb.slots[task]
+            noises = None if not std else {i: n.double().cpu() for i, n in slot.noises.items()}
+            ovr = None
+            if f16:                  # fp16 storage flips near-tied experts: follow the module's routing (tests/test_engine.py)
+                ovr = {i: slot.eng.act[i]["gate"]["idx"].cpu() for i in (1, 3)}
+            tr, cr, _ = R.backbone_forward(Pr, cfg, img.double(), task, noises=noises, route_override=ovr)
+            assert rel(tok, tr) < tol, (step, task, rel(tok, tr))
+            assert abs(float(cv) - float(cr)) < 2e-3 * max(1.0, float(cr)), (step, task)
+            loss_ref = loss_ref + (tr * dtok.double()).sum() + 0.01 * cr
+        loss.backward()
+        loss_ref.backward()
+        torch.cuda.synchronize()
+        assert not any(s.busy for s in fb.slots)
+        bad = [(n, rel(p.grad, Pr[n].grad)) for n, p in m.named_parameters()
+               if Pr[n].grad is not None and rel(p.grad, Pr[n].grad) > 3 * tol + 7e-4]
+        assert not bad, (step, bad)
+        with torch.no_grad():                                          # optimizer.step(): the operand copies must follow
+            for p in m.parameters():
+                p.add_(p.grad, alpha=-0.05)
+    assert fb.slots[0].graphs_f and fb.slots[0].graphs_b and fb.slots[1].graphs_b, "steps 2.. must have replayed hipGraphs"
+
+
+def test_fused_module_matches_per_op_module_path():
+    """same weights, same images: the fused node and the per-op autograd Functions (fused=False) agree on tokens, balance
+    loss and every gradient (fp32: summation order only)"""
+    _need_gpu()
+    a, cfg = _model(fused="auto")
+    b, _ = _model(fused=False)
+    img = torch.randn(4, 3, 32, 48).cuda()
+    dtok = (torch.randn(4, cfg.num_tokens, 64) * 0.1).cuda()
+    for rep in range(3):
+        for m in (a, b):
+            m.zero_grad(set_to_none=True)
+            loss = 0.0
+            for task in (0, 1):
+                tok, cv = m(img, task_id=task)
+                loss = loss + (tok * dtok).sum() + 0.01 * cv
+            loss.backward()
+            m.last = (tok.detach(), cv.detach())
+        assert a.fused_fallback_reason is None and b._fused is None
+        assert rel(a.last[0], b.last[0]) < 1e-5 and abs(float(a.last[1]) - float(b.last[1])) < 1e-5
+        bad = [(n, rel(p.grad, q.grad)) for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters())
+               if rel(p.grad, q.grad) > 2e-4]
+        assert not bad, (rep, bad)
+
+
+def test_fused_module_gradient_semantics():
+    """.grad handling of the fused node = torch's: accumulation over backward calls without a zero_grad, zero_grad(set_to_none
+    =False), a .grad tensor assigned by someone else (its value is kept and added to), one task at a time
+    (train/train_utils.py:373-404 `one_by_one`) equal to the joint backward."""
+    _need_gpu()
+    m, cfg = _model()
+    img = torch.randn(3, 3, 32, 48).cuda()
+    dtok = (torch.randn(3, cfg.num_tokens, 64) * 0.1).cuda()
+
+    def joint():
+        loss = 0.0
+        for task in (0, 1):
+            tok, cv = m(img, task_id=task)
+            loss = loss + (tok * dtok).sum() + 0.01 * cv
+        loss.backward()
+
+    def grads():
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+
+    for _ in range(3):                                   # eager, capture, replay
+        m.zero_grad(set_to_none=True)
+        joint()
+    g1 = grads()
+    joint()                                              # no zero_grad: accumulates
+    g2 = grads()
+    assert all(rel(g2[n], 2 * g1[n]) < 1e-6 for n in g1 if float(g1[n].abs().max()) > 0)
+    m.zero_grad(set_to_none=False)                       # zeroes in place: the views stay installed
+    ptr = m.cls_token.grad.data_ptr()
+    joint()
+    g3 = grads()
+    assert m.cls_token.grad.data_ptr() == ptr
+    assert all(torch.equal(g3[n], g1[n]) for n in g1), "deterministic: same step, same bits"
+    # a foreign .grad on some parameters, None on others, the view on the rest
+    names = [n for n, _ in m.named_parameters()]
+    for i, (n, p) in enumerate(m.named_parameters()):
+        if i % 3 == 0:
+            p.grad = torch.full_like(p, 0.5)
+        elif i % 3 == 1:
+            p.grad = None
+        else:
+            p.grad.zero_()
+    joint()
+    g4 = grads()
+    for i, n in enumerate(names):
+        want = g1[n] + (0.5 if i % 3 == 0 else 0.0)
+        assert rel(g4[n], want) < 1e-6, n
+    # one task at a time: forward / backward per task (the same slot twice) = the joint step
+    m.zero_grad(set_to_none=True)
+    for task in (0, 1):
+        tok, cv = m(img, task_id=task)
+        ((tok * dtok).sum() + 0.01 * cv).backward()
+    g5 = grads()
+    assert all(rel(g5[n], g1[n]) < 1e-5 for n in g1 if float(g1[n].abs().max()) > 0)
+    assert len(m._fused.slots) == 2
+
+
+def test_fused_module_eval_and_no_grad_forward():
+    _need_gpu()
+    a, cfg = _model(std=1.0, E=8)
+    b, _ = _model(std=1.0, E=8, fused=False)
+    img = torch.randn(2, 3, 32, 48).cuda()
+    a.eval(); b.eval()
+    with torch.no_grad():
+        ta, ca = a(img, task_id=1)
+        tb, cb = b(img, task_id=1)
+    assert a.fused_fallback_reason is None
+    assert rel(ta, tb) < 1e-5 and float(ca) == 0.0 and float(cb) == 0.0          # eval: no noise, no balance loss
+    tc, _ = a(img, task_id=1)                                                    # eval with autograd on: per-op path
+    assert a.fused_fallback_reason == "eval mode with autograd on" and rel(tc, tb) < 1e-5
+    # a dropped forward (no backward) gives its slot back
+    a.train()
+    tok, cv = a(img, task_id=0)
+    assert a._fused.slots[0].busy
+    del tok, cv
+    import gc
+    gc.collect()
+    assert not a._fused.slots[0].busy
+
+
+def test_fused_module_drop_path_matches_oracle():
+    """stochastic depth on the fused node: the per-sample factors it drew (slot.path_scales) fed to the oracle"""
+    _need_gpu()
+    from oracle import ref_torch as R
+    m, cfg = _model(model_kw=dict(drop_path_rate=0.5), img_size=(32, 32))
+    img = torch.randn(6, 3, 32, 32)
+    dtok = torch.randn(6, cfg.num_tokens, 64) * 0.1
+    for step in range(3):
+        m.zero_grad(set_to_none=True)
+        torch.manual_seed(step)
+        tok, cv = m(img.cuda(), task_id=1)
+        assert m.fused_fallback_reason is None
+        ps = m._fused.slots[0].path_scales
+        assert sorted(ps) == [1, 2, 3]
+        scales = {i: (sa.double().cpu(), sm.double().cpu()) for i, (sa, sm) in ps.items()}
+        allv = torch.cat([torch.cat(v) for v in scales.values()])
+        keep = {1: 1 - 0.5 / 3, 2: 1 - 1.0 / 3, 3: 0.5}
+        for i, (sa, sm) in scales.items():
+            for v in (sa, sm):
+                assert all(abs(float(x)) < 1e-6 or abs(float(x) - 1 / keep[i]) < 1e-5 for x in v)
+        assert float((allv == 0).float().mean()) > 0.05, "some branches must have been dropped"
+        Pr = {k: v.detach().clone().double().cpu().requires_grad_() for k, v in m.state_dict().items()}
+        tr, cr, _ = R.backbone_forward(Pr, cfg, img.double(), 1, path_scales=scales)
+        assert rel(tok, tr) < 2e-4
+        ((tok * dtok.cuda()).sum() + 0.01 * cv).backward()
+        ((tr * dtok.double()).sum() + 0.01 * cr).backward()
+        bad = [(n, rel(p.grad, Pr[n].grad)) for n, p in m.named_parameters()
+               if Pr[n].grad is not None and rel(p.grad, Pr[n].grad) > 1e-3]
+        assert not bad, (step, bad)
+
+
+def test_fused_module_origin_convention_and_task_conditioned_gate():
+    """origin convention (train_fastmoe.py:425-435 with --use_checkpointing False): tokens only, the balance loss through
+    utils/moe_utils.py::collect_noisy_gating_loss; on a task-conditioned gate (configs[2] structure), whose task-embedding
+    MLP gets its gradient through the fused node too."""
+    _need_gpu()
+    from m3vit_amd.moe_utils import collect_noisy_gating_loss
+    from oracle import ref_torch as R
+    over = dict(gate_dim=69, multi_gate=False, gate_task_specific_dim=16)
+    m, cfg = _model(E=8, model_kw=dict(convention="origin"), **over)
+    img = torch.randn(3, 3, 32, 48)
+    dtok = torch.randn(3, cfg.num_tokens, 64) * 0.1
+    for step in range(3):
+        m.zero_grad(set_to_none=True)
+        Pr = {k: v.detach().clone().double().cpu().requires_grad_() for k, v in m.state_dict().items()}
+        loss, loss_ref = 0.0, 0.0
+        for task in (0, 2, 4):
+            tok = m(img.cuda(), task_id=task)
+            assert torch.is_tensor(tok) and m.fused_fallback_reason is None
+            loss = loss + (tok * dtok.cuda()).sum() + collect_noisy_gating_loss(m, 0.01)
+            tr, cr, _ = R.backbone_forward(Pr, cfg, img.double(), task)
+            assert rel(tok, tr) < 2e-4
+            loss_ref = loss_ref + (tr * dtok.double()).sum() + 0.01 * cr
+        loss.backward()
+        loss_ref.backward()
+        bad = [(n, rel(p.grad, Pr[n].grad)) for n, p in m.named_parameters()
+               if Pr[n].grad is not None and rel(p.grad, Pr[n].grad) > 1e-3]
+        assert not bad, (step, bad)
+        assert float(m.gate_task_represent.fc1.weight.grad.abs().max()) > 0
+    assert len(m._fused.slots) == 3

@@ -15,9 +15,12 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
+@pytest.mark.parametrize("fused", [False, "auto"])
 @pytest.mark.parametrize("std", [0.0, 1.0])
-def test_vit_mirror_matches_oracle_fwd_bwd(std):
-    """std = 1: the module draws the gate noise itself (torch.randn on the GPU, noisy_gate_vmoe.py:168);
+def test_vit_mirror_matches_oracle_fwd_bwd(std, fused):
+    """fused = False: every op its own autograd Function (m3vit_amd/functional.py); "auto": the whole backbone call as one
+    autograd node on the fused executor (m3vit_amd/fused.py; more in tests/test_fused_module_gpu.py).
+    std = 1: the module draws the gate noise itself (torch.randn on the GPU, noisy_gate_vmoe.py:168);
     the test re-draws the same tensors from the same seed for the oracle.  The load term is then the
     Normal-CDF form computed from the gate outputs (vision_transformer_moe.py:456-457)."""
     _need_gpu()
@@ -27,7 +30,7 @@ def test_vit_mirror_matches_oracle_fwd_bwd(std):
               gate_dim=66, multi_gate=True)
     cfg = R.BackboneCfg(mlp_ratio=4.0, moe_mlp_ratio=1.0, vmoe_noisy_std=std, **kw)
     P = R.init_backbone_params(cfg, seed=9)
-    m = VisionTransformerMoE(mlp_ratio=4.0, moe_mlp_ratio=1, vmoe_noisy_std=std, **kw).cuda()
+    m = VisionTransformerMoE(mlp_ratio=4.0, moe_mlp_ratio=1, vmoe_noisy_std=std, fused=fused, **kw).cuda()
     m.load_state_dict(P)                                        # reference key names and shapes
     m.train()
     img = torch.randn(3, 3, 32, 48)
@@ -37,6 +40,7 @@ def test_vit_mirror_matches_oracle_fwd_bwd(std):
     for task in (0, 1):
         torch.manual_seed(50 + task)
         tok, cv = m(img.cuda(), task_id=task)
+        assert (m._fused is not None) == (fused == "auto")
         noises = None
         if std:
             torch.manual_seed(50 + task)
@@ -62,8 +66,8 @@ def test_vit_mirror_drop_path_matches_oracle():
               multi_gate=True)
     cfg = R.BackboneCfg(mlp_ratio=4.0, moe_mlp_ratio=1.0, vmoe_noisy_std=0.0, **kw)
     P = R.init_backbone_params(cfg, seed=12)
-    m = VisionTransformerMoE(mlp_ratio=4.0, moe_mlp_ratio=1, vmoe_noisy_std=0.0, drop_path_rate=0.5, **kw).cuda()
-    m.load_state_dict(P)
+    m = VisionTransformerMoE(mlp_ratio=4.0, moe_mlp_ratio=1, vmoe_noisy_std=0.0, drop_path_rate=0.5, fused=False, **kw).cuda()
+    m.load_state_dict(P)                 # (per-op path: the test reads the DropPath modules' draws; fused: tests/test_fused_module_gpu.py)
     rates = [blk.drop_path.drop_prob if isinstance(blk.drop_path, DropPath) else 0.0 for blk in m.blocks]
     assert rates == pytest.approx([0.0, 0.5 / 3, 1.0 / 3, 0.5])
     drawn = {}
