@@ -32,15 +32,18 @@ PEAK = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}      # dense MFMA TFLOP/s, 
 PEAK_HBM = 8000.0                          # GB/s, MI355X_MICROARCH.md
 METRIC = "images/sec fwd+bwd ViT-S/16 MoE(E=16,k=4) 224^2 bs=128"
 EP_WATCHDOG_S = 420            # N > 1: the expert-parallel leg may not hang the whole line (see attempt())
+DP_WATCHDOG_S = 300            # ... nor the data-parallel one (it takes well under a minute when it works)
+AGREE_S = 120                  # after each leg the ranks agree on its outcome over a CPU group, at most this long
 SHARED_WATCHDOG_S = 240       # the optional dp_shared_stem leg (the plain dp leg takes well under a minute)
+_JSON_OUT = sys.stdout
 CV_WEIGHT = 0.01                           # --moe_noisy_gate_loss_weight default (train_fastmoe.py:118; applied at train/train_utils.py:277)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)       # >= 10 warm-up + >= 50 timed steps
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", choices=["f16", "bf16", "f32"], default="f16")
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--checkpoint", action="store_true",
@@ -68,6 +71,10 @@ def parse():
                     "ranks, all-to-all over RCCL); default: expert parallel (primary, when E %% N == 0) AND data parallel")
     ap.add_argument("--dp-only", action="store_true", help="N > 1: time only the replicated-experts data-parallel form")
     ap.add_argument("--no-f32", action="store_true", help="N = 1: skip the fp32 run reported as the sub-object \"f32\"")
+    ap.add_argument("--module-path", action="store_true", help="N = 1: time ONLY the drop-in module path (install_fmoe_shim() + "
+                    "m3vit_amd.vit.VisionTransformerMoE + torch.autograd: backbone(x, task_id) per task, one loss.backward()) and "
+                    "report it as `value`; by default it is timed after the executor and reported as the sub-object \"module_path\"")
+    ap.add_argument("--no-module-path", action="store_true", help="N = 1: do not time the drop-in module path")
     a = ap.parse_args()
     if a.checkpoint and a.wgrad_streams:
         ap.error("--checkpoint re-uses the activation buffers a wgrad stream may still read: pick one of the two")
@@ -163,6 +170,12 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
+    # stdout carries exactly ONE line, the JSON: libraries that print there (gloo's "[Gloo] Rank 0 is connected to ..." banner
+    # in CPU-side rehearsals) are sent to stderr - file descriptor 1 is pointed at stderr and the JSON goes to a saved copy
+    global _JSON_OUT
+    sys.stdout.flush()
+    _JSON_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -390,7 +403,7 @@ def main():
                                    "sample": f"{n} full steps (2 task passes fwd+bwd, fp32 torch CPU oracle) at batch "
                                              f"{args.cpu_batch}, scaled per image"}
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            print(json.dumps(out), file=_JSON_OUT, flush=True)
 
 
     def attempt(tag, fn, watchdog_s=None, on_timeout=None):
@@ -421,8 +434,23 @@ def main():
             if timer is not None:
                 timer.cancel()
 
+    def module_leg(dtype_name):
+        """the drop-in path: what a trainer that imports the reference's names gets (tools/module_bench.py)"""
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from module_bench import module_path_step_time
+        return module_path_step_time(dtype_name, "auto", steps=args.steps, warmup=args.warmup, batch=args.batch, log=log)
+
     main_res = None
-    if world == 1:
+    if world == 1 and args.module_path:
+        mp = module_leg(args.dtype)
+        cfg0 = BackboneConfig(**VIT_SMALL_MOE)
+        main_res = {"value": mp["value"], "ms_per_step": mp["ms_per_step"], "model_tflops": mp["model_tflops"],
+                    "launch": mp["path"], "task_streams": cfg0.num_tasks, "wgrad_streams": 0, "capture_refused": None,
+                    "task_passes": cfg0.num_tasks, "tokens_per_image": cfg0.num_tokens, "activation_checkpointing": False,
+                    "shared_stem": False, "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+                    "parallelism": "single"}
+        extra["module_path"] = mp
+    elif world == 1:
         # `value` is the reference's schedule: one FULL backbone pass per task.  Every task pass of a step reads the same images
         # (train/train_utils.py:248-256) and the patch embedding + block 0 see neither task id nor gate, so they can be computed
         # once per step with their backward on the summed d x (m3vit_amd/step.py share_stem; identical gradients:
@@ -447,42 +475,77 @@ def main():
             if f32 is not None:
                 extra["f32"] = {k: f32[k] for k in ("value", "ms_per_step", "model_tflops", "launch", "roofline")}
                 extra["f32"]["dtype"] = "f32"
+        if not args.no_module_path and not args.serial_tasks and not args.checkpoint and not (args.noisy or args.skew):
+            # The number above is the executor driven directly (m3vit_amd.step.MultiTaskStep).  What a maintainer who drops
+            # the library in calls is the MODULE API - install_fmoe_shim() + VisionTransformerMoE.forward(x, task_id) per task +
+            # one loss.backward() (models/models.py:299-320, train/train_utils.py:423-457): timed here on the same
+            # configuration, same dtype (and fp32, train_fastmoe.py's arithmetic), reported beside the headline
+            mp = attempt("module_path", lambda: module_leg(args.dtype))
+            if mp is not None:
+                mp["ratio_to_value"] = round(mp["value"] / main_res["value"], 4)
+                extra["module_path"] = mp
+                if "f32" in extra:
+                    mp32 = attempt("module_path_f32", lambda: module_leg("f32"))
+                    if mp32 is not None:
+                        mp32["ratio_to_f32_value"] = round(mp32["value"] / extra["f32"]["value"], 4)
+                        extra["module_path"]["f32"] = mp32
     else:
         want_ep = args.ep or (not args.dp_only and E % world == 0)
         want_dp = not args.ep
         results = {}
         sub = ("value", "ms_per_step", "model_tflops", "launch", "parallelism")
-        # data parallel first: it needs one collective (all-reduce) and its line must survive whatever the expert-parallel
-        # leg (count all-to-all + uneven all-to-all-v on several streams) does at its first contact with RCCL
+        # The legs, in this order: data parallel first - it needs one collective (all-reduce) and its line must survive whatever
+        # the expert-parallel leg (count all-to-all + uneven all-to-all-v on several streams) does at its first contact with
+        # RCCL; the opt-in shared-stem data-parallel leg (--share-stem; the one-GPU gloo rehearsal stalls in it, DESIGN
+        # section 6) last.  EVERY leg runs under a watchdog on every rank (a collective that never returns cannot be caught: on a
+        # time-out rank 0 prints the line from what the earlier legs measured and the process ends), and after every leg the
+        # ranks AGREE on its outcome over a CPU (gloo) group: a rank that failed alone (out of memory, a RCCL error) must not
+        # walk into the next leg's collectives while its peers still sit in the failed leg's - if any rank failed, every rank
+        # records the error, no further collective leg is started, and the line is printed from the legs that finished.
+        legs = []
         if want_dp:
-            results[False] = attempt("dp", lambda: run_mode(args.dtype, False, False, share_stem=False))
-            if results[False] is not None:
-                extra["dp"] = {k: results[False][k] for k in sub}
+            legs.append(("dp", False, lambda: run_mode(args.dtype, False, False, share_stem=False), DP_WATCHDOG_S))
         if want_ep:
-            def ep_hung():
-                extra["ep_error"] = f"no result after {EP_WATCHDOG_S} s (a collective that never returned); reporting the data-parallel leg"
-                done = [r for r in (results.get(False),) if r is not None]
-                if rank == 0 and done:
-                    emit(max(done, key=lambda r: r["value"]))
-                os._exit(0 if done else 1)
-            results[True] = attempt("ep", lambda: run_mode(args.dtype, True, False), watchdog_s=EP_WATCHDOG_S, on_timeout=ep_hung)
-            if results[True] is not None:
-                extra["ep"] = {k: results[True][k] for k in sub}
+            legs.append(("ep", True, lambda: run_mode(args.dtype, True, False), EP_WATCHDOG_S))
         if want_dp and args.share_stem and not args.serial_tasks:
-            # opt-in at N > 1 (--share-stem; no two-GPU box was ever available to try it over RCCL, and the one-GPU gloo rehearsal
-            # stalls in it): the data-parallel form with the task-independent stem computed once per step (see the N = 1 branch): LAST and under
-            # its own watchdog, so that whatever it does at its first contact with RCCL costs only itself - on a time-out the
-            # line is printed from what the legs above measured
-            def shared_hung():
-                extra["dp_shared_stem_error"] = f"no result after {SHARED_WATCHDOG_S} s; reporting the legs that finished"
-                done = [r for r in (results.get(True), results.get(False)) if r is not None]
-                if rank == 0 and done:
-                    emit(max(done, key=lambda r: r["value"]))
-                os._exit(0 if done else 1)
-            results["dp_shared_stem"] = attempt("dp_shared_stem", lambda: run_mode(args.dtype, False, False, share_stem=True),
-                                                watchdog_s=SHARED_WATCHDOG_S, on_timeout=shared_hung)
-            if results["dp_shared_stem"] is not None:
-                extra["dp_shared_stem"] = {k: results["dp_shared_stem"][k] for k in sub}
+            legs.append(("dp_shared_stem", "dp_shared_stem", lambda: run_mode(args.dtype, False, False, share_stem=True),
+                         SHARED_WATCHDOG_S))
+        import datetime
+        agree_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=AGREE_S))
+
+        def finished():
+            return [r for r in results.values() if r is not None]
+
+        def bail(code_if_none=1):
+            done = finished()
+            if rank == 0 and done:
+                emit(max(done, key=lambda r: r["value"]))
+            _JSON_OUT.flush()
+            os._exit(0 if done else code_if_none)
+
+        def agree(ok):
+            """True iff the leg succeeded on EVERY rank (min over the ranks on the CPU group; a peer that never arrives - it
+            hangs in a collective until its watchdog ends it - counts as a failure after AGREE_S seconds)"""
+            try:
+                t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=agree_group)
+                return bool(int(t[0]))
+            except Exception as exc:      # noqa: BLE001
+                log(f"agreement over the CPU group failed: {type(exc).__name__}: {exc}")
+                return False
+
+        for tag, key, fn, wd in legs:
+            def hung(tag=tag, wd=wd):
+                extra[f"{tag}_error"] = f"no result after {wd} s (a collective that never returned); reporting the legs that finished"
+                bail()
+            results[key] = attempt(tag, fn, watchdog_s=wd, on_timeout=hung)
+            if not agree(results[key] is not None):
+                extra.setdefault(f"{tag}_error", "failed on another rank (see its stderr)")
+                results[key] = None                   # a leg some rank did not finish has no max-over-ranks time
+                names = [l[0] for l in legs]
+                extra["legs_skipped"] = names[names.index(tag) + 1:]
+                bail()
+            extra[tag] = {k: results[key][k] for k in sub}
         # primary: the faster of the expert-parallel and data-parallel forms that ran (in the line as "ep" / "dp"; "dp_shared_stem" beside them).  configs[1]'s experts
         # (E = 16 x 0.6 MB) fit one GPU many times over, so sharding them is a choice, not a need: expert parallelism moves
         # ~3.7 GB of routed rows per step and rank through the xGMI links (DESIGN.md section 6 has the predicted table) where
@@ -493,7 +556,7 @@ def main():
         main_res = max(ran, key=lambda r: r["value"]) if ran else None
         if main_res is None:
             if rank == 0:
-                print(json.dumps({"metric": METRIC, "value": None, "n_gpus": world, **extra}), flush=True)
+                print(json.dumps({"metric": METRIC, "value": None, "n_gpus": world, **extra}), file=_JSON_OUT, flush=True)
             sys.exit(1)
     emit(main_res, final=True)
     if world > 1:

@@ -16,8 +16,9 @@ allocations and ~1500 Python-issued launches.  FusedBackbone puts the executor b
     scalar: m3_gate_bwd_args.balance_scale_dev);
   * autograd runs a node's backward on the stream of its forward, so the task passes of a joint multi-task step
     (all forwards, one backward) run their backward passes side by side on the GPU like m3vit_amd.step.MultiTaskStep's
-    task streams; gradient buffers of the extra slots are added into slot 0's on slot 0's stream (one writer stream
-    for the buffer the `.grad` views alias), and the stream that called forward() waits for all of it.
+    task streams; every slot's gradient buffer is added, as soon as its backward is done, into the ONE buffer the `.grad`
+    views alias, on a stream of its own (the only stream that ever writes that buffer - a slot's add runs under the other
+    slots' backward kernels), and the stream that called forward() waits for all of it.
 
 The per-op path stays for everything the executor does not cover (see `unsupported()`).
 """
@@ -84,6 +85,7 @@ class FusedBackbone:
         self.dirty = True
         self.anchor = None
         self.names = None
+        self._join_queued = False
 
     # ------------------------------------------------------------------ eligibility
     @staticmethod
@@ -123,7 +125,13 @@ class FusedBackbone:
         self.cfg, self.batch, self.device = cfg, B, device
         self.slots = [_Slot(0, eng0, device)]
         self.plist = [named[n] for n in eng0.params]                 # in the flat buffer's order
-        self.views = [eng0.grads[n] for n in eng0.params]
+        # the buffer the parameters' .grad alias: the sum over the slots' own gradient buffers (same layout)
+        self.gsum = torch.zeros_like(eng0.flat_grads)
+        self.gstream = torch.cuda.Stream(device=device)
+        self.views, o = [], 0
+        for n, p in eng0.params.items():
+            self.views.append(self.gsum[o:o + p.numel()].view_as(p))
+            o += p.numel()
         self.view_ptrs = [v.data_ptr() for v in self.views]
         self.ptrs = [p.data_ptr() for p in self.plist]
         self.anchor = torch.zeros((), device=device, requires_grad=True)
@@ -221,8 +229,8 @@ class FusedBackbone:
 
     def _run_forward(self, slot, task_id, images):
         eng = slot.eng
-        zero = slot.index > 0                     # slot 0's buffer is what the .grad views alias: the trainer zeroes it
-        if slot.add_done is not None:             # the previous add of this slot's buffer into slot 0's has read it
+        zero = True                               # the slot's own buffer holds this pass only; .grad aliases the sum (self.gsum)
+        if slot.add_done is not None:             # the previous add of this slot's buffer into the sum has read it
             torch.cuda.current_stream().wait_event(slot.add_done)
         n = slot.calls_f.get(task_id, 0)
         slot.calls_f[task_id] = n + 1
@@ -254,10 +262,10 @@ class FusedBackbone:
 
     # ------------------------------------------------------------------ backward
     def _install_grads(self):
-        """Make every parameter's .grad the view of slot 0's flat buffer, with torch's accumulation semantics: a parameter
+        """Make every parameter's .grad the view of the sum buffer, with torch's accumulation semantics: a parameter
         whose .grad is None starts from zero, one that already holds the view accumulates in place, one that holds another
-        tensor (assigned by the trainer or another wrapper) contributes that tensor's value.  All on slot 0's stream - the
-        one stream that ever writes the buffer."""
+        tensor (assigned by the trainer or another wrapper) contributes that tensor's value.  All on the gradient stream -
+        the one stream that ever writes the buffer."""
         plist, views, vptrs = self.plist, self.views, self.view_ptrs
         fresh, foreign = [], []
         for i, p in enumerate(plist):
@@ -268,8 +276,8 @@ class FusedBackbone:
                 foreign.append(i)
         if not fresh and not foreign:
             return
-        flat = self.slots[0].eng.flat_grads
-        gs = self.slots[0].stream
+        flat = self.gsum
+        gs = self.gstream
         with torch.cuda.stream(gs):
             if len(fresh) == len(plist):
                 flat.zero_()
@@ -286,7 +294,7 @@ class FusedBackbone:
     def _run_backward(self, slot, task_id, g_tok, g_cv):
         eng = slot.eng
         cur = torch.cuda.current_stream()             # autograd: the stream of the node's forward = slot.stream
-        gs = self.slots[0].stream
+        gs = self.gstream
         if slot.main is not None and cur != slot.stream:
             # (a caller that ran backward under another stream context: order this pass behind the slot's own stream)
             cur.wait_stream(slot.stream)
@@ -319,16 +327,22 @@ class FusedBackbone:
                     eng.backward(slot.dtok, cv_weight=slot.dcv)
                 slot.graphs_b[task_id] = g
             g.replay()
-        if slot.index > 0:
-            done = torch.cuda.Event()
-            done.record(cur)
-            gs.wait_event(done)
-            with torch.cuda.stream(gs):
-                ops.add_f32(self.slots[0].eng.flat_grads, eng.flat_grads)
+        gs.wait_stream(cur)
+        with torch.cuda.stream(gs):
+            ops.add_f32(self.gsum, eng.flat_grads)
+            if slot.add_done is None:
                 slot.add_done = torch.cuda.Event()
-                slot.add_done.record(gs)
-        elif cur != gs:
-            gs.wait_stream(cur)
-        slot.main.wait_stream(gs)
+            slot.add_done.record(gs)
+        # The caller's stream must see the finished gradients - but not from here: nodes that autograd runs AFTER this one
+        # on the caller's stream (the loss arithmetic of the other task passes, which produces their d tokens) would then
+        # wait for this pass, and the passes' backward would run one after the other.  The wait is queued as a callback
+        # of the backward pass: it runs once, on the thread and stream that called backward(), when every node is done.
+        if not self._join_queued:
+            self._join_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._join_caller)
         slot.busy = False
         self.dirty = True
+
+    def _join_caller(self):
+        self._join_queued = False
+        torch.cuda.current_stream().wait_stream(self.gstream)

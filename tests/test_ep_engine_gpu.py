@@ -26,10 +26,10 @@ EP_CASES = {
                              multi_gate=True), B=3, dtype="float32", tol=2e-4),
     "config3_vit_base_e64_f16": dict(cfg=dict(img_size=(224, 224), embed_dim=768, depth=2, num_heads=12, mlp_ratio=4.0,
                                               moe_mlp_ratio=1.0, moe_experts=64, moe_top_k=4, gate_dim=770, multi_gate=True),
-                                     B=2, dtype="float16", tol=2e-4),
+                                     B=2, dtype="float16", tol=1e-3),
     "config4_vit_base_ratio4_n1201_f16": dict(cfg=dict(img_size=(480, 640), embed_dim=768, depth=2, num_heads=12, mlp_ratio=4.0,
                                                        moe_mlp_ratio=4.0, moe_experts=16, moe_top_k=4, gate_dim=770,
-                                                       multi_gate=True), B=1, dtype="float16", tol=2e-4),
+                                                       multi_gate=True), B=1, dtype="float16", tol=1e-3),
 }
 
 
@@ -37,8 +37,12 @@ def _worker(rank, world, port, q, case="toy_f32"):
     """The expert-parallel engine (experts sharded over two ranks, custom_moe_layer.py:263-265 behind
     utils/common_config.py:179-185) against the same engine with every expert local, on this rank's own images: tokens,
     balance loss, every gradient (this rank's experts saw the rows of BOTH ranks), and the dense-only gradient sync.
-    Both engines run the same kernels on the same rows (a routed row's result does not depend on its slot), so the
-    comparison is tight in fp16 too: what differs is the fp32 summation order of the weight gradients."""
+    Both engines run the same kernels on the same rows (a routed row's result does not depend on its slot): the forward is
+    compared at 1e-4 in fp16 too.  The backward rounds at different points by design - with local experts d y = score * d x
+    is never materialised (FC2's backward GEMMs take fp16(d x) and apply the score on the way: fp16(score * fp16(d x))),
+    with sharded experts it must cross the wire (fp16(score * d x) from the fp32 d x) - so in fp16 the expert FC2
+    gradients differ by one fp16 rounding per element (measured 3.5e-4 relative L2 at ~25 rows per expert); bound 1e-3,
+    the fp16 bound of tests/test_engine.py."""
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -64,7 +68,7 @@ def _worker(rank, world, port, q, case="toy_f32"):
             for i in range(cfg.depth):
                 if cfg.is_moe(i):                                   # same routing on both engines
                     assert torch.equal(ep.act[i]["gate"]["idx"], ref.act[i]["gate"]["idx"]), (task, i)
-            assert rel(t_ep, t_ref) < tol / 10, ("tokens", task, rel(t_ep, t_ref))
+            assert rel(t_ep, t_ref) < (1e-5 if dtype == torch.float32 else 1e-4), ("tokens", task, rel(t_ep, t_ref))
             assert abs(float(cv_ep) - float(cv_ref)) < 1e-5 * max(1.0, abs(float(cv_ref)))
             ref.backward(dtok, cv_weight=0.01)
             ep.backward(dtok, cv_weight=0.01)
