@@ -69,6 +69,10 @@ def parse():
     ap.add_argument("--no-share-stem", action="store_true", help="do not time the shared-stem schedule at all")
     ap.add_argument("--ep", action="store_true", help="N > 1: time ONLY the expert-parallel form (experts sharded over the "
                     "ranks, all-to-all over RCCL); default: expert parallel (primary, when E %% N == 0) AND data parallel")
+    ap.add_argument("--ep-capacity", type=float, default=0.0, help="N > 1, expert parallel: exchange the routed rows with a fixed "
+                    "capacity of this multiple of the uniform share per (source, destination) pair (e.g. 1.25) instead of the exact "
+                    "a2a-v: no host read inside the step, one flag read at its end, the step repeated on the exact path on overflow "
+                    "(MultiTaskStep ep_capacity); default 0 = exact exchange")
     ap.add_argument("--dp-only", action="store_true", help="N > 1: time only the replicated-experts data-parallel form")
     ap.add_argument("--no-f32", action="store_true", help="N = 1: skip the fp32 run reported as the sub-object \"f32\"")
     ap.add_argument("--module-path", action="store_true", help="N = 1: time ONLY the drop-in module path (install_fmoe_shim() + "
@@ -224,7 +228,8 @@ def main():
         runner = MultiTaskStep(cfg, params, batch=args.batch, dtype=dtype, device=str(dev), cv_weight=CV_WEIGHT,
                                parallel_tasks=not args.serial_tasks, graph=not args.no_graph, world=world, rank=rank,
                                expert_parallel=expert_parallel, wgrad_streams=args.wgrad_streams, dp_parts=args.dp_parts,
-                               checkpoint=args.checkpoint, share_stem=share_stem)
+                               checkpoint=args.checkpoint, share_stem=share_stem,
+                               ep_capacity=args.ep_capacity if expert_parallel else 0.0)
         use_ep, par_tasks, ntasks = runner.use_ep, runner.par or runner.par_ep, len(runner.tasks)
         g = torch.Generator().manual_seed(1000 + rank)          # each rank its own images
         images = torch.randn(args.batch, 3, *cfg.img_size, generator=g).to(dev)
@@ -279,6 +284,8 @@ def main():
                "task_passes": ntasks, "tokens_per_image": cfg.num_tokens,
                "activation_checkpointing": bool(args.checkpoint), "shared_stem": bool(runner.share_stem),
                "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+               "ep_exchange": (None if not use_ep else ("exact a2a-v (2 W split sizes read per MoE layer and pass)" if not runner.ep_capacity
+                               else f"fixed capacity {runner.ep_capacity} x R / W per pair, {runner.ep_repeats} step(s) repeated on the exact path")),
                "parallelism": "single" if world == 1 else (f"dp{world}+ep{world} (experts sharded, {coll} all-to-all + all-reduce)"
                                                             if use_ep else f"dp{world} (replicated experts, {coll} all-reduce)")}
         if want_roofline:
@@ -493,7 +500,7 @@ def main():
         want_ep = args.ep or (not args.dp_only and E % world == 0)
         want_dp = not args.ep
         results = {}
-        sub = ("value", "ms_per_step", "model_tflops", "launch", "parallelism")
+        sub = ("value", "ms_per_step", "model_tflops", "launch", "parallelism", "ep_exchange")
         # The legs, in this order: data parallel first - it needs one collective (all-reduce) and its line must survive whatever
         # the expert-parallel leg (count all-to-all + uneven all-to-all-v on several streams) does at its first contact with
         # RCCL; the opt-in shared-stem data-parallel leg (--share-stem; the one-GPU gloo rehearsal stalls in it, DESIGN

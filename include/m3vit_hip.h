@@ -142,6 +142,19 @@ int m3_route_build(const int32_t *idx32, int64_t n, int E, int32_t *counts, int3
  * tile_starts i32 [E_loc+1] as m3_route_build writes them.  W * E_loc <= 4096. */
 int m3_ep_plan(const int64_t *send_counts, const int64_t *recv_counts, int W, int E_loc, int64_t *splits,
                int32_t *regroup, int64_t regroup_cap, int32_t *offsets, int32_t *tile_starts, void *stream);
+/* The same plan for an exchange with a FIXED row capacity per (source, destination) pair (same reference call site): every
+ * pair exchanges exactly `cap` rows, the valid ones first, so the all-to-all has equal splits, the host reads nothing and a
+ * step with sharded experts can be captured into a hipGraph.  row_of_slot / pos i32 [n_rows]: this rank's m3_route_build
+ * output.  Outputs: regroup i32 [W*cap] (indices into the padded received buffer [W*cap, D]; the first offsets[E_loc]
+ * entries are valid), offsets / tile_starts i32 [E_loc+1], pad_idx i32 [W*cap] (token-major entry whose row goes to
+ * position q of the padded send buffer: gather with m3_gather_rows(div = k)), unpad_idx i32 [n_rows] (position of entry
+ * i's expert output in the returned padded buffer), splits i64 [2W] (true row counts, informational), *overflow i32 set to
+ * 1 (never cleared) when some pair routes more than cap rows: such a pair keeps its first cap rows on both sides, the
+ * results are incomplete and the caller repeats the step with m3_ep_plan.  W <= 64, W * E_loc <= 4096. */
+int m3_ep_plan_fixed(const int64_t *send_counts, const int64_t *recv_counts, int W, int E_loc, int cap,
+                     const int32_t *row_of_slot, const int32_t *pos, int64_t n_rows, int64_t *splits,
+                     int32_t *regroup, int32_t *offsets, int32_t *tile_starts, int32_t *pad_idx,
+                     int32_t *unpad_idx, int32_t *overflow, void *stream);
 
 /* -------------------------------------------------- GEMM family (a6, a8, a10)
  * C[m, n] = epilogue( sum_k A[arow(m), k] * B[g(m)][n, k] )      ("NT": both K-contiguous)

@@ -130,9 +130,14 @@ __global__ __launch_bounds__(RT_THREADS) void route_assign_kernel(const int32_t 
 // i-th row of the expert-major order.  Also: the a2a-v split sizes (the only values the host reads), the expert-major
 // group offsets and the 128-row tile prefix the grouped GEMMs take.
 constexpr int EP_MAX_BLOCKS = 64 * 64;       // W * E_loc (sources x local experts)
+//
+// Fixed-capacity form (cap > 0; m3_ep_plan_fixed): every (source, destination) pair exchanges exactly `cap` rows (equal
+// splits: nothing of the exchange is read by the host, so a step can be captured), the valid rows first.  A source's rows
+// then land at s * cap + their prefix within the source; a pair that routes more than `cap` rows keeps the FIRST cap rows
+// of its (expert, token) order on both sides, raises *overflow and the caller repeats the step on the exact path.
 __global__ __launch_bounds__(256) void ep_plan_kernel(const int64_t *send, const int64_t *recv, int W, int E_loc,
                                                       int64_t *splits, int32_t *rg, int64_t rg_cap, int32_t *offsets,
-                                                      int32_t *tile_starts) {
+                                                      int32_t *tile_starts, int cap, int32_t *overflow) {
   __shared__ int32_t src_start[EP_MAX_BLOCKS + 1]; // [s * E_loc + e]: first received row of block (s, e)
   __shared__ int32_t em_start[EP_MAX_BLOCKS + 1]; // [e * W + s]: first expert-major slot of block (e, s)
   __shared__ int32_t part[256];
@@ -159,7 +164,29 @@ __global__ __launch_bounds__(256) void ep_plan_kernel(const int64_t *send, const
     __syncthreads();
   };
   scan([&](int q) { return (int32_t)recv[q]; }, src_start);                                   // order (s, e); src_start[nb] unused
-  scan([&](int q) { const int e = q / W, sr = q - e * W; return (int32_t)recv[sr * E_loc + e]; }, em_start);   // order (e, s)
+  // rows of block (s, e) that fit the pair's capacity (all of them on the exact path)
+  auto kept = [&](int sr, int e) -> int32_t {
+    const int b = sr * E_loc + e;
+    if (cap <= 0) return (int32_t)recv[b];
+    const int32_t before = src_start[b] - src_start[sr * E_loc];          // rows of source sr in front of expert e
+    const int32_t lo_ = before < cap ? before : cap;
+    const int32_t hi_ = before + (int32_t)recv[b] < cap ? before + (int32_t)recv[b] : cap;
+    return hi_ - lo_;
+  };
+  scan([&](int q) { const int e = q / W, sr = q - e * W; return kept(sr, e); }, em_start);   // order (e, s)
+  if (cap > 0) {
+    // received row of block (s, e): s * cap + min(rows of s in front of e, cap)   (every thread rewrites the same values)
+    __syncthreads();
+    for (int sr = 0; sr < W; ++sr) {
+      const int32_t base = src_start[sr * E_loc];
+      __syncthreads();
+      for (int e = tid; e < E_loc; e += 256) {
+        const int32_t before = src_start[sr * E_loc + e] - base;
+        src_start[sr * E_loc + e] = sr * cap + (before < cap ? before : cap);
+      }
+      __syncthreads();
+    }
+  }
   if (blockIdx.x == 0) {
     if (tid == 0) {
       int32_t ts = 0;
@@ -176,6 +203,7 @@ __global__ __launch_bounds__(256) void ep_plan_kernel(const int64_t *send, const
       for (int e = 0; e < E_loc; ++e) { a_ += send[d * E_loc + e]; b_ += recv[d * E_loc + e]; }
       splits[d] = a_;            // rows this rank sends to rank d
       splits[W + d] = b_;        // rows this rank receives from rank d
+      if (cap > 0 && overflow && (a_ > cap || b_ > cap)) *overflow = 1;
     }
   }
   const int64_t n = em_start[nb] < rg_cap ? em_start[nb] : rg_cap;
@@ -187,6 +215,42 @@ __global__ __launch_bounds__(256) void ep_plan_kernel(const int64_t *send, const
     }
     const int e = lo / W, s = lo - e * W;
     rg[i] = src_start[s * E_loc + e] + (int32_t)(i - em_start[lo]);
+  }
+}
+
+// Index vectors of the fixed-capacity exchange.  send: this rank's route_build counts by global expert id, so the
+// expert-major slots [send_off[d], send_off[d + 1]) go to rank d.
+//   pad_idx[d * cap + j]  = row_of_slot[send_off[d] + j]  (token-major entry whose row is the j-th sent to rank d; past the
+//                           pair's rows: the last valid one - the receiver never looks at those rows)
+//   unpad_idx[i]          = d * cap + (pos[i] - send_off[d])  (where entry i's expert output sits in the returned padded
+//                           buffer; an entry that did not fit reads the pair's last row - the step is repeated anyway)
+__global__ __launch_bounds__(256) void ep_pad_index_kernel(const int64_t *send, int W, int E_loc, int cap,
+                                                           const int32_t *row_of_slot, const int32_t *pos, int64_t n,
+                                                           int32_t *pad_idx, int32_t *unpad_idx) {
+  __shared__ int32_t send_off[65];
+  if (threadIdx.x == 0) {
+    int32_t o = 0;
+    for (int d = 0; d < W; ++d) {
+      send_off[d] = o;
+      for (int e = 0; e < E_loc; ++e) o += (int32_t)send[d * E_loc + e];
+    }
+    send_off[W] = o;
+  }
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t q = i0; q < (int64_t)W * cap; q += stride) {
+    const int d = (int)(q / cap), j = (int)(q - (int64_t)d * cap);
+    const int32_t nd = send_off[d + 1] - send_off[d];
+    int32_t slot = send_off[d] + (j < nd ? j : (nd > 0 ? nd - 1 : 0));
+    if (slot >= n) slot = n > 0 ? (int32_t)n - 1 : 0;
+    pad_idx[q] = n > 0 ? row_of_slot[slot] : 0;
+  }
+  for (int64_t i = i0; i < n; i += stride) {
+    const int32_t slot = pos[i];
+    int d = 0;
+    while (d + 1 < W && send_off[d + 1] <= slot) ++d;
+    const int32_t j = slot - send_off[d];
+    unpad_idx[i] = d * cap + (j < cap ? j : cap - 1);
   }
 }
 
@@ -227,6 +291,26 @@ extern "C" int m3_ep_plan(const int64_t *send_counts, const int64_t *recv_counts
   const int64_t want = (regroup_cap + 255) / 256;
   const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 512 ? 512 : want));
   hipLaunchKernelGGL(ep_plan_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, send_counts, recv_counts, W, E_loc, splits,
-                     regroup, regroup_cap, offsets, tile_starts);
+                     regroup, regroup_cap, offsets, tile_starts, 0, (int32_t *)nullptr);
   return check_launch("m3_ep_plan");
+}
+
+extern "C" int m3_ep_plan_fixed(const int64_t *send_counts, const int64_t *recv_counts, int W, int E_loc, int cap,
+                                const int32_t *row_of_slot, const int32_t *pos, int64_t n_rows, int64_t *splits,
+                                int32_t *regroup, int32_t *offsets, int32_t *tile_starts, int32_t *pad_idx,
+                                int32_t *unpad_idx, int32_t *overflow, void *stream) {
+  M3_REQUIRE(send_counts && recv_counts && splits && regroup && offsets && tile_starts && pad_idx && unpad_idx && overflow &&
+             row_of_slot && pos, "m3_ep_plan_fixed: null operand");
+  M3_REQUIRE(W >= 1 && W <= 64 && E_loc >= 1 && W * E_loc <= EP_MAX_BLOCKS, "m3_ep_plan_fixed: W = %d, E_loc = %d out of range", W, E_loc);
+  M3_REQUIRE(cap >= 1 && (int64_t)W * cap < ((int64_t)1 << 31) && n_rows >= 0 && n_rows < ((int64_t)1 << 31),
+             "m3_ep_plan_fixed: capacity / row count out of range");
+  const int64_t rg_cap = (int64_t)W * cap;
+  const int64_t want = (rg_cap + 255) / 256;
+  const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 512 ? 512 : want));
+  hipLaunchKernelGGL(ep_plan_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, send_counts, recv_counts, W, E_loc, splits,
+                     regroup, rg_cap, offsets, tile_starts, cap, overflow);
+  const int64_t w2 = ((n_rows > rg_cap ? n_rows : rg_cap) + 255) / 256;
+  hipLaunchKernelGGL(ep_pad_index_kernel, dim3((unsigned)(w2 < 1 ? 1 : (w2 > 512 ? 512 : w2))), dim3(256), 0, (hipStream_t)stream,
+                     send_counts, W, E_loc, cap, row_of_slot, pos, n_rows, pad_idx, unpad_idx);
+  return check_launch("m3_ep_plan_fixed");
 }

@@ -39,7 +39,7 @@ class _Cfg:
 class BackboneEngine:
     def __init__(self, cfg, params: Dict[str, torch.Tensor], batch: int, dtype=torch.float16,
                  device="cuda:0", ep_group=None, ep_world: int = 1, ep_rank: int = 0, share: "BackboneEngine" = None,
-                 wgrad_stream: bool = False, checkpoint: bool = False):
+                 wgrad_stream: bool = False, checkpoint: bool = False, ep_capacity: float = 0.0):
         """params: GLOBAL parameters (all E experts).  With ep_world > 1 this rank keeps experts
         [ep_rank*E/W, (ep_rank+1)*E/W) (utils/common_config.py:179-185) and exchanges routed rows with
         the other ranks over torch.distributed (RCCL) - see _experts_fwd_ep.
@@ -54,7 +54,14 @@ class BackboneEngine:
         its backward.  All blocks then share ONE set of activation buffers.  With sharded experts (ep_world > 1, the
         reference's default combination) the recompute repeats NO collective: what crossed the wire in the forward - the
         exchange plan, the rows received for the local experts and the expert outputs that came back - is kept per MoE
-        block, and only the local work (gate, FC1 of the local experts) is re-run."""
+        block, and only the local work (gate, FC1 of the local experts) is re-run.
+        ep_capacity (with ep_world > 1; 0 = off): exchange the routed rows with a FIXED capacity of
+        ceil(ep_capacity * R / W) rows per (source, destination) pair (R = T * k rows routed by a rank; 1.25 leaves a
+        quarter of head room over a uniform routing) instead of the exact a2a-v: equal splits, the plan stays on the device
+        (m3_ep_plan_fixed), NOTHING of the exchange is read by the host - one host read per STEP (ep_overflowed()) instead
+        of one per MoE layer and pass, and a step that a collective library can capture.  A pair that routes more rows than
+        the capacity raises the flag; the step's results are then incomplete and the caller repeats it on the exact path
+        (MultiTaskStep does)."""
         assert not (checkpoint and wgrad_stream), "checkpoint mode re-uses the activation buffers a wgrad stream may still read"
         self.checkpoint = bool(checkpoint)
         assert dtype in (torch.float16, torch.bfloat16, torch.float32), "activation dtype: float16, bfloat16 or float32"
@@ -63,6 +70,9 @@ class BackboneEngine:
         self.dt = dtype
         self.B = batch
         self.ep_group, self.ep_world, self.ep_rank = ep_group, int(ep_world), int(ep_rank)
+        self.ep_capacity = float(ep_capacity) if int(ep_world) > 1 else 0.0
+        assert not (self.ep_capacity and checkpoint), "fixed-capacity exchange: not with activation checkpointing"
+        self.ep_fixed = self.ep_capacity > 0.0                 # switched off by the step runner for the exact repeat of a step
         self.D = cfg.embed_dim
         self.heads = cfg.num_heads
         self.dh = self.D // self.heads
@@ -198,9 +208,12 @@ class BackboneEngine:
         self.ones_k = torch.ones(T, self.k, dtype=f32, device=self.dev)
         # shared workspaces
         wg = 0
-        for (M, N, K, G) in [(T, self.Hd, D, 1), (T, D, self.Hd, 1), (T, 3 * D, D, 1), (T, D, D, 1),
-                             (R, self.Hm, D, self.E), (R, D, self.Hm, self.E), (self.B * self.np_, D, Kp, 1),
-                             (T, D, self.E, 1)]:
+        shapes = [(T, self.Hd, D, 1), (T, D, self.Hd, 1), (T, 3 * D, D, 1), (T, D, D, 1),
+                  (R, self.Hm, D, self.E), (R, D, self.Hm, self.E), (self.B * self.np_, D, Kp, 1), (T, D, self.E, 1)]
+        if self.ep_capacity:                                   # the padded exchange contracts over the capacity bound
+            ncap = self.ep_world * ((-(-int(self.ep_capacity * R + self.ep_world - 1) // self.ep_world) + 7) // 8 * 8)
+            shapes += [(ncap, self.Hm, D, self.E_loc), (ncap, D, self.Hm, self.E_loc)]
+        for (M, N, K, G) in shapes:
             wg = max(wg, ops.wgrad_ws_elems(M, N, K, G, grouped=G > 1, dtype=self.dt))
         # weight-gradient slab reductions ride in front of the NEXT weight-gradient launch of the pass (ops.WgradQueue: two
         # slab workspaces used in turn); with a wgrad side stream every call reduces for itself (its launches are not in
@@ -236,6 +249,19 @@ class BackboneEngine:
             self.ep_regroup = {i: torch.empty(self.ep_world * R, dtype=torch.int32, device=self.dev)
                                for i in range(self.depth) if self.is_moe[i]}
             self.ep_splits_host = torch.empty(2 * self.ep_world, dtype=torch.int64, pin_memory=True)
+            if self.ep_capacity:
+                W = self.ep_world
+                self.ep_cap = -(-int(self.ep_capacity * R + W - 1) // W)                # rows per (source, destination) pair
+                self.ep_cap = (self.ep_cap + 7) // 8 * 8
+                self.ep_overflow = torch.zeros(1, dtype=torch.int32, device=self.dev)
+                n = W * self.ep_cap
+                # static buffers of the padded exchange, per MoE block (a captured step replays on fixed addresses)
+                self.ep_fx = {i: dict(x_send=self._e(n, D), x_recv=self._e(n, D), hid_pre=self._e(n, self.Hm),
+                                      hid=self._e(n, self.Hm), y_recv=self._e(n, D), y_back=self._e(n, D),
+                                      recv_counts=torch.empty(self.E, dtype=torch.int64, device=self.dev), plan=None)
+                              for i in range(self.depth) if self.is_moe[i]}
+                self.ep_fx_bwd = dict(dy_send=self._e(n, D), dy_recv=self._e(n, D), dhp=self._e(n, self.Hm),
+                                      dx_recv=self._e(n, D), dx_back=self._e(n, D))
 
     def cfg_d_gate(self):
         g = self.cfg.gate_task_specific_dim
@@ -482,6 +508,8 @@ class BackboneEngine:
         import torch.distributed as dist
         b = f"blocks.{i}."
         p, k, D, dev = self.params, self.k, self.D, self.dev
+        if self.ep_fixed:
+            return self._experts_fwd_ep_fixed(i, a, g)
         if recompute:
             ep = a["ep"]
             n = ep["n"]
@@ -520,9 +548,73 @@ class BackboneEngine:
             ep["hid_pre"] = ep["hid"] = None
         a["ep"] = ep
 
+    def _a2a_equal(self, x, out):
+        """all-to-all with equal splits (the fixed-capacity exchange): no sizes, nothing for the host to read"""
+        import torch.distributed as dist
+        dist.all_to_all_single(out, x, group=self.ep_group)
+        return out
+
+    def _experts_fwd_ep_fixed(self, i, a, g):
+        """_experts_fwd_ep with ep_cap rows per (source, destination) pair: the send buffer is the padded [W * cap, D]
+        image gathered straight from h2 through pad_idx, rows arrive at source * cap + ..., the grouped GEMMs take the
+        device-resident regroup / offsets / tile prefix with M = the capacity bound (surplus workgroups retire on the
+        device-side tile prefix), and the outputs come home through unpad_idx."""
+        import torch.distributed as dist
+        b = f"blocks.{i}."
+        p, k = self.params, self.k
+        fx = self.ep_fx[i]
+        W, cap = self.ep_world, self.ep_cap
+        n = W * cap
+        r = ops.route_build(g["idx32"], self.E, want_counts64=True)
+        a["route"] = r
+        dist.all_to_all_single(fx["recv_counts"], r.counts64, group=self.ep_group)
+        plan = fx["plan"] = ops.ep_plan_fixed(r.counts64, fx["recv_counts"], W, self.E_loc, cap, r, self.ep_overflow,
+                                              bufs=fx["plan"])
+        ops.gather_rows(a["h2"], plan.pad_idx, fx["x_send"], div=k)
+        self._a2a_equal(fx["x_send"], fx["x_recv"])
+        ops.gemm_nt(fx["x_recv"], self.wc[b + "mlp.experts.htoh4"], fx["hid"], M=n, bias=p[b + "mlp.experts.htoh4.bias"],
+                    act=M3_ACT_GELU, pre_out=fx["hid_pre"], a_row_idx=plan.regroup, a_row_div=1,
+                    group_offsets=plan.offsets, tile_starts=plan.tile_starts)
+        ops.gemm_nt(fx["hid"], self.wc[b + "mlp.experts.h4toh"], fx["y_recv"], M=n, bias=p[b + "mlp.experts.h4toh.bias"],
+                    c_row_idx=plan.regroup, group_offsets=plan.offsets, tile_starts=plan.tile_starts)
+        self._a2a_equal(fx["y_recv"], fx["y_back"])
+        ops.gather_rows(fx["y_back"], plan.unpad_idx, a["y"])            # back to token-major [T*k, D]
+        a["ep"] = dict(fixed=True)
+
+    def _experts_bwd_ep_fixed(self, i, a):
+        b = f"blocks.{i}."
+        fx, fb = self.ep_fx[i], self.ep_fx_bwd
+        plan = fx["plan"]
+        n = self.ep_world * self.ep_cap
+        rg = plan.regroup
+        ops.gather_rows(self.s_dy, plan.pad_idx, fb["dy_send"])
+        self._a2a_equal(fb["dy_send"], fb["dy_recv"])
+        self._wgrad(fb["dy_recv"], fx["hid"], b + "mlp.experts.h4toh.weight", M=n, c_row_idx=rg,
+                    group_offsets=plan.offsets, bias=b + "mlp.experts.h4toh.bias")
+        ops.gemm_nt(fb["dy_recv"], self.wt[b + "mlp.experts.h4toh"], fb["dhp"], M=n, gelu_grad_pre=fx["hid_pre"],
+                    a_row_idx=rg, a_row_div=1, group_offsets=plan.offsets, tile_starts=plan.tile_starts)
+        self._wgrad(fb["dhp"], fx["x_recv"], b + "mlp.experts.htoh4.weight", M=n, a_row_idx=rg, a_row_div=1,
+                    group_offsets=plan.offsets, bias=b + "mlp.experts.htoh4.bias")
+        ops.gemm_nt(fb["dhp"], self.wt[b + "mlp.experts.htoh4"], fb["dx_recv"], M=n, c_row_idx=rg,
+                    group_offsets=plan.offsets, tile_starts=plan.tile_starts)
+        self._a2a_equal(fb["dx_recv"], fb["dx_back"])
+        ops.gather_rows(fb["dx_back"], plan.unpad_idx, self.s_dxe)
+
+    def ep_overflowed(self) -> bool:
+        """fixed-capacity exchange: did any (source, destination) pair of any layer since the last call route more rows
+        than the capacity?  ONE host read; clears the flag."""
+        if not self.ep_capacity:
+            return False
+        over = bool(int(self.ep_overflow.item()))
+        if over:
+            self.ep_overflow.zero_()
+        return over
+
     def _experts_bwd_ep(self, i, a):
         """mirror of _experts_fwd_ep: self.s_dy (token-major d y) -> expert grads (local experts only) and
         self.s_dxe (token-major d of the routed input copies)."""
+        if a["ep"].get("fixed"):
+            return self._experts_bwd_ep_fixed(i, a)
         b = f"blocks.{i}."
         k, D, r, ep = self.k, self.D, a["route"], a["ep"]
         plan, n = ep["plan"], ep["n"]

@@ -188,6 +188,36 @@ def ep_plan(send_counts64, recv_counts64, world: int, e_loc: int, regroup_buf: t
     return p
 
 
+class EpPlanFixed:
+    """Device-resident plan of a fixed-capacity exchange (m3_ep_plan_fixed): nothing of it is read by the host."""
+    __slots__ = ("cap", "world", "regroup", "offsets", "tile_starts", "pad_idx", "unpad_idx", "splits")
+
+
+def ep_plan_fixed(send_counts64, recv_counts64, world: int, e_loc: int, cap: int, route: "Route", overflow: torch.Tensor,
+                  bufs: Optional[EpPlanFixed] = None) -> EpPlanFixed:
+    """Plan of one expert-parallel exchange with `cap` rows per (source, destination) pair, entirely on the device.
+    overflow: i32 [1] flag the kernel raises (and never clears) when a pair routes more than cap rows.
+    bufs: a previous plan whose index buffers are overwritten (static addresses for a captured step)."""
+    _req(send_counts64, torch.int64, "send_counts"); _req(recv_counts64, torch.int64, "recv_counts")
+    _req(overflow, torch.int32, "overflow")
+    dev = send_counts64.device
+    p = bufs
+    if p is None:
+        p = EpPlanFixed()
+        p.cap, p.world = int(cap), int(world)
+        p.regroup = torch.empty(world * cap, dtype=torch.int32, device=dev)
+        p.pad_idx = torch.empty(world * cap, dtype=torch.int32, device=dev)
+        p.unpad_idx = torch.empty(max(route.n, 1), dtype=torch.int32, device=dev)
+        p.offsets = torch.empty(e_loc + 1, dtype=torch.int32, device=dev)
+        p.tile_starts = torch.empty(e_loc + 1, dtype=torch.int32, device=dev)
+        p.splits = torch.empty(2 * world, dtype=torch.int64, device=dev)
+    assert p.cap == cap and p.world == world and p.unpad_idx.numel() >= route.n
+    check(lib().m3_ep_plan_fixed(_p(send_counts64), _p(recv_counts64), world, e_loc, cap, _p(route.row_of_slot), _p(route.pos),
+                                 route.n, _p(p.splits), _p(p.regroup), _p(p.offsets), _p(p.tile_starts), _p(p.pad_idx),
+                                 _p(p.unpad_idx), _p(overflow), _stream()), "m3_ep_plan_fixed")
+    return p
+
+
 # ----------------------------------------------------------------------------- GEMM
 def gemm_nt(A, B, C, *, M=None, bias=None, act=M3_ACT_NONE, pre_out=None, gelu_grad_pre=None, residual=None,
             a_row_idx=None, a_row_div=1, c_row_idx=None, group_offsets=None, tile_starts=None, row_scale=None,

@@ -27,16 +27,23 @@ from .engine import BackboneEngine
 class MultiTaskStep:
     def __init__(self, cfg, params, batch: int, dtype=torch.float16, device="cuda:0", tasks=None, cv_weight: float = 0.01,
                  parallel_tasks: bool = True, graph: bool = True, world: int = 1, rank: int = 0, expert_parallel: bool = False,
-                 wgrad_streams: bool = False, dp_parts: int = 6, checkpoint: bool = False, share_stem: bool = False):
+                 wgrad_streams: bool = False, dp_parts: int = 6, checkpoint: bool = False, share_stem: bool = False,
+                 ep_capacity: float = 0.0):
+        """ep_capacity (expert parallel only; 0 = the exact exchange): fixed row capacity of the exchange as a multiple of
+        the uniform share R / W per (source, destination) pair (BackboneEngine ep_capacity).  The step then reads ONE flag
+        on the host, at its end, instead of 2 W split sizes per MoE layer and pass, and repeats itself on the exact path
+        when some pair overflowed (same gradients either way: tests/test_ep_engine_gpu.py)."""
         self.cfg, self.dev, self.world, self.cv_weight = cfg, torch.device(device), int(world), float(cv_weight)
         if tasks is None:
             tasks = list(range(cfg.num_tasks)) if (cfg.multi_gate or cfg.gate_task_specific_dim >= 0) else [None]
         self.tasks = list(tasks)
         self.use_ep = bool(expert_parallel) and self.world > 1
         wg = bool(wgrad_streams) and not self.use_ep
+        self.ep_capacity = float(ep_capacity) if self.use_ep else 0.0
+        self.ep_repeats = 0                              # steps repeated on the exact path after a capacity overflow
         self.eng = BackboneEngine(cfg, params, batch=batch, dtype=dtype, device=str(self.dev),
                                   ep_world=self.world if self.use_ep else 1, ep_rank=rank if self.use_ep else 0,
-                                  wgrad_stream=wg, checkpoint=checkpoint)
+                                  wgrad_stream=wg, checkpoint=checkpoint, ep_capacity=self.ep_capacity)
         self.par = bool(parallel_tasks) and not self.use_ep and len(self.tasks) > 1
         # expert parallel: the task passes still get their own engine contexts and streams, but their blocks are
         # interleaved on the host (_ep_interleaved): each pass stops once per MoE layer to read its exchange's split
@@ -44,7 +51,8 @@ class MultiTaskStep:
         self.par_ep = bool(parallel_tasks) and self.use_ep and len(self.tasks) > 1
         self.engs = [self.eng] + ([BackboneEngine(cfg, None, batch=batch, dtype=dtype, device=str(self.dev), share=self.eng,
                                                    ep_world=self.world if self.use_ep else 1, ep_rank=rank if self.use_ep else 0,
-                                                   wgrad_stream=wg, checkpoint=checkpoint) for _ in self.tasks[1:]]
+                                                   wgrad_stream=wg, checkpoint=checkpoint, ep_capacity=self.ep_capacity)
+                                    for _ in self.tasks[1:]]
                                     if (self.par or self.par_ep) else [])
         # (measured and dropped in round 3, profiles/r03_stream_experiments.txt: a high-priority side stream serialises the
         # passes - 18.6 -> 24 ms - and starting pass 1 a few forward blocks behind pass 0 only lengthens the step)
@@ -81,7 +89,13 @@ class MultiTaskStep:
         # refused here and runs eagerly.
         self.capture_refused = None
         if self.use_ep:
-            self.capture_refused = "expert-parallel steps read the exchange's split sizes on the host"
+            import os
+            import torch.distributed as dist
+            # the fixed-capacity exchange reads nothing on the host inside the step, so a collective library whose calls
+            # can be captured (RCCL) could replay it; never tried on hardware (the build box has one GPU), hence opt-in
+            if not (self.ep_capacity and os.environ.get("M3_EP_CAPTURE") == "1" and dist.get_backend() == "nccl"):
+                self.capture_refused = ("expert-parallel steps read the exchange's split sizes on the host" if not self.ep_capacity
+                                        else "fixed-capacity expert-parallel step: capture is opt-in (M3_EP_CAPTURE=1, backend nccl)")
         elif wg and self.par:
             self.capture_refused = ("wgrad streams forked from forked task streams: hipStreamEndCapture (ROCm 7.2) segfaults on "
                                     "a nested fork (engine-free reproducer: tools/nested_capture_probe.py); use serial tasks or "
@@ -199,6 +213,29 @@ class MultiTaskStep:
             main.wait_stream(st)
         self._add(0, self.flat.numel())
 
+    def _ep_exact_repeat(self, run):
+        """fixed-capacity exchange: the ONE host read of the step - did any pair of any layer of any pass overflow?  Every
+        rank must take the same branch (the repeat issues collectives): the flags are OR-ed over the ranks first."""
+        if not self.ep_capacity:
+            return
+        import torch.distributed as dist
+        flag = self.engs[0].ep_overflow
+        for e in self.engs[1:]:
+            flag = torch.maximum(flag, e.ep_overflow)
+        flag = flag.clone()
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if not bool(int(flag.item())):
+            return
+        self.ep_repeats += 1
+        for e in self.engs:
+            e.ep_overflow.zero_()
+            e.ep_fixed = False
+        try:
+            run()
+        finally:
+            for e in self.engs:
+                e.ep_fixed = True
+
     def part(self, j: int):
         """part j of the step on the current stream (part 0 alone is the whole step unless the step is cut)"""
         if self.par_ep:
@@ -247,6 +284,7 @@ class MultiTaskStep:
     def _collective_step(self, parts):
         if not self.two_parts:
             parts[0]()
+            self._ep_exact_repeat(lambda: self.part(0))  # fixed-capacity exchange only: one flag read, a repeat on overflow
             self.eng.sync_grads(world=self.world)       # mean over ranks; the experts stay local under expert parallelism
             return
         import torch.distributed as dist

@@ -231,6 +231,94 @@ def test_expert_parallel_step_with_interleaved_task_streams_two_ranks_one_gpu():
     assert all(r[1] == "ok" for r in res), res
 
 
+def _ep_fixed_worker(rank, world, port, q):
+    """fixed-capacity exchange (BackboneEngine ep_capacity: equal-split all-to-all of ceil(1.25 R / W) rows per pair, plan on
+    the device, no host read inside the step) against the exact a2a-v path: identical tokens / loss / gradients when every
+    pair fits; with a routing skewed so that one pair overflows, the flag is raised on the device, the step runner repeats
+    the step on the exact path and again leaves the exact gradients.  The gate's arithmetic is the same on both paths, so
+    the comparison is bit-exact except for the slab order of the grouped weight gradients (different M bound)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from m3vit_amd.config import BackboneConfig, init_params
+        from m3vit_amd.engine import BackboneEngine
+        from m3vit_amd.step import MultiTaskStep
+        torch.cuda.set_device(0)
+        cfg = BackboneConfig(img_size=(32, 48), embed_dim=64, depth=4, num_heads=2, moe_experts=8, moe_top_k=2, gate_dim=66,
+                             multi_gate=True)
+        P = init_params(cfg, seed=3, zero_bias=False)
+        B = 4
+        g = torch.Generator().manual_seed(50 + rank)
+        img = torch.randn(B, 3, 32, 48, generator=g).cuda()
+        dtok = (torch.randn(B, cfg.num_tokens, 64, generator=g) * 0.1).cuda()
+        for dtype in (torch.float32, torch.float16):
+            exact = BackboneEngine(cfg, P, batch=B, dtype=dtype, ep_world=world, ep_rank=rank)
+            fixed = BackboneEngine(cfg, P, batch=B, dtype=dtype, ep_world=world, ep_rank=rank, ep_capacity=1.5)
+            assert fixed.ep_cap >= 1.5 * fixed.R / world and fixed.ep_cap % 8 == 0
+            orig_item = torch.Tensor.item
+            for task in (0, 1):
+                t0, c0 = exact.forward(img, task)
+                exact.backward(dtok, cv_weight=0.01)
+                reads = []
+                torch.Tensor.item = lambda self_, *a, **k: (reads.append(1), orig_item(self_, *a, **k))[1]
+                sync = torch.cuda.Stream.synchronize
+                torch.cuda.Stream.synchronize = lambda self_: (reads.append(1), sync(self_))[1]
+                try:
+                    t1, c1 = fixed.forward(img, task)
+                    fixed.backward(dtok, cv_weight=0.01)
+                finally:
+                    torch.Tensor.item = orig_item
+                    torch.cuda.Stream.synchronize = sync
+                assert not reads, "the fixed-capacity pass must not read anything on the host"
+                assert torch.equal(t0, t1) and torch.equal(c0, c1), (dtype, task, rel(t1, t0))
+            assert not fixed.ep_overflowed()
+            torch.cuda.synchronize()
+            tol = 1e-5 if dtype == torch.float32 else 1e-4
+            bad = [(n, rel(fixed.grads[n], exact.grads[n])) for n in exact.grads if rel(fixed.grads[n], exact.grads[n]) > tol]
+            assert not bad, (dtype, bad)
+            assert float(fixed.flat_grads.abs().max()) > 0
+        # overflow: a logit bias sends every token of BOTH ranks to experts 0 and 1 (rank 0's): the pair (r -> 0) carries
+        # all R rows against a capacity of 0.75 R, (r -> 1) none
+        bias = torch.zeros(cfg.moe_experts); bias[0] = 30.0; bias[1] = 20.0
+        lb = {i: bias.cuda() for i in range(cfg.depth) if cfg.is_moe(i)}
+        ref = MultiTaskStep(cfg, P, batch=B, dtype=torch.float32, world=world, rank=rank, expert_parallel=True)
+        cap = MultiTaskStep(cfg, P, batch=B, dtype=torch.float32, world=world, rank=rank, expert_parallel=True, ep_capacity=1.5)
+        for run in (ref, cap):
+            run.bind(img, dtok, logit_bias=lb)
+            run.step()
+        torch.cuda.synchronize()
+        assert cap.ep_repeats == 1, cap.ep_repeats
+        assert rel(cap.flat, ref.flat) < 1e-5, rel(cap.flat, ref.flat)
+        cap.bind(img, dtok)                                   # balanced routing again: no repeat, same gradients as exact
+        ref.bind(img, dtok)
+        ref.step(); cap.step()
+        torch.cuda.synchronize()
+        assert cap.ep_repeats == 1 and rel(cap.flat, ref.flat) < 1e-5
+        q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_expert_parallel_fixed_capacity_exchange_two_ranks_one_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ep_fixed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert all(r[1] == "ok" for r in res), res
+
+
 def _ep_ckpt_worker(rank, world, port, q):
     """expert parallel x activation checkpointing (the reference's default combination: train_fastmoe.py:178 with sharded
     experts): the recompute of a block in backward repeats no collective - the exchange plan, the received rows and the
