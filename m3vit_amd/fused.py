@@ -41,6 +41,7 @@ class _Slot:
         self.eng = eng
         self.stream = torch.cuda.Stream(device=device)
         self.busy = False
+        self.result = None
         self.calls_f, self.calls_b = {}, {}          # per task: number of forward / backward calls seen
         self.graphs_f, self.graphs_b = {}, {}
         self.images = self.dtok = None               # static inputs of the graphs
@@ -86,6 +87,11 @@ class FusedBackbone:
         self.anchor = None
         self.names = None
         self._join_queued = False
+        import os
+        self.prefetch = os.environ.get("M3VIT_PREFETCH", "1") != "0"
+        self.hist, self.pattern, self.spec, self.spec_images, self.spec_version = [], None, {}, None, 0
+        self.backoff, self.prefetch_misses = 0, 0
+        self.backward_seen = False
 
     # ------------------------------------------------------------------ eligibility
     @staticmethod
@@ -182,20 +188,87 @@ class FusedBackbone:
             # activation-dtype operand copies W, W^T of every Linear - one launch, ~0.1 ms (engine.prepare_weights)
             self.slots[0].eng.prepare_weights()
             self.dirty = False
-        slot = self._slot()
         if not train:
+            slot = self._slot()
             tok, cv = self._forward_eager(slot, task_id, images.float().contiguous(), False)
             tok = tok.clone()
             return tok, (tok.new_zeros(()) if not model.training else cv)
+        new_step = self.backward_seen or not self.hist          # first training forward after a backward: a new step begins
+        self.backward_seen = False
+        if new_step:
+            self._close_step()
+        # a pass that was started ahead of its call (see _prefetch): hand it over
+        hit = self.spec.pop(task_id, None) if (self.spec and images is self.spec_images and
+                                               images._version == self.spec_version) else None
+        if hit is None and self.spec:
+            self._drop_prefetched()                   # the caller did something else than last step: stop predicting for a while
+        self.hist.append((task_id, weakref.ref(images)))
+        if not self.spec:
+            self.spec_images = None
+        if hit is not None:
+            slot, tok, cv = hit
+            slot.main = main
+        else:
+            slot = self._launch(task_id, images, main)
+            tok, cv = slot.result
+            slot.result = None
+            if new_step:
+                self._prefetch(task_id, images, main)
+        main.wait_stream(slot.stream)
+        tok.record_stream(main)
+        cv.record_stream(main)
+        return tok, cv
+
+    def _launch(self, task_id, images, main):
+        """start one task pass on a free slot's stream, ordered behind everything queued on `main` so far; main is NOT made to
+        wait for it here"""
+        slot = self._slot()
         slot.busy, slot.main = True, main
         s = slot.stream
         s.wait_stream(main)
         with torch.cuda.stream(s):
-            tok, cv = _BackboneFn.apply(self.anchor, self, slot, task_id, images)
-        main.wait_stream(s)
-        tok.record_stream(main)
-        cv.record_stream(main)
-        return tok, cv
+            slot.result = _BackboneFn.apply(self.anchor, self, slot, task_id, images)
+        return slot
+
+    # ---- task passes started ahead of their call
+    # The reference's multi-task forward calls the backbone once per task on the SAME images (models/models.py:299-320), and
+    # between two such calls the caller's stream has to wait for the pass just returned (its tokens are consumed right
+    # away), so pass t + 1 cannot start before pass t is done: the forward passes of a step run one after the other where
+    # m3vit_amd.step.MultiTaskStep runs them side by side.  When the previous step called forward(x, t0), forward(x, t1), ..
+    # on one image tensor, the first call of this step also starts the passes of t1, .. on their own streams (they depend on
+    # x and the parameters only); their calls then find the result under way.  A call that does not match (other images,
+    # other task order) drops what was started - wasted GPU time, never a wrong result - and switches the prediction off
+    # for the next PREFETCH_BACKOFF steps.
+    PREFETCH_BACKOFF = 16
+
+    def _close_step(self):
+        """first training forward after a backward: the calls since the last boundary were one step"""
+        if self.spec:
+            self._drop_prefetched()
+        tasks = [t for t, _ in self.hist]
+        first = self.hist[0][1]() if self.hist else None
+        same = len(self.hist) >= 2 and first is not None and all(im() is first for _, im in self.hist) and \
+            len(set(tasks)) == len(tasks)
+        self.pattern = tasks if same else None
+        self.hist = []
+        if self.backoff > 0:
+            self.backoff -= 1
+
+    def _drop_prefetched(self):
+        self.spec.clear()                             # the nodes die with their outputs; _Release frees the slots
+        self.spec_images = None
+        self.backoff = self.PREFETCH_BACKOFF
+        self.prefetch_misses += 1
+
+    def _prefetch(self, task_id, images, main):
+        if not self.prefetch or self.backoff > 0 or not self.pattern or self.pattern[0] != task_id:
+            return
+        self.spec_images, self.spec_version = images, images._version
+        for t in self.pattern[1:]:
+            slot = self._launch(t, images, main)
+            tok, cv = slot.result
+            slot.result = None
+            self.spec[t] = (slot, tok, cv)
 
     def _draw(self, slot, eng):
         """per-step random inputs of the pass, drawn outside the graphs into the slot's static buffers: gate noise
@@ -342,6 +415,7 @@ class FusedBackbone:
             torch.autograd.Variable._execution_engine.queue_callback(self._join_caller)
         slot.busy = False
         self.dirty = True
+        self.backward_seen = True
 
     def _join_caller(self):
         self._join_queued = False

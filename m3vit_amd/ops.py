@@ -453,6 +453,8 @@ def wgrad_ws_elems(M, N, K, G, grouped, bias=True, dtype=None):
 
 
 _WGRAD_MIN_STEPS = 16      # 32-row steps per split at least (measured on the 8-image configs; no effect at batch 128)
+import os as _os
+_WGRAD_SLOTS = int(_os.environ.get("M3_WGRAD_SLOTS", "512"))      # workgroup slots a weight-gradient launch is split to fill (2 per CU)
 
 
 def wgrad_set_wide(on: int):
@@ -480,7 +482,7 @@ def default_wgrad_splits(M, N, K, G, dtype=None):
     steps = max(1, (M // max(G, 1) + 31) // 32)
     cap = max(1, steps // _WGRAD_MIN_STEPS)
     if (tn, tk) == (128, 128):
-        return int(max(1, min(cap, 32, 512 // tiles if tiles <= 512 else 1)))
+        return int(max(1, min(cap, 32, _WGRAD_SLOTS // tiles if tiles <= _WGRAD_SLOTS else 1)))
     slots = 256
     if 3 * tiles <= slots:
         return int(max(1, min(cap, slots // tiles)))

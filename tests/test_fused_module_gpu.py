@@ -248,3 +248,45 @@ def test_fused_module_origin_convention_and_task_conditioned_gate():
         assert not bad, (step, bad)
         assert float(m.gate_task_represent.fc1.weight.grad.abs().max()) > 0
     assert len(m._fused.slots) == 3
+
+
+def test_fused_module_prefetches_the_other_task_passes_and_survives_a_wrong_guess():
+    """After a step that called forward(x, 0), forward(x, 1) on one image tensor, the next step's forward(x, 0) also starts
+    the pass of task 1 on its own stream (m3vit_amd/fused.py _prefetch); its call finds the result under way - same tokens,
+    loss and gradients as without the prefetch.  A step that then does something else (other images for the second task)
+    drops the started pass, gets the right result all the same, and the prediction pauses."""
+    _need_gpu()
+    a, cfg = _model()
+    b, _ = _model()
+    imgs = [torch.randn(3, 3, 32, 48).cuda() for _ in range(6)]
+    dtok = (torch.randn(3, cfg.num_tokens, 64) * 0.1).cuda()
+
+    def step(m, x0, x1):
+        m.zero_grad(set_to_none=True)
+        loss = 0.0
+        for task, x in ((0, x0), (1, x1)):
+            tok, cv = m(x, task_id=task)
+            if m is b:
+                m._fused.prefetch = False
+            loss = loss + (tok * dtok).sum() + 0.01 * cv
+        loss.backward()
+        torch.cuda.synchronize()
+        return tok.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+
+    for i in range(4):                                      # same tensor for both tasks: prefetch from the third step on
+        ta, ga = step(a, imgs[i], imgs[i])
+        tb, gb = step(b, imgs[i], imgs[i])
+        assert torch.equal(ta, tb) and all(torch.equal(ga[n], gb[n]) for n in ga), i
+    fa = a._fused
+    assert fa.pattern == [0, 1] and fa.prefetch_misses == 0 and b._fused.prefetch_misses == 0
+    assert not fa.spec and not any(s.busy for s in fa.slots)
+    ta, ga = step(a, imgs[4], imgs[5])                     # the guess (task 1 on imgs[4]) is wrong
+    tb, gb = step(b, imgs[4], imgs[5])
+    assert fa.prefetch_misses == 1 and fa.backoff > 0
+    assert torch.equal(ta, tb) and all(torch.equal(ga[n], gb[n]) for n in ga)
+    import gc
+    gc.collect()
+    assert not any(s.busy for s in fa.slots)
+    ta, ga = step(a, imgs[0], imgs[0])                     # and on it goes
+    tb, gb = step(b, imgs[0], imgs[0])
+    assert torch.equal(ta, tb) and all(torch.equal(ga[n], gb[n]) for n in ga)
