@@ -77,6 +77,8 @@ typedef struct m3_gate_fwd_args {
   float *part_load_prob;            /* [nblk,E] or NULL: partial sums of _prob_in_top_k
                                        (vision_transformer_moe.py:33-71), the load of noisy training
                                        (:456-457; needs noise, noise_std != 0, k < E, clean and noisy) */
+  int32_t *part_count;              /* [nblk,E] or NULL: tokens of each 64-token block whose top-k holds expert e - the
+                                       routing histogram m3_route_build would count from idx (m3_balance_route scans it) */
 } m3_gate_fwd_args;
 int m3_gate_fwd(const m3_gate_fwd_args *args, void *stream);
 /* importance f32 [E], load i64 [E] from the per-block partials */
@@ -108,8 +110,19 @@ typedef struct m3_gate_bwd_args {
   int64_t T; int32_t E; int32_t k;
   float *d_logits;
   const float *balance_scale_dev;
+  void *d_logits_act; int32_t act_dtype;   /* optional second copy of d_logits in M3_F16 / M3_BF16 / M3_F32 (NULL: none) */
 } m3_gate_bwd_args;
 int m3_gate_bwd_logits(const m3_gate_bwd_args *args, void *stream);
+/* m3_balance_loss and the scan pass of m3_route_build in ONE launch (two workgroups): the dispatch metadata of
+ * custom_moe_layer.py:263-265 straight from the gate kernel's per-block counts, two launches less on every MoE layer's
+ * critical path.  part_count i32 [nblk,E] from m3_gate_fwd; outputs blk_base i32 [nblk,E] (exclusive prefix along the
+ * blocks, for m3_route_assign), counts i32 [E], offsets / tile_starts i32 [E+1], counts64 i64 [E] or NULL - as
+ * m3_route_build writes them. */
+int m3_balance_route(const float *part_importance, const int32_t *part_load, const float *part_load_prob,
+                     int nblk, int E, float *importance, int64_t *load, float *load_prob,
+                     float *loss_out, float *loss_acc, float *d_importance, float *d_load_prob,
+                     const int32_t *part_count, int32_t *blk_base, int32_t *counts, int32_t *offsets,
+                     int32_t *tile_starts, int64_t *counts64, void *stream);
 /* d_w_gate[D,E] (+)= x^T d_logits ; dx[T,D] (+)= d_logits w_gate^T  (noisy_gate_vmoe.py:91).
  * part_dw f32 [m3_gate_dw_blocks(T), D, E] workspace; dx fp32 accumulate (beta_dx 0/1). */
 int m3_gate_bwd_params(const void *x, int x_dtype, int64_t T, int D, int64_t ldx,
@@ -130,6 +143,11 @@ int64_t m3_route_ws_elems(int64_t n, int E);
 int m3_route_build(const int32_t *idx32, int64_t n, int E, int32_t *counts, int32_t *offsets,
                    int32_t *pos, int32_t *row_of_slot, int32_t *tile_starts, int64_t *counts64,
                    int32_t *ws, void *stream);
+
+/* The slot pass of m3_route_build on its own: stable slots pos / row_of_slot i32 [n] of the n = T*k entries of idx32 from
+ * the per-64-token-block prefixes blk_base and the expert offsets that m3_balance_route wrote.  k must divide 16. */
+int m3_route_assign(const int32_t *idx32, int64_t n, int E, int k, const int32_t *blk_base, const int32_t *offsets,
+                    int32_t *pos, int32_t *row_of_slot, void *stream);
 
 /* Expert-parallel exchange plan, on the device (what fastmoe's expert_exchange / global_scatter bookkeeping computes
  * on the host behind _fmoe_general_global_forward with world_size > 1, models/moe/ckpt/custom_moe_layer.py:263-265;

@@ -97,7 +97,7 @@ class GateFwdArgs(Structure):
         ("idx", c_void_p), ("idx32", c_void_p), ("idx_next", c_void_p),
         ("score", c_void_p), ("top_logits", c_void_p),
         ("clean", c_void_p), ("noisy", c_void_p), ("gates", c_void_p),
-        ("part_importance", c_void_p), ("part_load", c_void_p), ("part_load_prob", c_void_p),
+        ("part_importance", c_void_p), ("part_load", c_void_p), ("part_load_prob", c_void_p), ("part_count", c_void_p),
     ]
 
 
@@ -108,7 +108,7 @@ class GateBwdArgs(Structure):
         ("d_score", c_void_p), ("d_top", c_void_p), ("d_importance", c_void_p), ("d_load_prob", c_void_p),
         ("balance_scale", c_float), ("noise_std", c_float),
         ("T", c_int64), ("E", c_int32), ("k", c_int32),
-        ("d_logits", c_void_p), ("balance_scale_dev", c_void_p),
+        ("d_logits", c_void_p), ("balance_scale_dev", c_void_p), ("d_logits_act", c_void_p), ("act_dtype", c_int32),
     ]
 
 
@@ -124,6 +124,8 @@ SIGNATURES = {
     "m3_gate_fwd": (c_int, [POINTER(GateFwdArgs), _V]),
     "m3_gate_reduce": (c_int, [_V, _V, _I, _I, _V, _V, _V]),
     "m3_balance_loss": (c_int, [_V, _V, _V, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V]),
+    "m3_balance_route": (c_int, [_V, _V, _V, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V]),
+    "m3_route_assign": (c_int, [_V, _L, _I, _I, _V, _V, _V, _V, _V]),
     "m3_gate_bwd_logits": (c_int, [POINTER(GateBwdArgs), _V]),
     "m3_gate_bwd_params": (c_int, [_V, _I, _L, _I, _L, _V, _I, _V, _V, _V, _I, _V, _L, _I, _V]),
     "m3_route_ws_elems": (c_int64, [_L, _I]),

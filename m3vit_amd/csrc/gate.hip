@@ -38,6 +38,7 @@ struct GateFwdDev {
   int64_t *idx; int32_t *idx32; int32_t *idx_next; float *score; float *top_logits;
   float *clean; float *noisy; float *gates;
   float *part_imp; int32_t *part_load; float *part_load_prob;
+  int32_t *part_count;      // optional [nblk, E]: tokens of the block whose top-k holds expert e (the routing histogram)
 };
 
 // EW = experts per wave, NW = EPAD / EW waves per workgroup
@@ -251,6 +252,12 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
       }
       const float wsum = wave_sum(gv);
       const unsigned long long b = __ballot(gv > 0.f);
+      if (p.part_count) {
+        // routed entries per expert of this 64-token block: what m3_route_build's histogram pass would count from idx
+        // (NOT the load: a selected expert whose probability underflowed to 0 is routed all the same)
+        const unsigned long long bs = __ballot(sel && tok_ok);
+        if (lane == 0) p.part_count[(int64_t)blockIdx.x * E + e] = __popcll(bs);
+      }
       float psum = 0.f;
       if (prob_load) {
         // _prob_in_top_k, vision_transformer_moe.py:33-71: thresholds are PROBABILITIES, clean/noisy are logits
@@ -276,7 +283,48 @@ struct BalanceDev {
   float *importance; int64_t *load; float *load_prob;
   float *loss_acc; float *loss_out;
   float *d_importance; float *d_load_prob;
+  // routing scan riding along as workgroup 1 (m3_balance_route): per-block exclusive prefix of part_count along the block
+  // axis + the expert totals / offsets / 128-row tile prefix - what m3_route_build's second launch computes
+  const int32_t *part_count; int32_t *blk_base; int32_t *counts; int32_t *offsets; int32_t *tile_starts; int64_t *counts64;
 };
+
+// one wave per expert (64 blocks per step, shuffle scan), then offsets / tile prefix by one thread
+__device__ __forceinline__ void route_scan_blocks(const BalanceDev &p) {
+  __shared__ int32_t tot[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, E = p.E;
+  for (int e = wave; e < E; e += 1024 / 64) {
+    int32_t carry = 0;
+    for (int b0 = 0; b0 < p.nblk; b0 += 64) {
+      const int b = b0 + lane;
+      const int32_t v = b < p.nblk ? p.part_count[(int64_t)b * E + e] : 0;
+      int32_t inc = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int32_t up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+      }
+      if (b < p.nblk) p.blk_base[(int64_t)b * E + e] = carry + inc - v;
+      carry += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) {
+      tot[e] = carry;
+      p.counts[e] = carry;
+      if (p.counts64) p.counts64[e] = carry;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t o = 0, ts = 0;
+    for (int i = 0; i < E; ++i) {
+      p.offsets[i] = o;
+      p.tile_starts[i] = ts;
+      o += tot[i];
+      ts += (tot[i] + 127) / 128;
+    }
+    p.offsets[E] = o;
+    p.tile_starts[E] = ts;
+  }
+}
 
 __device__ __forceinline__ void cv2_and_grad(const float *v, int E, float &cv, float *grad_scratch) {
   // unbiased var / (mean^2 + 1e-10); zero for a single expert
@@ -293,6 +341,7 @@ __device__ __forceinline__ void cv2_and_grad(const float *v, int E, float &cv, f
 }
 
 __global__ __launch_bounds__(1024) void balance_kernel(const BalanceDev p) {
+  if (blockIdx.x == 1) { route_scan_blocks(p); return; }
   // thread (r, e): e = tid % E, r = tid / E sums rows r, r + RL, ... (4 independent loads in flight),
   // then the RL row-lanes are added in lane order by thread (0, e)
   __shared__ float s_imp[1024], s_prob[1024];
@@ -372,6 +421,7 @@ struct GateBwdDev {
   int64_t T; int E; int k;
   float *d_logits;
   const float *balance_scale_dev;
+  void *d_logits_act; int act_dtype;     // optional second copy in the activation dtype (the operand of the d w_gate GEMM)
 };
 
 template <int EPAD>
@@ -448,8 +498,17 @@ __global__ __launch_bounds__(256) void gate_bwd_logits_kernel(const GateBwdDev p
 #pragma unroll
   for (int e = 0; e < EPAD; ++e) dot += dp[e] * pr[e];
 #pragma unroll
-  for (int e = 0; e < EPAD; ++e)
-    if (e < E) p.d_logits[t * E + e] = pr[e] * (dp[e] - dot) + g[e];
+  for (int e = 0; e < EPAD; ++e) {
+    if (e < E) {
+      const float v = pr[e] * (dp[e] - dot) + g[e];
+      p.d_logits[t * E + e] = v;
+      if (p.d_logits_act) {
+        if (p.act_dtype == M3_F16) ((half_t *)p.d_logits_act)[t * E + e] = (half_t)v;
+        else if (p.act_dtype == M3_BF16) ((bf16_t *)p.d_logits_act)[t * E + e] = (bf16_t)v;
+        else ((float *)p.d_logits_act)[t * E + e] = v;
+      }
+    }
+  }
 }
 
 // dW partials: lanes own d, tokens are walked; d_logits rows are wave-uniform scalars.
@@ -638,6 +697,7 @@ extern "C" int m3_gate_fwd(const m3_gate_fwd_args *a, void *stream) {
   d.idx = a->idx; d.idx32 = a->idx32; d.idx_next = a->idx_next; d.score = a->score; d.top_logits = a->top_logits;
   d.clean = a->clean; d.noisy = a->noisy; d.gates = a->gates;
   d.part_imp = a->part_importance; d.part_load = a->part_load; d.part_load_prob = a->part_load_prob;
+  d.part_count = a->part_count;
   const dim3 grid((unsigned)m3_gate_num_blocks(a->T));
   hipStream_t s = (hipStream_t)stream;
   if (a->x_dtype == M3_F16) return launch_gate_fwd<half_t>(epad_of(a->E), grid, s, d);
@@ -664,8 +724,28 @@ extern "C" int m3_balance_loss(const float *part_importance, const int32_t *part
   d.part_imp = part_importance; d.part_load = part_load; d.part_load_prob = part_load_prob;
   d.nblk = nblk; d.E = E; d.importance = importance; d.load = load; d.load_prob = load_prob;
   d.loss_acc = loss_acc; d.loss_out = loss_out; d.d_importance = d_importance; d.d_load_prob = d_load_prob;
+  d.part_count = nullptr; d.blk_base = nullptr; d.counts = nullptr; d.offsets = nullptr; d.tile_starts = nullptr; d.counts64 = nullptr;
   hipLaunchKernelGGL(balance_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d);
   return check_launch("m3_balance_loss");
+}
+
+extern "C" int m3_balance_route(const float *part_importance, const int32_t *part_load, const float *part_load_prob,
+                                int nblk, int E, float *importance, int64_t *load, float *load_prob, float *loss_out,
+                                float *loss_acc, float *d_importance, float *d_load_prob, const int32_t *part_count,
+                                int32_t *blk_base, int32_t *counts, int32_t *offsets, int32_t *tile_starts,
+                                int64_t *counts64, void *stream) {
+  M3_REQUIRE(part_importance && part_load && importance && load && E >= 1 && E <= 64 && nblk >= 1,
+             "m3_balance_route: bad args");
+  M3_REQUIRE(!part_load_prob || load_prob, "m3_balance_route: load_prob output needed with part_load_prob");
+  M3_REQUIRE(part_count && blk_base && counts && offsets && tile_starts, "m3_balance_route: null routing operand");
+  BalanceDev d;
+  d.part_imp = part_importance; d.part_load = part_load; d.part_load_prob = part_load_prob;
+  d.nblk = nblk; d.E = E; d.importance = importance; d.load = load; d.load_prob = load_prob;
+  d.loss_acc = loss_acc; d.loss_out = loss_out; d.d_importance = d_importance; d.d_load_prob = d_load_prob;
+  d.part_count = part_count; d.blk_base = blk_base; d.counts = counts; d.offsets = offsets; d.tile_starts = tile_starts;
+  d.counts64 = counts64;
+  hipLaunchKernelGGL(balance_kernel, dim3(2), dim3(1024), 0, (hipStream_t)stream, d);      // workgroup 0: balance loss, 1: routing scan
+  return check_launch("m3_balance_route");
 }
 
 extern "C" int m3_gate_bwd_logits(const m3_gate_bwd_args *a, void *stream) {
@@ -682,6 +762,8 @@ extern "C" int m3_gate_bwd_logits(const m3_gate_bwd_args *a, void *stream) {
   d.balance_scale = a->balance_scale; d.noise_std = a->noise_std; d.T = a->T; d.E = a->E; d.k = a->k;
   d.d_logits = a->d_logits;
   d.balance_scale_dev = a->balance_scale_dev;
+  d.d_logits_act = a->d_logits_act; d.act_dtype = a->act_dtype;
+  M3_REQUIRE(!a->d_logits_act || dtype_ok(a->act_dtype), "m3_gate_bwd_logits: bad dtype of the second copy");
   const dim3 grid((unsigned)((a->T + 255) / 256));
   hipStream_t s = (hipStream_t)stream;
   switch (epad_of(a->E)) {

@@ -80,14 +80,17 @@ __global__ __launch_bounds__(RT_SCAN_THREADS) void route_scan_kernel(const int32
   }
 }
 
+// base_stride: prefix blocks per workgroup - 1 for m3_route_build's own histogram blocks (RT_BLOCK entries each), the
+// number of 64-token gate blocks in RT_BLOCK entries for m3_route_assign (prefix of the first of them: the workgroup
+// walks its entries in order, so the running counts pass through the others' prefixes by themselves)
 __global__ __launch_bounds__(RT_THREADS) void route_assign_kernel(const int32_t *idx, int64_t n, int E,
                                                                   const int32_t *blk_base, const int32_t *offsets,
-                                                                  int32_t *pos, int32_t *row_of_slot) {
+                                                                  int32_t *pos, int32_t *row_of_slot, int base_stride) {
   __shared__ int32_t run[RT_MAX_E];          // entries of expert e seen in earlier passes of this block
   __shared__ int32_t wcnt[4][RT_MAX_E];      // per-wave counts of the current pass
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int e = threadIdx.x; e < E; e += RT_THREADS)
-    run[e] = offsets[e] + blk_base[(int64_t)blockIdx.x * E + e];
+    run[e] = offsets[e] + blk_base[(int64_t)blockIdx.x * base_stride * E + e];
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * RT_BLOCK;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -279,8 +282,20 @@ extern "C" int m3_route_build(const int32_t *idx32, int64_t n, int E, int32_t *c
   rc = check_launch("m3_route_build(scan)");
   if (rc) return rc;
   hipLaunchKernelGGL(route_assign_kernel, dim3(nblk), dim3(RT_THREADS), 0, s, idx32, n, E, blk_base, offsets, pos,
-                     row_of_slot);
+                     row_of_slot, 1);
   return check_launch("m3_route_build(assign)");
+}
+
+extern "C" int m3_route_assign(const int32_t *idx32, int64_t n, int E, int k, const int32_t *blk_base, const int32_t *offsets,
+                               int32_t *pos, int32_t *row_of_slot, void *stream) {
+  M3_REQUIRE(idx32 && blk_base && offsets && pos && row_of_slot, "m3_route_assign: null operand");
+  M3_REQUIRE(E >= 1 && E <= RT_MAX_E && n >= 0 && n < ((int64_t)1 << 31), "m3_route_assign: E / n out of range");
+  M3_REQUIRE(k >= 1 && k <= 16 && 16 % k == 0 && n % k == 0, "m3_route_assign: k = %d must divide 16 (64-token prefix blocks)", k);
+  if (n == 0) return M3_OK;
+  const int nblk = (int)route_blocks(n);
+  hipLaunchKernelGGL(route_assign_kernel, dim3(nblk), dim3(RT_THREADS), 0, (hipStream_t)stream, idx32, n, E, blk_base, offsets,
+                     pos, row_of_slot, RT_BLOCK / (64 * k));
+  return check_launch("m3_route_assign");
 }
 
 extern "C" int m3_ep_plan(const int64_t *send_counts, const int64_t *recv_counts, int W, int E_loc, int64_t *splits,

@@ -25,8 +25,12 @@ from typing import Dict, Optional
 
 import torch
 
+import os
+
 from . import ops
 from .ops import M3_ACT_GELU
+
+_ROUTE_FOLD = os.environ.get("M3_ROUTE_FOLD", "1") != "0"       # A/B knob: 0 = the three-launch m3_route_build behind the gate
 
 
 class _Cfg:
@@ -412,14 +416,15 @@ class BackboneEngine:
             wg_tok = wg if wg.shape[0] == D else wg[:D]
             noise = None if noises is None else noises.get(i)
             std = (self.cfg.vmoe_noisy_std / self.E) if noise is not None else 0.0
-            # gate + balance loss (importance, load, cv^2 and its gradient) - two launches
+            # gate + balance loss (importance, load, cv^2 and its gradient) + dispatch metadata: three launches (the routing
+            # histogram comes out of the gate kernel, its scan rides in the balance launch)
             g = ops.gate_fwd(a["h2"], wg_tok, self.k, logit_bias=None if tsf_bias is None else tsf_bias[i],
-                             noise=noise, noise_std=std, dense=True, loss_acc=loss_acc)
+                             noise=noise, noise_std=std, dense=True, loss_acc=loss_acc, route=self.ep_world == 1 and _ROUTE_FOLD)
             a["gate"] = g
             if self.ep_world > 1:
                 self._experts_fwd_ep(i, a, g, recompute=loss_acc is None)
             else:
-                r = ops.route_build(g["idx32"], self.E)
+                r = g["route"] if g["route"] is not None else ops.route_build(g["idx32"], self.E)
                 a["route"] = r
                 ops.gemm_nt(a["h2"], self.wc[b + "mlp.experts.htoh4"], a["hid"], M=self.R,
                             bias=p[b + "mlp.experts.htoh4.bias"], act=M3_ACT_GELU, pre_out=a["hid_pre"],
@@ -774,7 +779,8 @@ class BackboneEngine:
                                          balance_scale=1.0 if cvw_dev is not None else cv_weight, balance_scale_dev=cvw_dev,
                                          idx_next=g["idx_next"],
                                          d_load_prob=g["d_load_prob"] if bal else None, clean=g["clean"],
-                                         top_logits=g["top_logits"], noise_std=g["noise_std"], out=self.s_dl)
+                                         top_logits=g["top_logits"], noise_std=g["noise_std"], out=self.s_dl,
+                                         out_act=self.s_dl_t if (self.gate_via_gemm and self.dt != torch.float32) else None)
                 # token rows of w_gate ([:D]; the task-conditioned rows [D:]: _task_feature_block_bwd below)
                 wg, dwg = p[a["wname"]][:D], gr[a["wname"]][:D]
                 dh2_moe = self.s_dh32
@@ -783,7 +789,7 @@ class BackboneEngine:
                     # measured in round 3: 24 us + 6 us partial reduce against 17.5 us for the padded TN GEMM whose reduce rides
                     # along: the GEMM stays)
                     # d w_gate += h2^T dl (TN GEMM) ; dh2 = sum_j dxe[t,j] + dl w_gate^T
-                    dl_t = dl if self.dt == torch.float32 else ops.cast_f32(dl, self.s_dl_t)
+                    dl_t = dl if self.dt == torch.float32 else self.s_dl_t      # (written by the gate's backward kernel itself)
                     self._fork(("dl",), lambda: ops.wgrad_tn(a["h2"], dl_t, dwg, beta=1, ws=self.ws_wgrad, queue=self.wq))
                     if self.fused_gate_dx:
                         # one pass over the [T, D] result, stored in the activation dtype like a dense block's d h2 (the sum

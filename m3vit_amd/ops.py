@@ -45,14 +45,17 @@ def _req(t: torch.Tensor, dtype=None, name="tensor"):
 
 # ----------------------------------------------------------------------------- gate
 def gate_fwd(x, w_gate, k, logit_bias=None, noise=None, noise_std=0.0, dense=True, want_idx32=True,
-             loss_acc=None):
+             loss_acc=None, route=False, want_counts64=False):
     """x [T,D] f32/f16, w_gate [D,E] f32 (rows beyond D are ignored: pass w_gate[:D] + bias for
     task conditioning).  Returns dict with idx i64 [T,k], idx32, idx_next i32 [T], score, top_logits,
     clean, noisy, gates (dense only), importance f32 [E], load i64 [E], and the block's balance loss
     cv_loss = cv^2(importance) + cv^2(load) (0-dim) with its gradients d_importance / d_load_prob [E].
     For noisy training (noise given, noise_std != 0, k < E; needs dense) load is the Normal-CDF form
     load_prob f32 [E] (vision_transformer_moe.py:456-457), otherwise the count and d_load_prob is None.
-    loss_acc: optional 1-element f32 tensor the loss is also added to."""
+    loss_acc: optional 1-element f32 tensor the loss is also added to.
+    route: also build the dispatch metadata (result["route"]: a Route as route_build(idx32, E) returns it) from the gate
+    kernel's own per-block counts - the histogram pass is not launched and the scan rides in the balance launch
+    (m3_balance_route); needs k | 16."""
     _req(x, name="x"); _req(w_gate, torch.float32, "w_gate")
     T, D = x.shape
     E = w_gate.shape[1]
@@ -82,29 +85,49 @@ def gate_fwd(x, w_gate, k, logit_bias=None, noise=None, noise_std=0.0, dense=Tru
         _req(logit_bias, f32, "logit_bias")
     if noise is not None:
         _req(noise, f32, "noise")
+    route = bool(route) and T > 0 and 16 % k == 0 and want_idx32
+    pc = torch.empty((2, max(nblk, 1), E), dtype=torch.int32, device=dev) if route else None     # counts, then their prefix
     a = _lib.GateFwdArgs(_p(x), dt_code(x.dtype), T, D, x.stride(0), _p(w_gate), E, _p(logit_bias), _p(noise),
                          float(noise_std), k, _p(idx), _p(idx32), _p(idx_next), _p(score), _p(top), _p(clean), _p(noisy),
-                         _p(gates), _p(pi), _p(pl), _p(pp))
+                         _p(gates), _p(pi), _p(pl), _p(pp), _p(pc))
     check(lib().m3_gate_fwd(byref(a), _stream()), "m3_gate_fwd")
-    check(lib().m3_balance_loss(_p(pi), _p(pl), _p(pp), nblk, E, _p(imp), _p(load),
-                                _p(load_prob), _p(loss), _p(loss_acc), _p(d_imp), _p(d_lp), _stream()),
-          "m3_balance_loss")
-    return dict(idx=idx, idx32=idx32, idx_next=idx_next, score=score, top_logits=top, clean=clean, noisy=noisy,
+    r = None
+    if route:
+        n = T * k
+        r = Route()
+        r.n, r.E, r.k = n, E, k
+        meta = torch.empty(3 * E + 2, dtype=torch.int32, device=dev)
+        r.counts, r.offsets, r.tile_starts = meta[:E], meta[E:2 * E + 1], meta[2 * E + 1:]
+        r.pos = torch.empty(n, dtype=torch.int32, device=dev)
+        r.row_of_slot = torch.empty(n, dtype=torch.int32, device=dev)
+        r.counts64 = torch.empty(E, dtype=torch.int64, device=dev) if want_counts64 else None
+        check(lib().m3_balance_route(_p(pi), _p(pl), _p(pp), nblk, E, _p(imp), _p(load), _p(load_prob), _p(loss),
+                                     _p(loss_acc), _p(d_imp), _p(d_lp), _p(pc[0]), _p(pc[1]), _p(r.counts), _p(r.offsets),
+                                     _p(r.tile_starts), _p(r.counts64), _stream()), "m3_balance_route")
+        check(lib().m3_route_assign(_p(idx32), n, E, k, _p(pc[1]), _p(r.offsets), _p(r.pos), _p(r.row_of_slot), _stream()),
+              "m3_route_assign")
+    else:
+        check(lib().m3_balance_loss(_p(pi), _p(pl), _p(pp), nblk, E, _p(imp), _p(load),
+                                    _p(load_prob), _p(loss), _p(loss_acc), _p(d_imp), _p(d_lp), _stream()),
+              "m3_balance_loss")
+    return dict(route=r, idx=idx, idx32=idx32, idx_next=idx_next, score=score, top_logits=top, clean=clean, noisy=noisy,
                 gates=gates, importance=imp, load=load, load_prob=load_prob, cv_loss=loss, d_importance=d_imp,
                 d_load_prob=d_lp, noise_std=float(noise_std) if prob else 0.0)
 
 
 def gate_bwd_logits(noisy, idx, d_score, d_importance, k, *, balance_scale=1.0, d_top=None, idx_next=None,
-                    d_load_prob=None, clean=None, top_logits=None, noise_std=0.0, out=None, balance_scale_dev=None):
+                    d_load_prob=None, clean=None, top_logits=None, noise_std=0.0, out=None, balance_scale_dev=None,
+                    out_act=None):
     """d_logits [T,E] from d_score [T,k], d_top [T,k+1], balance_scale * (d_importance, d_load_prob) [E].
-    balance_scale_dev: optional 1-element f32 device tensor multiplied onto balance_scale inside the kernel."""
+    balance_scale_dev: optional 1-element f32 device tensor multiplied onto balance_scale inside the kernel.
+    out_act: optional [T,E] tensor (activation dtype) that receives a second copy of the result."""
     T, E = noisy.shape
     dl = torch.empty_like(noisy) if out is None else out
     if balance_scale_dev is not None:
         _req(balance_scale_dev, torch.float32, "balance_scale_dev")
     a = _lib.GateBwdArgs(_p(noisy), _p(clean), _p(top_logits), _p(idx), _p(idx_next), _p(d_score), _p(d_top),
                          _p(d_importance), _p(d_load_prob), float(balance_scale), float(noise_std), T, E, k, _p(dl),
-                         _p(balance_scale_dev))
+                         _p(balance_scale_dev), _p(out_act), dt_code(out_act.dtype) if out_act is not None else M3_F32)
     check(lib().m3_gate_bwd_logits(byref(a), _stream()), "m3_gate_bwd_logits")
     return dl
 

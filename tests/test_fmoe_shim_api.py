@@ -147,3 +147,43 @@ def test_origin_convention_signatures():
     ck = VisionTransformerMoE(img_size=(32, 32), embed_dim=64, depth=2, num_heads=2, moe_mlp_ratio=1, moe_experts=4,
                               moe_top_k=2, gate_dim=66, multi_gate=True)
     assert set(ck.state_dict().keys()) == {k for k in vit.state_dict().keys() if not k.startswith(("blocks.2", "blocks.3"))}
+
+
+def test_fused_backbone_eligibility_rules():
+    """which calls VisionTransformerMoE hands to the fused executor (m3vit_amd/fused.py) and which go through the per-op
+    autograd Functions - decided without touching the GPU"""
+    import torch
+    from m3vit_amd.fused import FusedBackbone
+    from m3vit_amd.vit import VisionTransformerMoE
+    kw = dict(img_size=(32, 32), embed_dim=64, depth=2, num_heads=2, moe_mlp_ratio=1, moe_experts=4, moe_top_k=2, gate_dim=66,
+              multi_gate=True)
+    m = VisionTransformerMoE(**kw)
+    assert m.fused == "auto" and m._fused_static_ok
+    x = torch.zeros(2, 3, 32, 32)
+    assert FusedBackbone.unsupported(m, x, None, 0, None) == "CPU tensor"
+    for bad_kw, why in ((dict(qkv_bias=False), "qkv_bias"), (dict(world_size=2), "expert parallel"),
+                        (dict(expert_prune=True), "routing edits"), (dict(gate_input_ahead=True), "routing edits"),
+                        (dict(num_heads=4), "head dim")):
+        mm = VisionTransformerMoE(**{**kw, **bad_kw})
+        assert not mm._fused_static_ok and why in mm._fused_static_why, (bad_kw, mm._fused_static_why)
+
+    class FakeCuda(torch.Tensor):                     # (is_cuda is all `unsupported` looks at before the shape)
+        is_cuda = True
+    xc = torch.zeros(2, 3, 32, 32).as_subclass(FakeCuda)
+    assert FusedBackbone.unsupported(m, xc, None, 0, None) is None
+    assert FusedBackbone.unsupported(m, xc, xc, 0, None) == "caller-supplied gate input"
+    assert FusedBackbone.unsupported(m, xc, None, None, None) == "multi-gate model called without a task id"
+    assert "image size" in FusedBackbone.unsupported(m, torch.zeros(2, 3, 64, 32).as_subclass(FakeCuda), None, 0, None)
+    m.eval()
+    assert FusedBackbone.unsupported(m, xc, None, 0, None) == "eval mode with autograd on"
+    with torch.no_grad():
+        assert FusedBackbone.unsupported(m, xc, None, 0, None) is None
+    m.train()
+    m.blocks[1].mlp.gate_hook = lambda *a: None
+    assert "gate hook" in FusedBackbone.unsupported(m, xc, None, 0, None)
+    import os
+    os.environ["M3VIT_FUSED"] = "0"
+    try:
+        assert VisionTransformerMoE(**kw).fused is False
+    finally:
+        del os.environ["M3VIT_FUSED"]

@@ -290,3 +290,67 @@ def test_fused_module_prefetches_the_other_task_passes_and_survives_a_wrong_gues
     ta, ga = step(a, imgs[0], imgs[0])                     # and on it goes
     tb, gb = step(b, imgs[0], imgs[0])
     assert torch.equal(ta, tb) and all(torch.equal(ga[n], gb[n]) for n in ga)
+
+
+def _dgdp_worker(rank, world, port, q):
+    """the reference's data-parallel wrapper around the fused module path (train_fastmoe.py:460 DistributedGroupedDataParallel,
+    train/train_utils.py:414 model.allreduce_params()): every rank its own images, the averaged gradients of the dense
+    parameters equal the mean of the per-rank gradients, the expert gradients (dp_comm "none") stay local; twice, so that the
+    second step runs on gradients that alias the wrapper's flat buffer."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import m3vit_amd
+        m3vit_amd.install_fmoe_shim()
+        from fmoe import DistributedGroupedDataParallel                     # the reference's import, bound to this repository
+        torch.cuda.set_device(0)
+        m, cfg = _model()
+        ref, _ = _model(fused=False)
+        w = DistributedGroupedDataParallel(m, device_ids=[0], find_unused_parameters=True)
+        g = torch.Generator().manual_seed(300 + rank)
+        for step in range(3):
+            img = torch.randn(3, 3, 32, 48, generator=g).cuda()
+            dtok = (torch.randn(3, cfg.num_tokens, 64, generator=g) * 0.1).cuda()
+            for model in (w, ref):
+                for p in model.parameters():
+                    p.grad = None                                            # optimizer.zero_grad(set_to_none=True)
+                loss = 0.0
+                for task in (0, 1):
+                    tok, cv = model(img, task_id=task)
+                    loss = loss + (tok * dtok).sum() + 0.01 * cv
+                loss.backward()
+            assert m.fused_fallback_reason is None and m._fused is not None
+            w.allreduce_params()
+            torch.cuda.synchronize()
+            for (n, p), (_, r) in zip(m.named_parameters(), ref.named_parameters()):
+                want = r.grad.detach().clone()
+                if getattr(p, "dp_comm", "dp") != "none":
+                    dist.all_reduce(want)
+                    want /= world
+                else:
+                    assert ".experts." in n
+                assert rel(p.grad, want) < 2e-4, (step, n, rel(p.grad, want))
+        q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fused_module_under_the_grouped_data_parallel_wrapper_two_ranks_one_gpu():
+    _need_gpu()
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dgdp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert all(r[1] == "ok" for r in res), res

@@ -331,6 +331,36 @@ def test_gate_full_size_bit_exact_and_route(ops, dtype):
     ts = np.concatenate([[0], np.cumsum((cc + 127) // 128)])
     assert np.array_equal(r.tile_starts.cpu().numpy(), ts)
     assert out["load"].cpu().numpy().sum() == T * k
+    # the same metadata with the histogram taken inside the gate kernel and the scan riding in the balance launch
+    out2 = ops.gate_fwd(x, w, k, dense=False, route=True, want_counts64=True)
+    r2 = out2["route"]
+    assert r2 is not None and torch.equal(out2["idx"], out["idx"]) and torch.equal(out2["cv_loss"], out["cv_loss"])
+    for name in ("counts", "counts64", "offsets", "pos", "row_of_slot", "tile_starts"):
+        assert torch.equal(getattr(r2, name), getattr(r, name)), name
+
+
+@pytest.mark.parametrize("T,E,k", [(1, 4, 2), (63, 8, 1), (64, 8, 8), (65, 16, 4), (777, 64, 4), (4097, 16, 2), (300, 5, 4),
+                                   (257, 16, 8)])
+def test_gate_route_folded_into_the_gate_and_balance_launches(ops, T, E, k):
+    """gate_fwd(route=True): ragged token counts, every k that divides 16, E up to 64, and a routing whose selected
+    probabilities underflow to exactly 0 (the LOAD no longer counts those entries, the routing must)."""
+    D = 64
+    x = rnd(T, D, seed=T)
+    w = (torch.rand(D, E, generator=torch.Generator().manual_seed(T + 1)) - 0.5).mul(0.1).to(dev())
+    for bias in (None, torch.linspace(0.0, 110.0 * (E - 1), E).to(dev())):              # softmax tail underflows with the second one
+        g1 = ops.gate_fwd(x, w, k, logit_bias=bias, dense=True)
+        r1 = ops.route_build(g1["idx32"], E, want_counts64=True)
+        g2 = ops.gate_fwd(x, w, k, logit_bias=bias, dense=True, route=True, want_counts64=True)
+        r2 = g2["route"]
+        assert r2 is not None
+        for name in ("idx", "score", "gates", "importance", "load", "cv_loss"):
+            assert torch.equal(g1[name], g2[name]), name
+        for name in ("counts", "counts64", "offsets", "pos", "row_of_slot", "tile_starts"):
+            assert torch.equal(getattr(r2, name), getattr(r1, name)), (name, bias is not None)
+        if bias is not None and k >= 4 and E >= 16:
+            assert int(g1["load"].sum()) < T * k, "the underflow case must actually occur"
+    if 16 % 3 != 0:                                                          # k = 3 does not divide 16: no folded route
+        assert ops.gate_fwd(x, w, 3 if E >= 3 else 1, route=True)["route"] is None or E < 3
 
 
 def test_route_edge_cases(ops):
@@ -373,6 +403,65 @@ def test_ep_plan_kernel_matches_the_host_plan(ops):
             assert np.array_equal(got.offsets.cpu().numpy(), off)
             ts = np.concatenate([[0], np.cumsum((np.asarray(want.fwd_expert_count) + 127) // 128)])
             assert np.array_equal(got.tile_starts.cpu().numpy(), ts)
+
+
+@pytest.mark.parametrize("world,e_loc,T,k,factor", [(2, 2, 50, 2, 1.5), (4, 4, 300, 4, 1.25), (8, 2, 197, 4, 1.25), (8, 8, 400, 4, 1.1),
+                                                    (3, 5, 64, 1, 2.0), (2, 4, 100, 2, 0.6)])
+def test_ep_plan_fixed_round_trip_of_a_simulated_exchange(ops, world, e_loc, T, k, factor):
+    """m3_ep_plan_fixed (fixed row capacity per (source, destination) pair) on W simulated ranks: every rank routes its own
+    tokens, the padded send buffers are exchanged with EQUAL splits (plain indexing stands for the all-to-all), and then
+      * every expert-major slot of a rank reads a row that was routed to exactly that local expert, each routed row once,
+        sources in rank order inside an expert (the order the exact plan, m3_ep_plan, produces);
+      * sending the received rows straight back and un-padding returns every token-major entry its own row;
+      * the overflow flag is raised exactly when some pair exceeds the capacity (factor 0.6), and the pairs that fit are
+        still exchanged completely."""
+    E = world * e_loc
+    R = T * k
+    cap = -(-int(factor * R + world - 1) // world)
+    cap = (cap + 7) // 8 * 8
+    g = torch.Generator().manual_seed(world * 100 + T)
+    routes, plans, flags, sends = [], [], [], []
+    idxs = [torch.stack([torch.randperm(E, generator=g)[:k] for _ in range(T)]).to(torch.int32).to(dev()) for _ in range(world)]
+    routes = [ops.route_build(ix, E, want_counts64=True) for ix in idxs]
+    cnt = torch.stack([r.counts64 for r in routes]).cpu()                    # [src, global expert]
+    over_pairs = set()
+    for me in range(world):
+        recv = cnt[:, me * e_loc:(me + 1) * e_loc].reshape(-1).contiguous().to(dev())       # [s * e_loc + e]
+        flag = torch.zeros(1, dtype=torch.int32, device=dev())
+        plans.append(ops.ep_plan_fixed(routes[me].counts64, recv, world, e_loc, cap, routes[me], flag))
+        flags.append(int(flag.item()))
+        # entry id (rank, token-major entry) as the payload: what x_send would carry
+        pad = plans[me].pad_idx.cpu().long()
+        sends.append(torch.stack((torch.full_like(pad, me), pad), 1))       # [W * cap, 2]
+    pair = cnt.view(world, world, e_loc).sum(2)                              # rows src -> dst
+    for me in range(world):
+        want_flag = int((pair[me] > cap).any() or (pair[:, me] > cap).any())
+        assert flags[me] == want_flag, (me, flags[me], want_flag)
+    for me in range(world):
+        recv_buf = torch.cat([sends[s][me * cap:(me + 1) * cap] for s in range(world)])      # equal-split all-to-all
+        pl = plans[me]
+        off = pl.offsets.cpu().tolist()
+        rg = pl.regroup.cpu().long()
+        ts = pl.tile_starts.cpu().tolist()
+        assert ts == [0] + list(np.cumsum([(off[e + 1] - off[e] + 127) // 128 for e in range(e_loc)]))
+        for e in range(e_loc):
+            rows = recv_buf[rg[off[e]:off[e + 1]]]                           # (src rank, entry) of the slots of local expert e
+            ge = me * e_loc + e
+            last = (-1, -1)
+            for s_, ent in rows.tolist():
+                assert int(idxs[s_].view(-1)[ent]) == ge, "a row landed at the wrong expert"
+                assert (s_, ent) > last, "sources in rank order, entries in routing order inside a source"
+                last = (s_, ent)
+            want_n = sum(min(int(cnt[s_, ge]), max(0, cap - int(cnt[s_, me * e_loc:ge].sum()))) for s_ in range(world))
+            assert len(rows) == want_n, (me, e, len(rows), want_n)
+        # the way back: what this rank received goes home unchanged, the sources un-pad it
+    for src in range(world):
+        back = torch.cat([torch.cat([sends[src][d * cap:(d + 1) * cap]]) for d in range(world)])   # identity experts
+        un = plans[src].unpad_idx.cpu().long()
+        got = back[un]                                                        # [R, 2]
+        fits = torch.tensor([bool(pair[src, int(idxs[src].view(-1)[i]) // e_loc] <= cap) for i in range(R)])
+        assert torch.equal(got[fits, 0], torch.full((int(fits.sum()),), src))
+        assert torch.equal(got[fits, 1], torch.arange(R)[fits]), "an entry did not get its own row back"
 
 
 def test_route_out_of_range_ids_are_reported_and_stay_in_range(ops):
