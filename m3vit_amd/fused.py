@@ -82,6 +82,7 @@ class FusedBackbone:
         self.max_slots = max_slots
         self.slots = []
         self.batch = None
+        self.device = None
         self.sig = None
         self.dirty = True
         self.anchor = None
@@ -176,7 +177,7 @@ class FusedBackbone:
         model = self.model()
         B = images.shape[0]
         dev = images.device
-        if self.batch != B or not self.slots or not self._check_params():
+        if self.batch != B or not self.slots or dev != self.device or not self._check_params():
             if any(s.busy for s in self.slots):
                 raise RuntimeError("fused backbone: batch size / parameter storage changed while a forward waits for its backward")
             self._build(B, dev)
@@ -226,8 +227,12 @@ class FusedBackbone:
         slot.busy, slot.main = True, main
         s = slot.stream
         s.wait_stream(main)
-        with torch.cuda.stream(s):
-            slot.result = _BackboneFn.apply(self.anchor, self, slot, task_id, images)
+        try:
+            with torch.cuda.stream(s):
+                slot.result = _BackboneFn.apply(self.anchor, self, slot, task_id, images)
+        except BaseException:
+            slot.busy = False                         # a failed launch must not keep the context
+            raise
         return slot
 
     # ---- task passes started ahead of their call
