@@ -88,15 +88,18 @@ class MultiTaskStep:
         # in profiles/r02_wgrad_capture_segv.txt): the runtime's fault, not the engine's event use.  That combination is
         # refused here and runs eagerly.
         self.capture_refused = None
+        import os
         if self.use_ep:
-            import os
             import torch.distributed as dist
             # the fixed-capacity exchange reads nothing on the host inside the step, so a collective library whose calls
             # can be captured (RCCL) could replay it; never tried on hardware (the build box has one GPU), hence opt-in
             if not (self.ep_capacity and os.environ.get("M3_EP_CAPTURE") == "1" and dist.get_backend() == "nccl"):
                 self.capture_refused = ("expert-parallel steps read the exchange's split sizes on the host" if not self.ep_capacity
                                         else "fixed-capacity expert-parallel step: capture is opt-in (M3_EP_CAPTURE=1, backend nccl)")
-        elif wg and self.par:
+        elif wg and self.par and (self.share_stem or os.environ.get("M3_LINEAR_GRAPHS", "1") == "0" or
+                                  os.environ.get("M3_WGRAD_STREAMS_CAPTURE", "0") != "1"):
+            # (with one linear graph per task pass - _capture_linear - a pass's wgrad stream is forked from that pass's OWN
+            # capturing stream, which is the pattern that works; opt-in M3_WGRAD_STREAMS_CAPTURE=1 until measured)
             self.capture_refused = ("wgrad streams forked from forked task streams: hipStreamEndCapture (ROCm 7.2) segfaults on "
                                     "a nested fork (engine-free reproducer: tools/nested_capture_probe.py); use serial tasks or "
                                     "no wgrad streams to replay a graph")
