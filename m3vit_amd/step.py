@@ -96,7 +96,7 @@ class MultiTaskStep:
             if not (self.ep_capacity and os.environ.get("M3_EP_CAPTURE") == "1" and dist.get_backend() == "nccl"):
                 self.capture_refused = ("expert-parallel steps read the exchange's split sizes on the host" if not self.ep_capacity
                                         else "fixed-capacity expert-parallel step: capture is opt-in (M3_EP_CAPTURE=1, backend nccl)")
-        elif wg and self.par and (self.share_stem or os.environ.get("M3_LINEAR_GRAPHS", "1") == "0" or
+        elif wg and self.par and (self.share_stem or not (os.environ.get("M3_LINEAR_GRAPHS", "auto") == "1" or (os.environ.get("M3_LINEAR_GRAPHS", "auto") == "auto" and self.world == 1)) or
                                   os.environ.get("M3_WGRAD_STREAMS_CAPTURE", "0") != "1"):
             # (with one linear graph per task pass - _capture_linear - a pass's wgrad stream is forked from that pass's OWN
             # capturing stream, which is the pattern that works; opt-in M3_WGRAD_STREAMS_CAPTURE=1 until measured)
@@ -107,7 +107,12 @@ class MultiTaskStep:
         # side-by-side passes are captured as one linear graph per pass and stream (_capture_linear); the shared stem, whose
         # passes meet in the middle of a part, keeps the one-graph-per-part form with the fork inside the capture
         import os as _os
-        self.linear_graphs = self.par and not self.share_stem and _os.environ.get("M3_LINEAR_GRAPHS", "1") != "0"
+        # (N > 1 keeps one graph per part unless M3_LINEAR_GRAPHS=1: the only multi-rank runs this build box allows - two
+        # PROCESSES on one GPU over gloo - stall for seconds per step with the per-pass graphs (71 -> 1 861 ms/step; the device
+        # stops executing both processes' queued work, profiles/r04_dp_shared_stem_stall.txt has the mechanism), so the form
+        # that has been rehearsed stays the default there until a one-rank-per-GPU run says otherwise)
+        lin = _os.environ.get("M3_LINEAR_GRAPHS", "auto")
+        self.linear_graphs = self.par and not self.share_stem and (lin == "1" or (lin == "auto" and self.world == 1))
         self.graphs = None
         self.capture_error = None
         self.images = self.dtok = self.noises = self.logit_bias = None
