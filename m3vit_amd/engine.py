@@ -43,7 +43,8 @@ class _Cfg:
 class BackboneEngine:
     def __init__(self, cfg, params: Dict[str, torch.Tensor], batch: int, dtype=torch.float16,
                  device="cuda:0", ep_group=None, ep_world: int = 1, ep_rank: int = 0, share: "BackboneEngine" = None,
-                 wgrad_stream: bool = False, checkpoint: bool = False, ep_capacity: float = 0.0):
+                 wgrad_stream: bool = False, checkpoint: bool = False, ep_capacity: float = 0.0,
+                 experts_are_local: bool = False):
         """params: GLOBAL parameters (all E experts).  With ep_world > 1 this rank keeps experts
         [ep_rank*E/W, (ep_rank+1)*E/W) (utils/common_config.py:179-185) and exchanges routed rows with
         the other ranks over torch.distributed (RCCL) - see _experts_fwd_ep.
@@ -65,7 +66,10 @@ class BackboneEngine:
         (m3_ep_plan_fixed), NOTHING of the exchange is read by the host - one host read per STEP (ep_overflowed()) instead
         of one per MoE layer and pass, and a step that a collective library can capture.  A pair that routes more rows than
         the capacity raises the flag; the step's results are then incomplete and the caller repeats it on the exact path
-        (MultiTaskStep does)."""
+        (MultiTaskStep does).
+        experts_are_local (with ep_world > 1): the expert tensors in `params` are already this rank's slice [E / W, ..] (a
+        module built the way utils/common_config.py:179-185 builds it: moe_experts // world_size experts per rank) and are
+        taken as they are - in place - instead of being cut out of global tensors."""
         assert not (checkpoint and wgrad_stream), "checkpoint mode re-uses the activation buffers a wgrad stream may still read"
         self.checkpoint = bool(checkpoint)
         assert dtype in (torch.float16, torch.bfloat16, torch.float32), "activation dtype: float16, bfloat16 or float32"
@@ -106,8 +110,12 @@ class BackboneEngine:
                 # backward_blocks(.., b) the prefix flat_grads[:grad_prefix(b)] is final and can be all-reduced
                 # while the blocks below still run
                 names = sorted(params, key=lambda n: -self._block_of(n))
-            self.params = {n: (params[n][lo:hi] if (is_exp(n) and self.ep_world > 1) else params[n])
+            cut = self.ep_world > 1 and not experts_are_local
+            self.params = {n: (params[n][lo:hi] if (is_exp(n) and cut) else params[n])
                            .to(self.dev, torch.float32).contiguous() for n in names}
+            for n, p in self.params.items():
+                if is_exp(n):
+                    assert p.shape[0] == self.E_loc, f"{n}: {p.shape[0]} experts on this rank, expected {self.E_loc}"
         self.n_dense = sum(p.numel() for n, p in self.params.items() if not is_exp(n))
         self.n_upper = self.grad_prefix(self.split_block)
         # one flat fp32 gradient buffer (views per parameter): zeroing is one memset and the data-parallel

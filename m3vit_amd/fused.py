@@ -100,6 +100,10 @@ class FusedBackbone:
         """None when this call can run on the executor, else the reason it takes the per-op path"""
         if not x.is_cuda:
             return "CPU tensor"
+        if model.world_size > 1:
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized()):
+                return "expert parallel layer without an initialised process group"
         if gate_inp is not None:
             return "caller-supplied gate input"
         if not model._fused_static_ok:
@@ -124,8 +128,18 @@ class FusedBackbone:
         named = dict(model.named_parameters())
         self.names = list(named)
         params = {n: p.detach() for n, p in named.items()}
+        # experts sharded over the ranks (world_size > 1, utils/common_config.py:179-185): the module holds this rank's
+        # moe_experts // world_size experts, the executor exchanges the routed rows (engine._experts_fwd_ep).  The exchange
+        # reads its split sizes on the host, so these passes run eagerly (no hipGraph)
+        self.ep = {}
+        if model.world_size > 1:
+            import torch.distributed as dist
+            group = next((blk.mlp.moe_group for blk in model.blocks if blk.moe), None)
+            self.ep = dict(ep_group=group, ep_world=model.world_size, ep_rank=dist.get_rank(group), experts_are_local=True)
+            assert dist.get_world_size(group) == model.world_size, "the layer's world_size must be the expert group's size"
+            self.graph = False
         eng0 = BackboneEngine(cfg, params, batch=B, dtype=model.act_dtype, device=str(device),
-                              checkpoint=bool(model.use_checkpointing))
+                              checkpoint=bool(model.use_checkpointing), **self.ep)
         for n, p in named.items():
             if eng0.params[n].data_ptr() != p.data_ptr():
                 raise RuntimeError(f"fused backbone: parameter {n} must be a contiguous fp32 CUDA tensor")
@@ -156,7 +170,7 @@ class FusedBackbone:
                                "call backward() (or drop the outputs) before running more")
         e0 = self.slots[0].eng
         eng = BackboneEngine(self.cfg, None, batch=self.batch, dtype=e0.dt, device=str(self.device), share=e0,
-                             checkpoint=e0.checkpoint)
+                             checkpoint=e0.checkpoint, **self.ep)
         s = _Slot(len(self.slots), eng, self.device)
         self.slots.append(s)
         return s

@@ -199,22 +199,25 @@ class VisionTransformerMoE(nn.Module):
         import os
         self.fused = False if os.environ.get("M3VIT_FUSED", "1") == "0" else fused
         self.use_checkpointing = bool(use_checkpointing)
+        self.world_size = int(world_size)
         self._fused = None
         self.fused_fallback_reason = None
         self._cfg_kwargs = dict(img_size=tuple(img_size) if isinstance(img_size, (tuple, list)) else (img_size, img_size),
                                 patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim, depth=depth, num_heads=num_heads,
                                 mlp_ratio=mlp_ratio, moe_mlp_ratio=moe_mlp_ratio if moe_mlp_ratio >= 0 else mlp_ratio,
-                                moe_experts=moe_experts, moe_top_k=moe_top_k, gate_dim=gate_dim if gate_dim >= 0 else embed_dim,
+                                moe_experts=moe_experts * world_size, moe_top_k=moe_top_k,     # the gate scores all E_loc * W experts
+                                gate_dim=gate_dim if gate_dim >= 0 else embed_dim,
                                 multi_gate=bool(multi_gate), gate_task_specific_dim=gate_task_specific_dim,
                                 vmoe_noisy_std=float(vmoe_noisy_std))
         why = None
         if not qkv_bias:
             why = "qkv_bias=False"
-        elif world_size != 1:
-            why = "expert parallel layer (world_size > 1)"
+        elif world_size > 1 and use_checkpointing:
+            why = "expert parallel layer with activation checkpointing"
         elif regu_experts_fromtask or expert_prune or gate_input_ahead:
             why = "regu_experts_fromtask / expert_prune / gate_input_ahead routing edits"
-        elif embed_dim // num_heads not in (32, 64) or moe_experts > 64 or moe_experts < 2 or moe_top_k > moe_experts:
+        elif embed_dim // num_heads not in (32, 64) or moe_experts * world_size > 64 or moe_experts * world_size < 2 or \
+                moe_top_k > moe_experts * world_size:
             why = "head dim not 32 / 64 or expert count outside [2, 64]"
         elif multi_gate and self._cfg_kwargs["gate_dim"] <= embed_dim:
             why = "multi_gate without tasks"

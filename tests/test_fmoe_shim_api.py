@@ -161,7 +161,9 @@ def test_fused_backbone_eligibility_rules():
     assert m.fused == "auto" and m._fused_static_ok
     x = torch.zeros(2, 3, 32, 32)
     assert FusedBackbone.unsupported(m, x, None, 0, None) == "CPU tensor"
-    for bad_kw, why in ((dict(qkv_bias=False), "qkv_bias"), (dict(world_size=2), "expert parallel"),
+    mm = VisionTransformerMoE(**{**kw, "world_size": 2})          # sharded experts: eligible once a process group exists
+    assert mm._fused_static_ok and mm._cfg_kwargs["moe_experts"] == 8
+    for bad_kw, why in ((dict(qkv_bias=False), "qkv_bias"), (dict(world_size=2, use_checkpointing=True), "expert parallel"),
                         (dict(expert_prune=True), "routing edits"), (dict(gate_input_ahead=True), "routing edits"),
                         (dict(num_heads=4), "head dim")):
         mm = VisionTransformerMoE(**{**kw, **bad_kw})

@@ -354,3 +354,75 @@ def test_fused_module_under_the_grouped_data_parallel_wrapper_two_ranks_one_gpu(
     for p in procs:
         p.join(timeout=30)
     assert all(r[1] == "ok" for r in res), res
+
+
+def _ep_module_worker(rank, world, port, q):
+    """the module path with SHARDED experts (world_size = 2: the module holds moe_experts // world_size experts per rank, the gate
+    scores all of them - utils/common_config.py:179-185, custom_moe_layer.py:263-265) on the fused executor's expert-parallel
+    path, against the same model with every expert local (world_size = 1) on this rank's images: tokens, balance loss, dense
+    gradients (own images), expert gradients (this rank's experts saw the rows of BOTH ranks), two steps."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from m3vit_amd.vit import VisionTransformerMoE
+        from oracle import ref_torch as R
+        torch.cuda.set_device(0)
+        E, e_loc = 8, 4
+        kw = dict(KW)
+        cfg = R.BackboneCfg(mlp_ratio=4.0, moe_mlp_ratio=1.0, vmoe_noisy_std=0.0, moe_experts=E, **kw)
+        P = R.init_backbone_params(cfg, seed=11)
+        full = VisionTransformerMoE(mlp_ratio=4.0, moe_mlp_ratio=1, vmoe_noisy_std=0.0, moe_experts=E, **kw).cuda()
+        full.load_state_dict(P)
+        ep = VisionTransformerMoE(mlp_ratio=4.0, moe_mlp_ratio=1, vmoe_noisy_std=0.0, moe_experts=e_loc, world_size=world, **kw).cuda()
+        lo = rank * e_loc
+        ep.load_state_dict({n: (v[lo:lo + e_loc] if ".mlp.experts." in n else v) for n, v in P.items()})
+        full.train(); ep.train()
+        g = torch.Generator().manual_seed(400 + rank)
+        for step in range(2):
+            img = torch.randn(3, 3, 32, 48, generator=g).cuda()
+            dtok = (torch.randn(3, cfg.num_tokens, 64, generator=g) * 0.1).cuda()
+            outs = {}
+            for m in (full, ep):
+                m.zero_grad(set_to_none=True)
+                loss = 0.0
+                for task in (0, 1):
+                    tok, cv = m(img, task_id=task)
+                    loss = loss + (tok * dtok).sum() + 0.01 * cv
+                loss.backward()
+                assert m.fused_fallback_reason is None, m.fused_fallback_reason
+                outs[m] = (tok.detach(), cv.detach())
+            torch.cuda.synchronize()
+            assert ep._fused.ep and ep._fused.slots[0].eng.ep_world == world and not ep._fused.slots[0].graphs_f
+            assert rel(outs[ep][0], outs[full][0]) < 1e-5 and abs(float(outs[ep][1]) - float(outs[full][1])) < 1e-5
+            fg = dict(full.named_parameters())
+            for n, p in ep.named_parameters():
+                want = fg[n].grad.detach().clone()
+                if ".mlp.experts." in n:
+                    dist.all_reduce(want)
+                    want = want[lo:lo + e_loc]
+                    assert getattr(p, "dp_comm", None) == "none"
+                assert rel(p.grad, want) < 2e-4, (step, n, rel(p.grad, want))
+        q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fused_module_with_sharded_experts_two_ranks_one_gpu():
+    _need_gpu()
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ep_module_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert all(r[1] == "ok" for r in res), res
