@@ -91,8 +91,9 @@ class FusedBackbone:
         import os
         self.prefetch = os.environ.get("M3VIT_PREFETCH", "1") != "0"
         self.hist, self.pattern, self.spec, self.spec_images, self.spec_version = [], None, {}, None, 0
-        self.backoff, self.prefetch_misses = 0, 0
+        self.backoff, self.prefetch_misses, self.prefetch_hits = 0, 0, 0
         self.backward_seen = False
+        self.versions_changed = False
 
     # ------------------------------------------------------------------ eligibility
     @staticmethod
@@ -183,7 +184,7 @@ class FusedBackbone:
             return False
         sig = [p._version for p in self.plist]
         if sig != self.sig:
-            self.sig, self.dirty = sig, True
+            self.sig, self.dirty, self.versions_changed = sig, True, True
         return True
 
     # ------------------------------------------------------------------ forward
@@ -198,9 +199,18 @@ class FusedBackbone:
             self._check_params()
         train = torch.is_grad_enabled()
         main = torch.cuda.current_stream()
-        if self.dirty:
+        refreshed = self.versions_changed
+        self.versions_changed = False
+        if self.dirty and (refreshed or not self.spec):
             # first forward after a backward (an optimizer step came in between) or after the values changed: refresh the
-            # activation-dtype operand copies W, W^T of every Linear - one launch, ~0.1 ms (engine.prepare_weights)
+            # activation-dtype operand copies W, W^T of every Linear - one launch, ~0.1 ms (engine.prepare_weights).  (Not
+            # while passes started ahead are reading the copies, unless the parameters really changed - then those passes
+            # are dropped below anyway)
+            if refreshed and self.spec:
+                self._drop_prefetched()
+                torch.cuda.current_stream().wait_stream(self.gstream)
+                for sl in self.slots:
+                    torch.cuda.current_stream().wait_stream(sl.stream)
             self.slots[0].eng.prepare_weights()
             self.dirty = False
         if not train:
@@ -208,7 +218,13 @@ class FusedBackbone:
             tok, cv = self._forward_eager(slot, task_id, images.float().contiguous(), False)
             tok = tok.clone()
             return tok, (tok.new_zeros(()) if not model.training else cv)
-        new_step = self.backward_seen or not self.hist          # first training forward after a backward: a new step begins
+        # a new step begins with the first training forward after the parameters changed (an optimizer step), or after a
+        # backward when this call cannot belong to the calls before it (other images, or a task that was already run): so
+        # both the joint schedule (all forwards, one backward) and one task at a time (forward / backward per task on the
+        # same images, train/train_utils.py:373-404) are seen as ONE step of [t0, t1, ..]
+        first = self.hist[0][1]() if self.hist else None
+        new_step = (not self.hist) or refreshed or (self.backward_seen and (first is not images or
+                                                                            task_id in [t for t, _ in self.hist]))
         self.backward_seen = False
         if new_step:
             self._close_step()
@@ -223,6 +239,7 @@ class FusedBackbone:
         if hit is not None:
             slot, tok, cv = hit
             slot.main = main
+            self.prefetch_hits += 1
         else:
             slot = self._launch(task_id, images, main)
             tok, cv = slot.result

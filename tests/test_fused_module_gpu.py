@@ -292,6 +292,33 @@ def test_fused_module_prefetches_the_other_task_passes_and_survives_a_wrong_gues
     assert torch.equal(ta, tb) and all(torch.equal(ga[n], gb[n]) for n in ga)
 
 
+def test_fused_module_one_task_at_a_time_prefetches_the_next_task():
+    """`one_by_one` (train/train_utils.py:373-404): forward / backward per task on the same images, the optimizer step after
+    the last task.  The step boundary is the parameter change, so the step is seen as [t0, t1] and from the third step on
+    the forward of t1 runs under t0's forward and backward; same gradients as without."""
+    _need_gpu()
+    a, cfg = _model()
+    b, _ = _model()
+    img = torch.randn(3, 3, 32, 48).cuda()
+    dtok = (torch.randn(3, cfg.num_tokens, 64) * 0.1).cuda()
+    for step in range(5):
+        res = []
+        for m in (a, b):
+            m.zero_grad(set_to_none=True)
+            for task in (0, 1):
+                tok, cv = m(img, task_id=task)
+                if m is b:
+                    m._fused.prefetch = False
+                ((tok * dtok).sum() + 0.01 * cv).backward()
+            torch.cuda.synchronize()
+            res.append({n: p.grad.detach().clone() for n, p in m.named_parameters()})
+            with torch.no_grad():
+                torch._foreach_mul_(list(m.parameters()), 1.0)          # optimizer.step(): every parameter written in place
+        assert all(torch.equal(res[0][n], res[1][n]) for n in res[0]), step
+    assert a._fused.pattern == [0, 1] and a._fused.prefetch_hits >= 3 and a._fused.prefetch_misses == 0
+    assert b._fused.prefetch_hits == 0
+
+
 def _dgdp_worker(rank, world, port, q):
     """the reference's data-parallel wrapper around the fused module path (train_fastmoe.py:460 DistributedGroupedDataParallel,
     train/train_utils.py:414 model.allreduce_params()): every rank its own images, the averaged gradients of the dense
