@@ -518,8 +518,13 @@ def main():
             legs.append(("dp_shared_stem", "dp_shared_stem", lambda: run_mode(args.dtype, False, False, share_stem=True),
                          SHARED_WATCHDOG_S))
         import datetime
-        agree_group = None if os.environ.get("M3_BENCH_NO_AGREE") == "1" else \
-            dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=AGREE_S))
+        agree_group = None
+        if os.environ.get("M3_BENCH_NO_AGREE") != "1":
+            try:          # (a CPU group next to the RCCL one; if gloo cannot come up on this host the legs run without agreement)
+                agree_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=AGREE_S))
+            except Exception as exc:      # noqa: BLE001
+                log(f"no CPU agreement group ({type(exc).__name__}: {exc}); legs run without cross-rank agreement")
+                extra["agreement"] = "unavailable"
 
         def finished():
             return [r for r in results.values() if r is not None]
