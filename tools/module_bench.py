@@ -15,14 +15,28 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def module_path_step_time(dtype_name="f16", fused="auto", steps=20, warmup=5, batch=128, one_by_one=False, log=None):
+# the other BASELINE configs' shapes on one GPU (parity-test cases, not bench lines: tools/config_bench.py has the executor's times)
+OTHER_CONFIGS = {
+    2: (8, dict(img_size=(512, 512), embed_dim=384, depth=12, num_heads=12, moe_experts=16, moe_top_k=4, gate_dim=389,
+                multi_gate=False, gate_task_specific_dim=64)),
+    3: (128, dict(img_size=(224, 224), embed_dim=768, depth=12, num_heads=12, moe_experts=64, moe_top_k=4, gate_dim=770,
+                  multi_gate=True)),
+    4: (8, dict(img_size=(480, 640), embed_dim=768, depth=12, num_heads=12, moe_experts=16, moe_top_k=4, moe_mlp_ratio=4.0,
+                gate_dim=770, multi_gate=True)),
+}
+
+
+def module_path_step_time(dtype_name="f16", fused="auto", steps=20, warmup=5, batch=128, one_by_one=False, log=None, config=1):
     import m3vit_amd
     m3vit_amd.install_fmoe_shim()                      # the reference's `from fmoe...` imports bind to this repository
     from m3vit_amd.config import VIT_SMALL_MOE, BackboneConfig, init_params
     from m3vit_amd.vit import VisionTransformerMoE
-    cfg = BackboneConfig(**VIT_SMALL_MOE)
-    dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[dtype_name]
     kw = dict(VIT_SMALL_MOE)
+    if config != 1:
+        batch, kw = OTHER_CONFIGS[config]
+        kw = dict(mlp_ratio=4.0, moe_mlp_ratio=1.0, **kw) if "moe_mlp_ratio" not in kw else dict(mlp_ratio=4.0, **kw)
+    cfg = BackboneConfig(**kw)
+    dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[dtype_name]
     model = VisionTransformerMoE(vmoe_noisy_std=0.0, act_dtype=dt, fused=("auto" if fused == "auto" else False), **kw).cuda()
     model.load_state_dict(init_params(cfg, seed=1))
     model.train()
@@ -75,7 +89,8 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--one-by-one", action="store_true")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4], help="BASELINE configs[N] shapes on one GPU")
     a = ap.parse_args()
     import json
     print(json.dumps(module_path_step_time(a.dtype, a.fused, a.steps, 5, a.batch, a.one_by_one,
-                                           log=lambda m: print(m, file=sys.stderr, flush=True))))
+                                           log=lambda m: print(m, file=sys.stderr, flush=True), config=a.config)))
