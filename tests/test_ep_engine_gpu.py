@@ -110,7 +110,7 @@ def test_engine_expert_parallel_two_ranks_one_gpu(case):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, case)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=400) for _ in procs]
+    res = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(timeout=30)
     assert all(r[1] == "ok" for r in res), res
@@ -172,7 +172,7 @@ def test_data_parallel_step_parts_two_ranks_one_gpu():
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in procs]
+    res = [q.get(timeout=480) for _ in procs]
     for p in procs:
         p.join(timeout=30)
     assert all(r[1] == "ok" for r in res), res
@@ -225,7 +225,7 @@ def test_expert_parallel_step_with_interleaved_task_streams_two_ranks_one_gpu():
     procs = [ctx.Process(target=_ep_step_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in procs]
+    res = [q.get(timeout=480) for _ in procs]
     for p in procs:
         p.join(timeout=30)
     assert all(r[1] == "ok" for r in res), res
@@ -313,7 +313,7 @@ def test_expert_parallel_fixed_capacity_exchange_two_ranks_one_gpu():
     procs = [ctx.Process(target=_ep_fixed_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in procs]
+    res = [q.get(timeout=480) for _ in procs]
     for p in procs:
         p.join(timeout=30)
     assert all(r[1] == "ok" for r in res), res
@@ -382,7 +382,7 @@ def test_expert_parallel_with_activation_checkpointing_two_ranks_one_gpu():
     procs = [ctx.Process(target=_ep_ckpt_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in procs]
+    res = [q.get(timeout=480) for _ in procs]
     for p in procs:
         p.join(timeout=30)
     assert all(r[1] == "ok" for r in res), res

@@ -377,7 +377,7 @@ def test_fused_module_under_the_grouped_data_parallel_wrapper_two_ranks_one_gpu(
     procs = [ctx.Process(target=_dgdp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in procs]
+    res = [q.get(timeout=480) for _ in procs]
     for p in procs:
         p.join(timeout=30)
     assert all(r[1] == "ok" for r in res), res
@@ -449,7 +449,7 @@ def test_fused_module_with_sharded_experts_two_ranks_one_gpu():
     procs = [ctx.Process(target=_ep_module_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in procs]
+    res = [q.get(timeout=480) for _ in procs]
     for p in procs:
         p.join(timeout=30)
     assert all(r[1] == "ok" for r in res), res
