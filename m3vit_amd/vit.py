@@ -34,25 +34,48 @@ class HipLayerNorm(nn.LayerNorm):
         return LayerNormFn.apply(x, self.weight, self.bias, self.eps, self.act_dtype)
 
 
+class Dropout(nn.Dropout):
+    """nn.Dropout that knows its call site (element-wise dropout, drop_rate > 0: configs/nyud/vit_moe/*drop0.1*.yml; the six
+    sites are listed in oracle/ref_torch.py).  `mask_fn(site, shape, p) -> factors` (class attribute, tests only) pins the
+    masks; otherwise torch draws them.  Dropout runs on the per-op module path: the fused executor has no dropout."""
+    mask_fn = None
+
+    def __init__(self, p=0.0, site=""):
+        super().__init__(p)
+        self.site = site
+
+    def forward(self, x, site=None):
+        if self.p == 0.0 or not self.training:
+            return x
+        if Dropout.mask_fn is not None:
+            return x * Dropout.mask_fn(site or self.site, x.shape, self.p).to(device=x.device, dtype=x.dtype)
+        return nn.functional.dropout(x, self.p, True)
+
+
 class Mlp(nn.Module):
-    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0., site=""):
         super().__init__()
-        assert drop == 0.0, "dropout is not part of the hot path (0 in all BASELINE configs)"
         out_features = out_features or in_features
         hidden_features = hidden_features or in_features
         self.fc1 = nn.Linear(in_features, hidden_features)
         self.act = act_layer()
         self.fc2 = nn.Linear(hidden_features, out_features)
-        self.drop = nn.Dropout(drop)
+        self.drop = Dropout(drop, site)
+        self.site = site
 
     def forward(self, x):
-        return MlpFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+        if self.drop.p == 0.0 or not self.training:
+            return MlpFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+        # vision_transformer_moe.py:255-261 with drop > 0: the ONE Dropout module is applied after the activation and after fc2
+        h = self.act(PlainLinearFn.apply(x, self.fc1.weight, self.fc1.bias))
+        h = self.drop(h, self.site + "mlp.act")
+        return self.drop(PlainLinearFn.apply(h, self.fc2.weight, self.fc2.bias), self.site + "mlp.out")
 
 
 class Attention(nn.Module):
-    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0., site=""):
         super().__init__()
-        assert attn_drop == 0.0 and proj_drop == 0.0
+        assert attn_drop == 0.0, "dropout on the attention probabilities (inside the attention kernel) is not supported"
         self.num_heads = num_heads
         head_dim = dim // num_heads
         assert qk_scale is None or abs(qk_scale - head_dim ** -0.5) < 1e-12, "custom qk_scale not supported"
@@ -60,12 +83,12 @@ class Attention(nn.Module):
         self.qkv = nn.Linear(dim, dim * 3, bias=bool(qkv_bias))
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj = nn.Linear(dim, dim)
-        self.proj_drop = nn.Dropout(proj_drop)
+        self.proj_drop = Dropout(proj_drop, site + "attn.proj")
 
     def forward(self, x):
         qkv = PlainLinearFn.apply(x, self.qkv.weight, self.qkv.bias)
         o = AttentionCoreFn.apply(qkv, self.num_heads)
-        return PlainLinearFn.apply(o, self.proj.weight, self.proj.bias)
+        return self.proj_drop(PlainLinearFn.apply(o, self.proj.weight, self.proj.bias))
 
 
 class DropPath(nn.Module):
@@ -118,21 +141,21 @@ class Block(nn.Module):
                  moe_gate_type="noisy_vmoe", vmoe_noisy_std=1, gate_task_specific_dim=-1, multi_gate=False,
                  regu_experts_fromtask=False, num_experts_pertask=-1, num_tasks=-1, gate_input_ahead=False,
                  regu_sem=False, sem_force=False, regu_subimage=False, expert_prune=False, use_checkpointing=False,
-                 convention="ckpt"):
+                 convention="ckpt", site=""):
         super().__init__()
-        assert drop == 0.0 and attn_drop == 0.0, "dropout inside the fused MLP / attention kernels is not supported"
+        assert attn_drop == 0.0, "dropout on the attention probabilities is not supported"
         assert convention in ("ckpt", "origin")
         self.convention = convention
         self.moe = moe
         self.norm1 = norm_layer(dim)
-        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, proj_drop=drop, site=site)
         self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()      # :397-398 (one module, two draws per block)
         self.norm2 = norm_layer(dim)
         self.gate_input_ahead = gate_input_ahead
         if moe:
             self.tot_expert = moe_experts * world_size
             self.moe_top_k = moe_top_k
-            activation = nn.Sequential(act_layer(), nn.Dropout(drop))
+            activation = nn.Sequential(act_layer(), Dropout(drop, site + "experts.act"))
             if moe_gate_dim < 0:
                 moe_gate_dim = dim
             if moe_mlp_ratio < 0:
@@ -146,9 +169,9 @@ class Block(nn.Module):
                                           regu_experts_fromtask=regu_experts_fromtask,
                                           num_experts_pertask=num_experts_pertask, num_tasks=num_tasks,
                                           expert_prune=expert_prune, sem_force=sem_force, convention=convention)
-            self.mlp_drop = nn.Dropout(drop)
+            self.mlp_drop = Dropout(drop, site + "mlp_drop")
         else:
-            self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+            self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop, site=site)
 
     def forward(self, x, gate_inp=None, task_id=None, task_specific_feature=None, sem=None):
         if self.gate_input_ahead:
@@ -158,11 +181,11 @@ class Block(nn.Module):
         if self.convention == "origin":                                   # origin/vision_transformer_moe.py:275-283
             if not self.moe:
                 return x + self.drop_path(self.mlp(normed).to(x.dtype))
-            return x + self.drop_path(self.mlp(normed, gate_inp, task_id, task_specific_feature, sem).to(x.dtype))
+            return x + self.drop_path(self.mlp_drop(self.mlp(normed, gate_inp, task_id, task_specific_feature, sem)).to(x.dtype))
         if not self.moe:
             return x + self.drop_path(self.mlp(normed).to(x.dtype)), None
         out, clean, noisy, std, top_logits, gates = self.mlp(normed, gate_inp, task_id, task_specific_feature, sem)
-        x = x + self.drop_path(out.to(x.dtype))
+        x = x + self.drop_path(self.mlp_drop(out).to(x.dtype))
         cv_loss = block_balance_loss(gates, clean, noisy, std, top_logits, self.mlp.top_k) if self.training else 0   # :453-459,540
         return x, cv_loss
 
@@ -210,7 +233,9 @@ class VisionTransformerMoE(nn.Module):
                                 multi_gate=bool(multi_gate), gate_task_specific_dim=gate_task_specific_dim,
                                 vmoe_noisy_std=float(vmoe_noisy_std))
         why = None
-        if not qkv_bias:
+        if drop_rate > 0.0:
+            why = "element-wise dropout (drop_rate > 0)"
+        elif not qkv_bias:
             why = "qkv_bias=False"
         elif world_size > 1 and use_checkpointing:
             why = "expert parallel layer with activation checkpointing"
@@ -224,7 +249,7 @@ class VisionTransformerMoE(nn.Module):
         elif (not multi_gate) and gate_task_specific_dim >= 0 and self._cfg_kwargs["gate_dim"] <= embed_dim:
             why = "task-conditioned gate without tasks"
         self._fused_static_ok, self._fused_static_why = why is None, why
-        assert drop_rate == 0.0 and attn_drop_rate == 0.0, "dropout inside the fused kernels is not supported"
+        assert attn_drop_rate == 0.0, "dropout on the attention probabilities is not supported"
         dpr = [drop_path_rate * i / max(depth - 1, 1) for i in range(depth)]          # linspace(0, rate, depth), :632
         self.img_size = tuple(img_size) if isinstance(img_size, (tuple, list)) else (img_size, img_size)
         self.patch_size = patch_size
@@ -237,7 +262,7 @@ class VisionTransformerMoE(nn.Module):
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
         self.dist_token = None
         self.pos_embed = nn.Parameter(torch.zeros(1, self.num_patches + 1, embed_dim))
-        self.pos_drop = nn.Dropout(p=drop_rate)
+        self.pos_drop = Dropout(drop_rate, "pos")
         self.num_tasks = gate_dim - embed_dim
         self.gate_task_specific_dim = gate_task_specific_dim
         self.multi_gate = multi_gate
@@ -248,11 +273,11 @@ class VisionTransformerMoE(nn.Module):
         blocks = []
         for i in range(depth):
             if i % 2 == 0:
-                blocks.append(Block(embed_dim, num_heads, mlp_ratio, qkv_bias, qk_scale, drop_path=dpr[i],
-                                    norm_layer=norm_layer, convention=convention))
+                blocks.append(Block(embed_dim, num_heads, mlp_ratio, qkv_bias, qk_scale, drop=drop_rate, drop_path=dpr[i],
+                                    norm_layer=norm_layer, convention=convention, site=f"blocks.{i}."))
             else:
-                blocks.append(Block(embed_dim, num_heads, mlp_ratio, qkv_bias, qk_scale, drop_path=dpr[i],
-                                    norm_layer=norm_layer, moe=True,
+                blocks.append(Block(embed_dim, num_heads, mlp_ratio, qkv_bias, qk_scale, drop=drop_rate, drop_path=dpr[i],
+                                    norm_layer=norm_layer, moe=True, site=f"blocks.{i}.",
                                     moe_mlp_ratio=moe_mlp_ratio, moe_experts=moe_experts, moe_top_k=moe_top_k,
                                     moe_gate_dim=gate_dim, world_size=world_size, moe_gate_type=moe_gate_type,
                                     vmoe_noisy_std=vmoe_noisy_std, gate_task_specific_dim=gate_task_specific_dim,
@@ -306,7 +331,7 @@ class VisionTransformerMoE(nn.Module):
                 raise RuntimeError(f"VisionTransformerMoE(fused=True): {self.fused_fallback_reason}")
         B = x.shape[0]
         x = self.patch_embed(x, self.act_dtype).float()
-        x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1) + self.pos_embed
+        x = self.pos_drop(torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1) + self.pos_embed)      # :791
         tsf = None
         if (task_id is not None) and (self.gate_task_represent is not None):
             one_hot = torch.zeros(self.num_tasks, device=x.device)

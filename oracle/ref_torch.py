@@ -113,6 +113,22 @@ def route_build(idx: torch.Tensor, num_expert: int):
     return counts, offsets, pos, row_of_slot
 
 
+# ------------------------------------------------------------------------ dropout sites
+# Element-wise dropout (drop_rate > 0: configs/nyud/vit_moe/*drop0.1*.yml) sits at six call sites of the backbone:
+#   "pos"                      pos_drop on the embedded tokens               vision_transformer_moe.py:791
+#   "blocks.i.attn.proj"       Attention.proj_drop                           :297,312
+#   "blocks.i.mlp.act/.out"    Mlp.drop after the activation and after fc2   :258,260
+#   "blocks.i.experts.act"     Dropout inside the experts' activation        :409-412
+#   "blocks.i.mlp_drop"        mlp_drop on the MoE output                    :434,450
+# backbone_forward(dropout=fn) calls fn(site, tensor) -> tensor there (tests pin the masks by site name); None = p = 0.
+_DROP = {"fn": None, "prefix": ""}
+
+
+def _drop(site, x):
+    fn = _DROP["fn"]
+    return x if fn is None else fn(_DROP["prefix"] + site, x)
+
+
 # ------------------------------------------------------------------------ experts
 def gelu_erf(x):
     """nn.GELU() (exact erf), activation at models/moe/ckpt/vision_transformer_moe.py:409-412."""
@@ -124,14 +140,20 @@ def experts_ffn(rows: torch.Tensor, counts, w1, b1, w2, b2):
     semantics (:32-33): rows are grouped by expert (counts[e] consecutive rows each);
     y_e = GELU(x_e W1_e^T + b1_e) W2_e^T + b2_e with W1 [E,H,D], W2 [E,D,H]
     (layout: utils/helpers.py:645-662)."""
-    outs = []
+    hs = []
     start = 0
-    for e, n in enumerate([int(c) for c in counts]):
-        xe = rows[start:start + n]
-        h = gelu_erf(F.linear(xe, w1[e], b1[e]))
-        outs.append(F.linear(h, w2[e], b2[e]))
+    ns = [int(c) for c in counts]
+    for e, n in enumerate(ns):
+        hs.append(gelu_erf(F.linear(rows[start:start + n], w1[e], b1[e])))
         start += n
-    return torch.cat(outs, 0) if outs else rows.new_zeros((0, w2.shape[1]))
+    if not hs:
+        return rows.new_zeros((0, w2.shape[1]))
+    h_all = _drop("experts.act", torch.cat(hs, 0))             # Sequential(GELU(), Dropout(drop)) on the expert-major rows
+    outs, start = [], 0
+    for e, n in enumerate(ns):
+        outs.append(F.linear(h_all[start:start + n], w2[e], b2[e]))
+        start += n
+    return torch.cat(outs, 0)
 
 
 def moe_dispatch_ffn(x: torch.Tensor, idx: torch.Tensor, w1, b1, w2, b2):
@@ -180,12 +202,12 @@ def attention(x, wqkv, bqkv, wproj, bproj, num_heads: int):
     attn = (q @ k.transpose(-2, -1)) * (dh ** -0.5)
     attn = attn.softmax(dim=-1)
     o = (attn @ v).transpose(1, 2).reshape(B, N, C)
-    return F.linear(o, wproj, bproj)
+    return _drop("attn.proj", F.linear(o, wproj, bproj))
 
 
 def mlp_dense(x, w1, b1, w2, b2):
     """Mlp.forward, models/moe/ckpt/vision_transformer_moe.py:255-261 (drop = 0)."""
-    return F.linear(gelu_erf(F.linear(x, w1, b1)), w2, b2)
+    return _drop("mlp.out", F.linear(_drop("mlp.act", gelu_erf(F.linear(x, w1, b1))), w2, b2))
 
 
 def task_embedding(params: Dict[str, torch.Tensor], num_tasks: int, task_id: int):
@@ -314,6 +336,7 @@ def block_forward(params, cfg: BackboneCfg, i: int, x, task_id: Optional[int], t
     Returns (x_out, cv_loss or None, aux dict)."""
     p = params
     b = f"blocks.{i}."
+    _DROP["prefix"] = b
     s_attn = s_mlp = 1.0
     if path_scale is not None:
         s_attn, s_mlp = (v.to(x.dtype).view(-1, 1, 1) for v in path_scale)
@@ -341,7 +364,7 @@ def block_forward(params, cfg: BackboneCfg, i: int, x, task_id: Optional[int], t
         p[b + "mlp.experts.h4toh.weight"], p[b + "mlp.experts.h4toh.bias"],
         cfg.moe_top_k, noise=noise, noise_std=cfg.vmoe_noisy_std, training=training,
         idx_override=idx_override)
-    x = x + s_mlp * out
+    x = x + s_mlp * _drop("mlp_drop", out)
     importance = gates.sum(0)                                  # :453
     E = gates.shape[1]
     if cfg.moe_top_k < E and abs(std) > 1e-6:                  # :456-459
@@ -354,12 +377,22 @@ def block_forward(params, cfg: BackboneCfg, i: int, x, task_id: Optional[int], t
 
 
 def backbone_forward(params, cfg: BackboneCfg, images, task_id: Optional[int], training: bool = True,
-                     noises=None, route_override=None, path_scales=None):
+                     noises=None, route_override=None, path_scales=None, dropout=None):
     """VisionTransformerMoE.forward_features, vision_transformer_moe.py:780-880:
-    returns (tokens[B,N,D] of the last block, total_cv_loss)."""
+    returns (tokens[B,N,D] of the last block, total_cv_loss).  dropout: fn(site, tensor) -> tensor applied at the
+    element-wise dropout sites (see _DROP above)."""
     p = params
+    _DROP["fn"], _DROP["prefix"] = dropout, ""
+    try:
+        return _backbone_forward(p, cfg, images, task_id, training, noises, route_override, path_scales)
+    finally:
+        _DROP["fn"], _DROP["prefix"] = None, ""
+
+
+def _backbone_forward(p, cfg, images, task_id, training, noises, route_override, path_scales):
     x = patch_embed(images, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"],
                     p["cls_token"], p["pos_embed"])
+    x = _drop("pos", x)
     tsf = None
     if task_id is not None and "gate_task_represent.fc1.weight" in p:
         tsf = task_embedding(p, cfg.num_tasks, task_id)

@@ -97,6 +97,66 @@ def test_vit_mirror_drop_path_matches_oracle():
     assert rel(tok_e, te) < 2e-4
 
 
+def test_vit_mirror_elementwise_dropout_matches_oracle():
+    """drop_rate > 0 (configs/nyud/vit_moe/*drop0.1*.yml): element-wise dropout at the reference's six call sites - pos_drop
+    (vision_transformer_moe.py:791), Attention.proj_drop (:297,312), Mlp.drop after the activation and after fc2 (:258,260),
+    the Dropout inside the experts' activation (:409-412), mlp_drop on the MoE output (:434,450) - with the masks pinned by
+    site name on both sides; forward and every gradient against the float64 oracle; eval mode is the drop_rate = 0 model.
+    Runs on the per-op path (the fused executor has no dropout and says so)."""
+    _need_gpu()
+    import zlib
+    from m3vit_amd.vit import Dropout, VisionTransformerMoE
+    from oracle import ref_torch as R
+    kw = dict(img_size=(32, 32), embed_dim=64, depth=4, num_heads=2, moe_experts=4, moe_top_k=2, gate_dim=66, multi_gate=True)
+    cfg = R.BackboneCfg(mlp_ratio=4.0, moe_mlp_ratio=1.0, vmoe_noisy_std=0.0, **kw)
+    P = R.init_backbone_params(cfg, seed=13)
+    p_drop = 0.25
+    m = VisionTransformerMoE(mlp_ratio=4.0, moe_mlp_ratio=1, vmoe_noisy_std=0.0, drop_rate=p_drop, **kw).cuda()
+    m.load_state_dict(P)
+    seen = []
+
+    def mask(site, shape, p):
+        n = 1
+        for d in shape:
+            n *= d
+        g = torch.Generator().manual_seed(zlib.crc32(site.encode()))
+        seen.append(site)
+        return ((torch.rand(n, generator=g) >= p).float() / (1.0 - p)).view(shape)
+
+    img = torch.randn(3, 3, 32, 32)
+    dtok = torch.randn(3, cfg.num_tokens, 64) * 0.1
+    Dropout.mask_fn = mask
+    try:
+        m.train()
+        tok, cv = m(img.cuda(), task_id=1)
+        assert m.fused_fallback_reason == "element-wise dropout (drop_rate > 0)" and m._fused is None
+        ours = list(seen)
+        del seen[:]
+        Pr = {k: v.clone().double().requires_grad_() for k, v in P.items()}
+        tr, cr, _ = R.backbone_forward(Pr, cfg, img.double(), 1, dropout=lambda site, x: x * mask(site, x.shape, p_drop).double())
+        assert sorted(ours) == sorted(seen) and len(ours) == 1 + 4 + 2 * 2 + 2 * 2, (ours, seen)
+        assert rel(tok, tr) < 2e-4, rel(tok, tr)
+        ((tok * dtok.cuda()).sum() + 0.01 * cv).backward()
+        ((tr * dtok.double()).sum() + 0.01 * cr).backward()
+        bad = [(n, rel(p.grad, Pr[n].grad)) for n, p in m.named_parameters()
+               if Pr[n].grad is not None and rel(p.grad, Pr[n].grad) > 1e-3]
+        assert not bad, bad
+    finally:
+        Dropout.mask_fn = None
+    ref = VisionTransformerMoE(mlp_ratio=4.0, moe_mlp_ratio=1, vmoe_noisy_std=0.0, drop_rate=0.0, fused=False, **kw).cuda()
+    ref.load_state_dict(P)
+    m.eval(); ref.eval()
+    with torch.no_grad():
+        a, _ = m(img.cuda(), task_id=0)
+        b, _ = ref(img.cuda(), task_id=0)
+    assert rel(a, b) < 1e-5                                  # eval: dropout is the identity
+    m.train()                                                # torch's own draws: a different mask every call, expectation kept
+    with torch.no_grad():
+        x1, _ = m(img.cuda(), task_id=0)
+        x2, _ = m(img.cuda(), task_id=0)
+    assert not torch.equal(x1, x2)
+
+
 def test_composable_fmoe_path_with_custom_activation():
     """_fmoe_general_global_forward + FMoELinear with an activation the fused path does not cover."""
     _need_gpu()
