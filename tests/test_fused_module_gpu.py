@@ -34,7 +34,8 @@ def _model(std=0.0, E=4, fused="auto", act_dtype=torch.float32, seed=9, model_kw
     return m, cfg
 
 
-@pytest.mark.parametrize("std,act_dtype,tol", [(0.0, torch.float32, 2e-4), (1.0, torch.float32, 2e-4), (0.0, torch.float16, 1e-3)])
+@pytest.mark.parametrize("std,act_dtype,tol", [(0.0, torch.float32, 2e-4), (1.0, torch.float32, 2e-4), (0.0, torch.float16, 1e-3),
+                                               (0.0, torch.bfloat16, 8e-3)])
 def test_fused_module_joint_multitask_steps_match_oracle(std, act_dtype, tol):
     """The reference's joint multi-task step (models/models.py:299-320 + train/train_utils.py:423-457): backbone(x, task_id)
     for every task, ONE loss.backward(), optimizer.zero_grad(set_to_none=True), a parameter update - four steps, so that the
@@ -43,7 +44,7 @@ def test_fused_module_joint_multitask_steps_match_oracle(std, act_dtype, tol):
     _need_gpu()
     from oracle import ref_torch as R
     m, cfg = _model(std=std, E=8 if std else 4, act_dtype=act_dtype)
-    f16 = act_dtype == torch.float16
+    f16 = act_dtype in (torch.float16, torch.bfloat16)       # 16-bit storage: follow the module's routing
     B = 3
     for step in range(4):
         g = torch.Generator().manual_seed(100 + step)
