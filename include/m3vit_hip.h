@@ -436,6 +436,17 @@ int m3_assemble_tokens(const float *patch, const float *cls, const float *pos, i
 int m3_tokens_bwd(const float *dtok, int B, int np_, int D, void *dpatch, int dtype, float *dpos,
                   float *dcls, int beta, void *stream);
 
+/* -------------------------------------------------- decoder-head element-wise stage ("custom later")
+ * ReLU (optional) + bilinear x2 up-sampling with align_corners = False in one pass, channels-last: the element-wise half of a
+ * stage of models/heads/vit_up_head.py:181-214 (F.relu(syncbn(conv(x))) then F.interpolate(.., size = 2x, mode='bilinear')).
+ * x [N, H, W, C] (x_dtype; C a multiple of 8 for 16-bit, 4 for fp32) -> y [N, 2H, 2W, C] in x's dtype or M3_F32.
+ * Backward: dx [N, H, W, C] (x's dtype) = relu'(x) * transpose-resize(dy), dy in x's dtype or M3_F32; a gather over the 4 x 4
+ * window of output gradients each input pixel fed (deterministic). */
+int m3_relu_up2x_fwd(const void *x, int x_dtype, int64_t N, int H, int W, int C, int relu, void *y, int y_dtype,
+                     void *stream);
+int m3_relu_up2x_bwd(const void *dy, int dy_dtype, const void *x, int x_dtype, int64_t N, int H, int W, int C,
+                     int relu, void *dx, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -131,6 +131,8 @@ SIGNATURES = {
     "m3_route_ws_elems": (c_int64, [_L, _I]),
     "m3_route_build": (c_int, [_V, _L, _I, _V, _V, _V, _V, _V, _V, _V, _V]),
     "m3_ep_plan": (c_int, [_V, _V, _I, _I, _V, _V, _L, _V, _V, _V]),
+    "m3_relu_up2x_fwd": (c_int, [_V, _I, _L, _I, _I, _I, _I, _V, _I, _V]),
+    "m3_relu_up2x_bwd": (c_int, [_V, _I, _V, _I, _L, _I, _I, _I, _I, _V, _V]),
     "m3_ep_plan_fixed": (c_int, [_V, _V, _I, _I, _I, _V, _V, _L, _V, _V, _V, _V, _V, _V, _V, _V]),
     "m3_gemm_nt": (c_int, [POINTER(GemmArgs), _V]),
     "m3_gemm_set_variant": (c_int, [_I]),

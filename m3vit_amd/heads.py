@@ -20,15 +20,48 @@ import torch.nn.functional as F
 from .functional import LayerNormFn
 
 
+class ReluUp2xFn(torch.autograd.Function):
+    """F.interpolate(F.relu(x), scale 2, mode='bilinear', align_corners=False) on a channels-last CUDA tensor as ONE kernel each
+    way (m3_relu_up2x_fwd / _bwd; relu=False: the resize alone).  The output keeps x's dtype (out_fp32: fp32) - under fp16
+    autocast torch's own resize returns fp32, 4x the input, and a cast kernel follows each way."""
+
+    @staticmethod
+    def forward(ctx, x, relu, out_fp32):
+        from . import ops
+        ctx.save_for_backward(x)
+        ctx.relu = bool(relu)
+        return ops.relu_up2x_fwd(x, relu=ctx.relu, out_dtype=torch.float32 if out_fp32 else None)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        x, = ctx.saved_tensors
+        if g.dtype not in (x.dtype, torch.float32):
+            g = g.float()
+        g = g.contiguous(memory_format=torch.channels_last)
+        return ops.relu_up2x_bwd(g, x, relu=ctx.relu), None, None
+
+
+def _fusable(x, align_corners):
+    """the fused ReLU + x2 resize takes channels-last CUDA activations (what MIOpen's convolutions return under autocast) whose
+    channel count fills 16-byte vectors"""
+    return (x.is_cuda and not align_corners and x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16, torch.float32)
+            and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] % (4 if x.dtype == torch.float32 else 8) == 0)
+
+
 class VisionTransformerUpHead(nn.Module):
     def __init__(self, img_size=(480, 640), patch_size=16, embed_dim=384, num_classes=40, num_conv=4,
                  num_upsampe_layer=4, conv3x3_conv1x1=True, align_corners=False, sync_bn=False,
-                 act_dtype=torch.float32, channels=256, multi_level=False, tam=False, amp=False):
+                 act_dtype=torch.float32, channels=256, multi_level=False, tam=False, amp=False, fused_resize=True):
         """amp: run the conv / BN / resize stages under fp16 autocast on the GPU, as the reference does under its AMP step
         (pretrain/engine/train_one_epoch.py:35-61): at 480 x 640 (8 images, 40 classes) forward + backward 33.4 -> 13.9 ms,
         MIOpen's fp16 3x3 convolutions running at 406-475 TFLOP/s (tools/head_bench.py)."""
         super().__init__()
         self.amp = bool(amp)
+        # fused_resize: ReLU + bilinear x2 of a stage as one hand-written kernel each way (ReluUp2xFn) whenever the stage's
+        # tensor is channels-last on the GPU; forward + backward of the head at 480 x 640 under autocast: 13.7 -> see
+        # tools/head_bench.py.  False: torch's relu + interpolate (what rounds 1-3 ran)
+        self.fused_resize = bool(fused_resize)
         self.multi_level, self.tam = bool(multi_level), bool(tam)       # p['multi_level'], p['model_kwargs']['tam'] (:96-105)
         if (num_conv, num_upsampe_layer) not in ((4, 4), (2, 2), (2, 1)):
             raise NotImplementedError("supported stacks: num_conv / num_upsampe_layer = 4/4, 2/2, 2/1")
@@ -80,15 +113,21 @@ class VisionTransformerUpHead(nn.Module):
                 x = self._up(x, size=x.shape[-1] * 4)          # :171 (square size, as the reference writes it)
             return self._up(self.conv_1(x), size=self.img_size)
         out, taps = {}, []
+        want_taps = self.tam and self.training
         for i in range(4):
-            x = F.relu(getattr(self, f"syncbn_fc_{i}")(getattr(self, f"conv_{i}")(x)))
-            if i >= 1:
-                taps.append(x)                                           # tam_feature0..2: after conv_1..3 (:190-206)
-            if i < 3:
-                x = self._up(x, 2)
-                if self.multi_level:
-                    out[f"level{i + 1}"] = getattr(self, f"output_level_{i}")(x)     # :184-200
-        x = self._up(self.conv_4(x), 2)
+            x = getattr(self, f"syncbn_fc_{i}")(getattr(self, f"conv_{i}")(x))
+            if self.fused_resize and i < 3 and not (want_taps and i >= 1) and _fusable(x, self.align_corners):
+                x = ReluUp2xFn.apply(x, True, False)                     # relu + resize in one pass, dtype kept
+            else:
+                x = F.relu(x)
+                if i >= 1:
+                    taps.append(x)                                       # tam_feature0..2: after conv_1..3 (:190-206)
+                if i < 3:
+                    x = self._up(x, 2)
+            if i < 3 and self.multi_level:
+                out[f"level{i + 1}"] = getattr(self, f"output_level_{i}")(x)     # :184-200
+        x = self.conv_4(x)
+        x = ReluUp2xFn.apply(x, False, True) if (self.fused_resize and _fusable(x, self.align_corners)) else self._up(x, 2)
         if self.multi_level:
             out["final"] = x
             return out

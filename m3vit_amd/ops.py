@@ -690,6 +690,35 @@ def scale_rows_cast(src, row_scale, div, dst):
     return dst
 
 
+def _nhwc(t, name):
+    """t is a [N, C, H, W] tensor in channels-last memory format (its storage is [N, H, W, C])"""
+    if t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
+        raise _lib.M3Error(f"{name} must be a 4-d channels-last tensor")
+    if not t.is_cuda:
+        raise _lib.M3Error(f"{name} must live on the GPU (no CPU path)")
+    return t
+
+
+def relu_up2x_fwd(x, relu=True, out_dtype=None):
+    """y = bilinear x2 (align_corners False) of relu(x), channels-last [N, C, H, W] in -> [N, C, 2H, 2W] out (m3_relu_up2x_fwd)"""
+    _nhwc(x, "x")
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, 2 * H, 2 * W), dtype=out_dtype or x.dtype, device=x.device, memory_format=torch.channels_last)
+    check(lib().m3_relu_up2x_fwd(_p(x), dt_code(x.dtype), N, H, W, C, 1 if relu else 0, _p(y), dt_code(y.dtype), _stream()),
+          "m3_relu_up2x_fwd")
+    return y
+
+
+def relu_up2x_bwd(dy, x, relu=True):
+    _nhwc(dy, "dy"); _nhwc(x, "x")
+    N, C, H, W = x.shape
+    assert tuple(dy.shape) == (N, C, 2 * H, 2 * W)
+    dx = torch.empty_like(x, memory_format=torch.channels_last)
+    check(lib().m3_relu_up2x_bwd(_p(dy), dt_code(dy.dtype), _p(x), dt_code(x.dtype), N, H, W, C, 1 if relu else 0, _p(dx),
+                                 _stream()), "m3_relu_up2x_bwd")
+    return dx
+
+
 def im2row(img, P, rows):
     B, Cin, H, W = img.shape
     check(lib().m3_im2row(_p(img), B, Cin, H, W, P, _p(rows), dt_code(rows.dtype), _stream()), "m3_im2row")

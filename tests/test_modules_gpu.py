@@ -553,6 +553,75 @@ def test_origin_convention_matches_ckpt_convention(std):
     assert float(collect_noisy_gating_loss(b, 1.0)) == 0.0
 
 
+@pytest.mark.parametrize("dtype,gdtype", [(torch.float32, torch.float32), (torch.float16, torch.float16),
+                                          (torch.float16, torch.float32), (torch.bfloat16, torch.bfloat16)])
+@pytest.mark.parametrize("shape", [(2, 8, 1, 1), (1, 16, 1, 5), (3, 8, 4, 1), (2, 40, 7, 9), (2, 256, 30, 40)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_relu_up2x_kernels_match_torch(dtype, gdtype, shape, relu):
+    """m3_relu_up2x_fwd / _bwd (ReLU + bilinear x2, align_corners False, channels-last) against F.interpolate(F.relu(x)) and
+    its autograd in float64, incl. one-pixel planes (every neighbour clamped) and the fp32-output / fp32-gradient variants the
+    classifier stage of the decoder head uses (models/heads/vit_up_head.py:181-214)."""
+    _need_gpu()
+    import torch.nn.functional as F
+    from m3vit_amd.heads import ReluUp2xFn
+    if dtype == torch.float32 and shape[1] % 4 or dtype != torch.float32 and shape[1] % 8:
+        pytest.skip("channel count does not fill a vector")
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+    out_fp32 = gdtype == torch.float32 and dtype != torch.float32
+    y = ReluUp2xFn.apply(x, relu, out_fp32)
+    assert y.dtype == (torch.float32 if out_fp32 else dtype) and y.is_contiguous(memory_format=torch.channels_last)
+    xr = x.detach().double().cpu().requires_grad_()
+    yr = F.interpolate(F.relu(xr) if relu else xr, scale_factor=2, mode="bilinear", align_corners=False)
+    tol = {torch.float32: 1e-6, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
+    assert tuple(y.shape) == tuple(yr.shape) and rel(y, yr) < tol, rel(y, yr)
+    dy = torch.randn(yr.shape, generator=g)
+    y.backward(dy.to(y.dtype).cuda().contiguous(memory_format=torch.channels_last))
+    yr.backward(dy.to(y.dtype).double())
+    assert x.grad.dtype == dtype and rel(x.grad, xr.grad) < tol, rel(x.grad, xr.grad)
+
+
+def test_head_fused_resize_matches_torch_stages():
+    """VisionTransformerUpHead(fused_resize=True) - ReLU + x2 resize of every stage as one kernel each way, the classifier
+    stage's resize with fp32 output - against the same head on torch's relu + interpolate, under fp16 autocast (the
+    convolutions return channels-last tensors there): logits and every parameter gradient."""
+    _need_gpu()
+    from m3vit_amd.heads import ReluUp2xFn, VisionTransformerUpHead
+    torch.manual_seed(4)
+    a = VisionTransformerUpHead(img_size=(64, 96), embed_dim=64, num_classes=40, amp=True, fused_resize=True).cuda().train()
+    b = VisionTransformerUpHead(img_size=(64, 96), embed_dim=64, num_classes=40, amp=True, fused_resize=False).cuda().train()
+    b.load_state_dict(a.state_dict())
+    tok = torch.randn(3, 4 * 6 + 1, 64, device="cuda")
+    calls = []
+    orig = ReluUp2xFn.forward
+    ReluUp2xFn.forward = staticmethod(lambda ctx, x, relu, out_fp32: (calls.append((tuple(x.shape), relu, out_fp32)), orig(ctx, x, relu, out_fp32))[1])
+    try:
+        ya = a(tok)
+    finally:
+        ReluUp2xFn.forward = orig
+    assert len(calls) == 4 and calls[-1][1:] == (False, True) and all(c[1:] == (True, False) for c in calls[:3]), calls
+    yb = b(tok)
+    assert ya.shape == (3, 40, 64, 96) and ya.dtype == yb.dtype == torch.float32
+    # both are fp16-autocast approximations of the fp32 head (batch-norm statistics over few pixels amplify fp16 rounding
+    # of the stage inputs): the fused stages must sit as close to the fp32 head as torch's own fp16 stages do
+    ref = VisionTransformerUpHead(img_size=(64, 96), embed_dim=64, num_classes=40, amp=False, fused_resize=False).cuda().train()
+    ref.load_state_dict(a.state_dict())
+    yr = ref(tok)
+    ea, eb = rel(ya, yr), rel(yb, yr)
+    assert ea < 1.5 * eb + 1e-3 and ea < 1e-2, (ea, eb)
+    w = torch.randn_like(ya)
+    for m, y in ((a, ya), (b, yb), (ref, yr)):
+        (y * w).sum().backward()
+    worst = []
+    for (n, p), (_, q), (_, r) in zip(a.named_parameters(), b.named_parameters(), ref.named_parameters()):
+        if n.startswith("conv_") and n.endswith(".bias") and n != "conv_4.bias":
+            continue                      # (a bias in front of a batch norm has a zero gradient: rounding noise only)
+        ga, gb = rel(p.grad, r.grad), rel(q.grad, r.grad)
+        worst.append((n, ga, gb))
+        assert ga < 1.5 * gb + 5e-3, (n, ga, gb)
+    print("head gradients vs the fp32 head (fused, torch fp16 stages):", [(n, f"{x:.1e}", f"{y_:.1e}") for n, x, y_ in worst[:4]])
+
+
 def test_head_amp_option_matches_fp32_head():
     """VisionTransformerUpHead(amp=True): the conv / BN / resize stages under fp16 autocast (the reference's AMP step) - same
     parameters and state_dict keys as the fp32 head, outputs and parameter gradients within fp16 rounding of it."""

@@ -13,7 +13,9 @@ from m3vit_amd.heads import VisionTransformerUpHead  # noqa: E402
 
 dev = torch.device("cuda:0")
 B, D = 8, 384
-head = VisionTransformerUpHead(img_size=(480, 640), embed_dim=D, num_classes=40).to(dev).train()
+FUSED = os.environ.get("M3_HEAD_FUSED", "1") != "0"       # ReLU + x2 resize of a stage as one hand-written kernel each way
+head = VisionTransformerUpHead(img_size=(480, 640), embed_dim=D, num_classes=40, fused_resize=FUSED).to(dev).train()
+print(f"fused_resize={FUSED}")
 tok = torch.randn(B, 30 * 40 + 1, D, device=dev, requires_grad=True)
 
 
