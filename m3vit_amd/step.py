@@ -112,7 +112,8 @@ class MultiTaskStep:
         # stops executing both processes' queued work, profiles/r04_dp_shared_stem_stall.txt has the mechanism), so the form
         # that has been rehearsed stays the default there until a one-rank-per-GPU run says otherwise)
         lin = _os.environ.get("M3_LINEAR_GRAPHS", "auto")
-        self.linear_graphs = self.par and not self.share_stem and (lin == "1" or (lin == "auto" and self.world == 1))
+        self.linear_graphs = self.par and (lin == "1" or (lin == "auto" and self.world == 1)) and \
+            not (self.share_stem and nparts > 1)            # (a shared stem cut into data-parallel parts keeps the old form)
         self.graphs = None
         self.capture_error = None
         self.images = self.dtok = self.noises = self.logit_bias = None
@@ -324,18 +325,39 @@ class MultiTaskStep:
         synchronises every step (it reads the loss) the step is 0.4 ms shorter, the host never becomes the limiter, and at
         N > 1 the all-reduce behind a part is issued the moment the part is queued."""
         nparts = len(self.block_ranges)
-        prep = torch.cuda.CUDAGraph()
+        G = lambda: torch.cuda.CUDAGraph()                                        # noqa: E731
+        prep = G()
         with torch.cuda.graph(prep, capture_error_mode="thread_local"):
             self.eng.prepare_weights()
+            if self.share_stem:                  # the task-independent stem once, before the passes fork (see part())
+                self.eng.zero_grad()
+                self.eng.forward_stem(self.images)
         per = []
         for j in range(nparts):
             fn, gs = self._part(j), []
             for e, t in zip(self.engs, self.tasks):
-                g = torch.cuda.CUDAGraph()
+                g = G()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     fn(e, t)
                 gs.append(g)
             per.append(gs)
+        add_g = post_g = None
+        if self.share_stem:
+            # behind the join (single part: asserted by the caller): the other passes' gradients above the stem boundary are
+            # added on the idle first task stream while the stem's backward runs once on the summed d x - as two more linear
+            # graphs (same launches as part()'s tail)
+            lo, hi = self.segments[0]
+            cut = min(hi, max(lo, self.eng.grad_prefix(self.stem)))
+            if cut > lo:
+                add_g = G()
+                with torch.cuda.graph(add_g, capture_error_mode="thread_local"):
+                    self._add(lo, cut)
+            post_g = G()
+            with torch.cuda.graph(post_g, capture_error_mode="thread_local"):
+                self._stem_backward(0)
+                for n in self.late_names:
+                    for e in self.engs[1:]:
+                        ops.add_f32(self.eng.grads[n].view(-1), e.grads[n].view(-1))
         step = self
 
         class PartReplay:
@@ -355,9 +377,17 @@ class MultiTaskStep:
                         g.replay()
                 for st in step.streams:
                     main.wait_stream(st)
-                step._add(*step.segments[j])
+                if not step.share_stem:
+                    step._add(*step.segments[j])
+                    return
+                step.add_stream.wait_stream(main)
+                if add_g is not None:
+                    with torch.cuda.stream(step.add_stream):
+                        add_g.replay()
+                post_g.replay()
+                main.wait_stream(step.add_stream)
 
-        self._linear_keep = (prep, per)
+        self._linear_keep = (prep, per, add_g, post_g)
         return [PartReplay(j) for j in range(nparts)]
 
     def capture(self) -> bool:

@@ -1,40 +1,32 @@
 #!/usr/bin/env python3
-"""decoder head forward + backward at 480 x 640, fp16 autocast: NCHW against channels_last, and where the time goes
-(torch profiler, top kernels)."""
+"""decoder head forward + backward at 8 x 480 x 640 under fp16 autocast: where the time goes (torch profiler, top kernels),
+with torch's relu + resize stages (M3_HEAD_FUSED=0) or the fused ReLU + x2 resize kernels (default)."""
 import os
 import sys
-import time
 
 import torch
+from torch.profiler import ProfilerActivity, profile
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from m3vit_amd.heads import VisionTransformerUpHead  # noqa: E402
 
 dev = torch.device("cuda:0")
-B, D = 8, 384
-tok = torch.randn(B, 30 * 40 + 1, D, device=dev, requires_grad=True)
-for cl in (False, True):
-    head = VisionTransformerUpHead(img_size=(480, 640), embed_dim=D, num_classes=40, amp=True).to(dev).train()
-    if cl:
-        head = head.to(memory_format=torch.channels_last)
-        orig = head._stages
-        head._stages = lambda x, o=orig: o(x.contiguous(memory_format=torch.channels_last))
+fused = os.environ.get("M3_HEAD_FUSED", "1") != "0"
+head = VisionTransformerUpHead(img_size=(480, 640), embed_dim=384, num_classes=40, amp=True, fused_resize=fused).to(dev).train()
+tok = torch.randn(8, 30 * 40 + 1, 384, device=dev, requires_grad=True)
 
-    def run():
-        y = head(tok)
-        y.float().square().mean().backward()
+
+def run():
+    y = head(tok)
+    y.float().square().mean().backward()
+
+
+for _ in range(3):
+    run()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CUDA]) as prof:
     for _ in range(3):
         run()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(10):
-        run()
-    torch.cuda.synchronize()
-    print(f"channels_last={cl}: {(time.perf_counter() - t0) / 10 * 1e3:.2f} ms fwd+bwd", flush=True)
-    if not cl:
-        from torch.profiler import ProfilerActivity, profile
-        with profile(activities=[ProfilerActivity.CUDA]) as prof:
-            for _ in range(3):
-                run()
-            torch.cuda.synchronize()
-        print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=14, max_name_column_width=70))
+print(f"fused_resize={fused}: 3 iterations")
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=16, max_name_column_width=64))
