@@ -22,6 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--rounds", type=int, default=2)
 ap.add_argument("--serial", action="store_true", help="one stream instead of two")
+ap.add_argument("--only", default="", help="comma-separated substrings: run only the classes whose name contains one (plus the full step)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = BackboneConfig(**VIT_SMALL_MOE)
@@ -42,9 +43,21 @@ CLASSES = {
     "cast_batch (weight copies)": ["m3_cast_batch"],
     "add_f32 (gradient buffers)": ["m3_add_f32"],
     "balance + gate_bwd_logits + cast_f32": ["m3_balance_loss", "m3_gate_bwd_logits", "m3_cast_f32"],
+    "gate_bwd_logits alone": ["m3_gate_bwd_logits"],
+    "combine_gate_bwd": ["m3_combine_gate_bwd"],
     "im2row + assemble + tokens_bwd": ["m3_im2row", "m3_assemble_tokens", "m3_tokens_bwd"],
 }
-orig = {n: getattr(L, n) for names in CLASSES.values() for n in names}
+# finer cuts of m3_gemm_nt by launch shape: (label, predicate on the m3_gemm_args struct)
+GEMM_CUTS = {
+    "m3_gemm_nt, dense N = 384 launches only (591 workgroups: proj fwd/dgrad, qkv dgrad, fc2 fwd, fc1 dgrad)":
+        lambda g: g.N == 384 and not g.group_offsets,
+    "m3_gemm_nt, expert grouped launches only": lambda g: bool(g.group_offsets),
+    "m3_gemm_nt, dense N >= 1152 launches only (qkv fwd, fc1 fwd, fc2 dgrad)": lambda g: g.N >= 1152 and not g.group_offsets,
+}
+for label in GEMM_CUTS:
+    CLASSES[label] = ["m3_gemm_nt:" + label]
+orig = {n: getattr(L, n) for names in CLASSES.values() for n in names if ":" not in n}
+orig.setdefault("m3_gemm_nt", getattr(L, "m3_gemm_nt"))
 
 
 def build(skip):
@@ -58,7 +71,11 @@ def build(skip):
     r.step_eager()                       # a COMPLETE step first: every buffer a skipped kernel would write keeps realistic
     torch.cuda.synchronize()             # (stale) values - zeros or NaNs downstream would change the clock the chip holds
     for n in skip:
-        setattr(L, n, lambda *args: 0)
+        if ":" in n:                     # a shape cut of m3_gemm_nt: skip the launches the predicate picks
+            pred, real = GEMM_CUTS[n.split(":", 1)[1]], orig["m3_gemm_nt"]
+            setattr(L, "m3_gemm_nt", lambda args, stream, pred=pred, real=real: 0 if pred(args._obj) else real(args, stream))
+        else:
+            setattr(L, n, lambda *args: 0)
     assert r.capture()                   # (capture's own warm-up run and the captured graph lack the skipped launches)
     return r
 
@@ -76,6 +93,8 @@ def time_it(r):
 
 res = {}
 for name, skip in CLASSES.items():
+    if a.only and name != "full step" and not any(k in name for k in a.only.split(",")):
+        continue
     r = build(skip)
     res[name] = min(time_it(r) for _ in range(a.rounds))
     del r
