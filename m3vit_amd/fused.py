@@ -91,6 +91,7 @@ class FusedBackbone:
         import os
         self.prefetch = os.environ.get("M3VIT_PREFETCH", "1") != "0"
         self.hist, self.pattern, self.spec, self.spec_images, self.spec_version = [], None, {}, None, 0
+        self.hist_same = True
         self.backoff, self.prefetch_misses, self.prefetch_hits = 0, 0, 0
         self.backward_seen = False
         self.versions_changed = False
@@ -233,6 +234,9 @@ class FusedBackbone:
                                                images._version == self.spec_version) else None
         if hit is None and self.spec:
             self._drop_prefetched()                   # the caller did something else than last step: stop predicting for a while
+        # (whether the step's calls share ONE image tensor is noted now, while the tensor is alive: by the time the step is
+        # closed - at the next step's first call - a trainer has usually dropped the batch)
+        self.hist_same = self.hist_same and (not self.hist or self.hist[0][1]() is images)
         self.hist.append((task_id, weakref.ref(images)))
         if not self.spec:
             self.spec_images = None
@@ -282,11 +286,9 @@ class FusedBackbone:
         if self.spec:
             self._drop_prefetched()
         tasks = [t for t, _ in self.hist]
-        first = self.hist[0][1]() if self.hist else None
-        same = len(self.hist) >= 2 and first is not None and all(im() is first for _, im in self.hist) and \
-            len(set(tasks)) == len(tasks)
+        same = len(self.hist) >= 2 and self.hist_same and len(set(tasks)) == len(tasks)
         self.pattern = tasks if same else None
-        self.hist = []
+        self.hist, self.hist_same = [], True
         if self.backoff > 0:
             self.backoff -= 1
 

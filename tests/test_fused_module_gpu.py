@@ -291,6 +291,20 @@ def test_fused_module_prefetches_the_other_task_passes_and_survives_a_wrong_gues
     ta, ga = step(a, imgs[0], imgs[0])                     # and on it goes
     tb, gb = step(b, imgs[0], imgs[0])
     assert torch.equal(ta, tb) and all(torch.equal(ga[n], gb[n]) for n in ga)
+    # a trainer's loop: a NEW batch tensor every step, the old one dropped before the next step's first call - the step's
+    # "same images for every task" property must have been noted while the tensor was alive
+    fa.backoff = 0
+    hits = fa.prefetch_hits
+    for i in range(4):
+        cpu = torch.randn(3, 3, 32, 48, generator=torch.Generator().manual_seed(900 + i))
+        xa = cpu.cuda()
+        ta, ga = step(a, xa, xa)
+        del xa
+        xb = cpu.cuda()
+        tb, gb = step(b, xb, xb)
+        del xb
+        assert torch.equal(ta, tb) and all(torch.equal(ga[n], gb[n]) for n in ga), i
+    assert fa.prefetch_hits >= hits + 2 and fa.pattern == [0, 1], (fa.prefetch_hits, hits, fa.pattern)
 
 
 def test_fused_module_one_task_at_a_time_prefetches_the_next_task():
