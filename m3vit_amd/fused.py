@@ -146,6 +146,8 @@ class FusedBackbone:
             if eng0.params[n].data_ptr() != p.data_ptr():
                 raise RuntimeError(f"fused backbone: parameter {n} must be a contiguous fp32 CUDA tensor")
         self.cfg, self.batch, self.device = cfg, B, device
+        self.base_eng = eng0                     # owns the operand copies every context shares
+        self.slot_sets = {}                      # batch size -> its contexts (a smaller last batch of an epoch comes back)
         self.slots = [_Slot(0, eng0, device)]
         self.plist = [named[n] for n in eng0.params]                 # in the flat buffer's order
         # the buffer the parameters' .grad alias: the sum over the slots' own gradient buffers (same layout)
@@ -163,6 +165,26 @@ class FusedBackbone:
         self.moe_blocks = [i for i in range(cfg.depth) if cfg.is_moe(i)]
         self.dirty = True
 
+    def _switch_batch(self, B):
+        """another batch size (the short last batch of an epoch): its own contexts - activations are sized by the batch - on
+        the SAME parameters, operand copies and gradient buffer; the contexts of the sizes seen before are kept (three sizes
+        at most), so that going back to the usual size costs nothing"""
+        if any(s.busy for s in self.slots):
+            raise RuntimeError("fused backbone: batch size changed while a forward waits for its backward")
+        if self.spec:
+            self._drop_prefetched()
+        self.slot_sets[self.batch] = self.slots
+        slots = self.slot_sets.pop(B, None)
+        if slots is None:
+            e0 = self.base_eng
+            eng = e0 if e0.B == B else BackboneEngine(self.cfg, None, batch=B, dtype=e0.dt, device=str(self.device), share=e0,
+                                                      checkpoint=e0.checkpoint, **self.ep)
+            slots = [_Slot(0, eng, self.device)]
+        while len(self.slot_sets) > 2:
+            self.slot_sets.pop(next(iter(self.slot_sets)))
+        self.slots, self.batch = slots, B
+        self.hist, self.hist_same, self.pattern = [], True, None
+
     def _slot(self):
         for s in self.slots:
             if not s.busy:
@@ -170,7 +192,7 @@ class FusedBackbone:
         if len(self.slots) >= self.max_slots:
             raise RuntimeError(f"fused backbone: {self.max_slots} forward passes are waiting for their backward; "
                                "call backward() (or drop the outputs) before running more")
-        e0 = self.slots[0].eng
+        e0 = self.base_eng
         eng = BackboneEngine(self.cfg, None, batch=self.batch, dtype=e0.dt, device=str(self.device), share=e0,
                              checkpoint=e0.checkpoint, **self.ep)
         s = _Slot(len(self.slots), eng, self.device)
@@ -193,11 +215,13 @@ class FusedBackbone:
         model = self.model()
         B = images.shape[0]
         dev = images.device
-        if self.batch != B or not self.slots or dev != self.device or not self._check_params():
+        if not self.slots or dev != self.device or not self._check_params():
             if any(s.busy for s in self.slots):
-                raise RuntimeError("fused backbone: batch size / parameter storage changed while a forward waits for its backward")
+                raise RuntimeError("fused backbone: parameter storage changed while a forward waits for its backward")
             self._build(B, dev)
             self._check_params()
+        elif self.batch != B:
+            self._switch_batch(B)
         train = torch.is_grad_enabled()
         main = torch.cuda.current_stream()
         refreshed = self.versions_changed
@@ -212,7 +236,7 @@ class FusedBackbone:
                 torch.cuda.current_stream().wait_stream(self.gstream)
                 for sl in self.slots:
                     torch.cuda.current_stream().wait_stream(sl.stream)
-            self.slots[0].eng.prepare_weights()
+            self.base_eng.prepare_weights()
             self.dirty = False
         if not train:
             slot = self._slot()

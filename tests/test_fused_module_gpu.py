@@ -334,6 +334,37 @@ def test_fused_module_one_task_at_a_time_prefetches_the_next_task():
     assert b._fused.prefetch_hits == 0
 
 
+def test_fused_module_batch_size_changes():
+    """the short last batch of an epoch: another batch size gets its own contexts on the same parameters and the same
+    gradient buffer, the usual size's contexts (and their graphs) are kept for when it comes back"""
+    _need_gpu()
+    a, cfg = _model()
+    b, _ = _model(fused=False)
+    g = torch.Generator().manual_seed(21)
+    ctx_of_3 = None
+    for step, B in enumerate((3, 3, 3, 2, 3, 3, 5, 3)):
+        img = torch.randn(B, 3, 32, 48, generator=g).cuda()
+        dtok = (torch.randn(B, cfg.num_tokens, 64, generator=g) * 0.1).cuda()
+        for m in (a, b):
+            m.zero_grad(set_to_none=True)
+            loss = 0.0
+            for task in (0, 1):
+                tok, cv = m(img, task_id=task)
+                loss = loss + (tok * dtok).sum() + 0.01 * cv
+            loss.backward()
+        torch.cuda.synchronize()
+        assert a.fused_fallback_reason is None and a._fused.batch == B
+        bad = [(n, rel(p.grad, q.grad)) for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters())
+               if rel(p.grad, q.grad) > 2e-4]
+        assert not bad, (step, B, bad)
+        if step == 2:
+            ctx_of_3 = a._fused.slots[0]
+            assert ctx_of_3.graphs_f and ctx_of_3.graphs_b
+        if step in (4, 7):
+            assert a._fused.slots[0] is ctx_of_3, "the contexts (and graphs) of the usual batch size must have been kept"
+    assert sorted(a._fused.slot_sets) == [2, 5]
+
+
 def _dgdp_worker(rank, world, port, q):
     """the reference's data-parallel wrapper around the fused module path (train_fastmoe.py:460 DistributedGroupedDataParallel,
     train/train_utils.py:414 model.allreduce_params()): every rank its own images, the averaged gradients of the dense
