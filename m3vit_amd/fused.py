@@ -96,6 +96,14 @@ class FusedBackbone:
         self.backward_seen = False
         self.versions_changed = False
 
+    # a copy of the model (copy.deepcopy for an EMA twin, torch.save of the whole module) gets no executor state - contexts,
+    # streams and graphs are rebuilt at its first call
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
+
     # ------------------------------------------------------------------ eligibility
     @staticmethod
     def unsupported(model, x, gate_inp, task_id, sem):

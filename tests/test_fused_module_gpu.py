@@ -85,11 +85,15 @@ def test_fused_module_joint_multitask_steps_match_oracle(std, act_dtype, tol):
     assert fb.slots[0].graphs_f and fb.slots[0].graphs_b and fb.slots[1].graphs_b, "steps 2.. must have replayed hipGraphs"
 
 
-def test_fused_module_matches_per_op_module_path():
+@pytest.mark.parametrize("ckpt", [False, True])
+def test_fused_module_matches_per_op_module_path(ckpt):
     """same weights, same images: the fused node and the per-op autograd Functions (fused=False) agree on tokens, balance
-    loss and every gradient (fp32: summation order only)"""
+    loss and every gradient (fp32: summation order only); ckpt: use_checkpointing=True (the reference's default memory mode:
+    the executor keeps block inputs only and re-runs each block in backward).  A deep copy of a model that already ran
+    (an EMA twin) starts without executor state and builds its own."""
     _need_gpu()
-    a, cfg = _model(fused="auto")
+    import copy
+    a, cfg = _model(fused="auto", model_kw=dict(use_checkpointing=ckpt))
     b, _ = _model(fused=False)
     img = torch.randn(4, 3, 32, 48).cuda()
     dtok = (torch.randn(4, cfg.num_tokens, 64) * 0.1).cuda()
@@ -103,10 +107,15 @@ def test_fused_module_matches_per_op_module_path():
             loss.backward()
             m.last = (tok.detach(), cv.detach())
         assert a.fused_fallback_reason is None and b._fused is None
+        assert a._fused.slots[0].eng.checkpoint == ckpt
         assert rel(a.last[0], b.last[0]) < 1e-5 and abs(float(a.last[1]) - float(b.last[1])) < 1e-5
         bad = [(n, rel(p.grad, q.grad)) for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters())
                if rel(p.grad, q.grad) > 2e-4]
         assert not bad, (rep, bad)
+    twin = copy.deepcopy(a)
+    assert twin._fused is None and a._fused is not None
+    tok, cv = twin(img, task_id=0)
+    assert twin._fused is not None and twin._fused is not a._fused and torch.equal(tok, a(img, task_id=0)[0])
 
 
 def test_fused_module_gradient_semantics():
