@@ -44,6 +44,7 @@ class _Slot:
         self.result = None
         self.calls_f, self.calls_b = {}, {}          # per task: number of forward / backward calls seen
         self.graphs_f, self.graphs_b = {}, {}
+        self.calls_e, self.graphs_e = {}, {}         # forward without autograd (evaluation): per (task, training flag)
         self.images = self.dtok = None               # static inputs of the graphs
         self.dcv = torch.zeros(1, dtype=torch.float32, device=device)
         self.noises = self.path_scales = None
@@ -247,10 +248,30 @@ class FusedBackbone:
             self.base_eng.prepare_weights()
             self.dirty = False
         if not train:
+            # no autograd (evaluation, or a no_grad probe in training mode): a forward on a free context, on the caller's
+            # stream; replayed from a hipGraph of its own from the second use on (an evaluation loop is ~100 launches a call)
             slot = self._slot()
-            tok, cv = self._forward_eager(slot, task_id, images.float().contiguous(), False)
+            key = (task_id, bool(model.training))
+            n = slot.calls_e.get(key, 0)
+            slot.calls_e[key] = n + 1
+            if not self.graph or n == 0:
+                tok, cv = self._forward_eager(slot, task_id, images.float().contiguous(), False)
+            else:
+                if slot.images is None:
+                    slot.images = torch.empty(images.shape, dtype=torch.float32, device=self.device)
+                slot.images.copy_(images)
+                noises, ps = self._draw(slot, slot.eng)
+                g = slot.graphs_e.get(key)
+                if g is None:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        out = slot.eng.forward(slot.images, task_id, noises=noises, path_scales=ps)
+                    slot.graphs_e[key] = (g, out)
+                g, out = slot.graphs_e[key]
+                g.replay()
+                tok, cv = out
             tok = tok.clone()
-            return tok, (tok.new_zeros(()) if not model.training else cv)
+            return tok, (tok.new_zeros(()) if not model.training else cv.clone())
         # a new step begins with the first training forward after the parameters changed (an optimizer step), or after a
         # backward when this call cannot belong to the calls before it (other images, or a task that was already run): so
         # both the joint schedule (all forwards, one backward) and one task at a time (forward / backward per task on the

@@ -186,6 +186,12 @@ def test_fused_module_eval_and_no_grad_forward():
         tb, cb = b(img, task_id=1)
     assert a.fused_fallback_reason is None
     assert rel(ta, tb) < 1e-5 and float(ca) == 0.0 and float(cb) == 0.0          # eval: no noise, no balance loss
+    with torch.no_grad():                                                        # second and third use: captured, replayed
+        for _ in range(2):
+            img2 = torch.randn(2, 3, 32, 48).cuda()
+            t2, _ = a(img2, task_id=1)
+            assert rel(t2, b(img2, task_id=1)[0]) < 1e-5
+    assert a._fused.slots[0].graphs_e
     tc, _ = a(img, task_id=1)                                                    # eval with autograd on: per-op path
     assert a.fused_fallback_reason == "eval mode with autograd on" and rel(tc, tb) < 1e-5
     # a dropped forward (no backward) gives its slot back
