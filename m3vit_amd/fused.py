@@ -96,6 +96,7 @@ class FusedBackbone:
         self.backoff, self.prefetch_misses, self.prefetch_hits = 0, 0, 0
         self.backward_seen = False
         self.versions_changed = False
+        self.e_first, self.e_hist, self.e_pattern, self.e_spec, self.e_version, self.e_backoff = None, [], None, {}, 0, 0
 
     # a copy of the model (copy.deepcopy for an EMA twin, torch.save of the whole module) gets no executor state - contexts,
     # streams and graphs are rebuilt at its first call
@@ -178,10 +179,15 @@ class FusedBackbone:
         """another batch size (the short last batch of an epoch): its own contexts - activations are sized by the batch - on
         the SAME parameters, operand copies and gradient buffer; the contexts of the sizes seen before are kept (three sizes
         at most), so that going back to the usual size costs nothing"""
-        if any(s.busy for s in self.slots):
-            raise RuntimeError("fused backbone: batch size changed while a forward waits for its backward")
+        for slot, _, _ in self.e_spec.values():           # evaluation passes started ahead and never asked for
+            slot.busy = False
+        self.e_spec, self.e_hist, self.e_first = {}, [], None
         if self.spec:
             self._drop_prefetched()
+            import gc
+            gc.collect()                                  # (their autograd nodes hold the contexts until collected)
+        if any(s.busy for s in self.slots):
+            raise RuntimeError("fused backbone: batch size changed while a forward waits for its backward")
         self.slot_sets[self.batch] = self.slots
         slots = self.slot_sets.pop(B, None)
         if slots is None:
@@ -248,30 +254,7 @@ class FusedBackbone:
             self.base_eng.prepare_weights()
             self.dirty = False
         if not train:
-            # no autograd (evaluation, or a no_grad probe in training mode): a forward on a free context, on the caller's
-            # stream; replayed from a hipGraph of its own from the second use on (an evaluation loop is ~100 launches a call)
-            slot = self._slot()
-            key = (task_id, bool(model.training))
-            n = slot.calls_e.get(key, 0)
-            slot.calls_e[key] = n + 1
-            if not self.graph or n == 0:
-                tok, cv = self._forward_eager(slot, task_id, images.float().contiguous(), False)
-            else:
-                if slot.images is None:
-                    slot.images = torch.empty(images.shape, dtype=torch.float32, device=self.device)
-                slot.images.copy_(images)
-                noises, ps = self._draw(slot, slot.eng)
-                g = slot.graphs_e.get(key)
-                if g is None:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                        out = slot.eng.forward(slot.images, task_id, noises=noises, path_scales=ps)
-                    slot.graphs_e[key] = (g, out)
-                g, out = slot.graphs_e[key]
-                g.replay()
-                tok, cv = out
-            tok = tok.clone()
-            return tok, (tok.new_zeros(()) if not model.training else cv.clone())
+            return self._forward_nograd(images, task_id, model, main)
         # a new step begins with the first training forward after the parameters changed (an optimizer step), or after a
         # backward when this call cannot belong to the calls before it (other images, or a task that was already run): so
         # both the joint schedule (all forwards, one backward) and one task at a time (forward / backward per task on the
@@ -306,6 +289,77 @@ class FusedBackbone:
         main.wait_stream(slot.stream)
         tok.record_stream(main)
         cv.record_stream(main)
+        return tok, cv
+
+    # ------------------------------------------------------------------ forward without autograd (evaluation)
+    def _nograd_pass(self, slot, task_id, images, model):
+        """one forward on `slot`, on the current stream: eager at its first use, a hipGraph replay from then on (an evaluation
+        loop is ~100 launches a call)"""
+        key = (task_id, bool(model.training))
+        n = slot.calls_e.get(key, 0)
+        slot.calls_e[key] = n + 1
+        if not self.graph or n == 0:
+            tok, cv = self._forward_eager(slot, task_id, images.float().contiguous(), False)
+        else:
+            if slot.images is None:
+                slot.images = torch.empty(images.shape, dtype=torch.float32, device=self.device)
+            slot.images.copy_(images)
+            noises, ps = self._draw(slot, slot.eng)
+            if key not in slot.graphs_e:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    out = slot.eng.forward(slot.images, task_id, noises=noises, path_scales=ps)
+                slot.graphs_e[key] = (g, out)
+            g, (tok, cv) = slot.graphs_e[key]
+            g.replay()
+        return tok.clone(), (tok.new_zeros(()) if not model.training else cv.clone())
+
+    def _forward_nograd(self, images, task_id, model, main):
+        """Evaluation (model.eval() under torch.no_grad()) or a no_grad probe: every call runs on a free context's stream and
+        the caller's stream waits for it.  An evaluation loop calls the backbone once per task on the same batch
+        (models/models.py:299-320) just like training: when the previous batch saw tasks [t0, t1, ..] on one tensor, the first
+        call on a new batch starts the other tasks' passes as well (same rule, same fall-back as _prefetch)."""
+        first = self.e_first() if self.e_first is not None else None
+        if first is not images:                          # a new batch: what was called on the last one is the prediction
+            tasks = self.e_hist
+            self.e_pattern = tasks if (len(tasks) >= 2 and len(set(tasks)) == len(tasks)) else None
+            for slot, _, _ in self.e_spec.values():      # (passes nobody asked for)
+                slot.busy = False
+            if self.e_spec:
+                self.e_backoff = self.PREFETCH_BACKOFF
+            self.e_spec, self.e_hist, self.e_first = {}, [], weakref.ref(images)
+            if self.e_backoff > 0:
+                self.e_backoff -= 1
+            new_batch = True
+        else:
+            new_batch = False
+        self.e_hist.append(task_id)
+        hit = self.e_spec.pop(task_id, None) if images._version == self.e_version else None
+        if hit is None:
+            if self.e_spec:                              # the batch tensor was written to: started passes are stale
+                for slot, _, _ in self.e_spec.values():
+                    slot.busy = False
+                self.e_spec = {}
+
+            def start(t):
+                slot = self._slot()
+                slot.busy = True
+                slot.stream.wait_stream(main)
+                with torch.cuda.stream(slot.stream):
+                    tok, cv = self._nograd_pass(slot, t, images, model)
+                return slot, tok, cv
+            slot, tok, cv = start(task_id)
+            if new_batch and self.prefetch and self.e_backoff == 0 and self.e_pattern and self.e_pattern[0] == task_id:
+                self.e_version = images._version
+                for t in self.e_pattern[1:]:
+                    self.e_spec[t] = start(t)
+        else:
+            slot, tok, cv = hit
+            self.prefetch_hits += 1
+        main.wait_stream(slot.stream)
+        tok.record_stream(main)
+        cv.record_stream(main)
+        slot.busy = False
         return tok, cv
 
     def _launch(self, task_id, images, main):

@@ -204,6 +204,32 @@ def test_fused_module_eval_and_no_grad_forward():
     assert not a._fused.slots[0].busy
 
 
+def test_fused_module_evaluation_loop_overlaps_the_task_passes():
+    """model.eval() under no_grad, the backbone called once per task on every batch (a new tensor each time): from the second
+    batch on the other task's pass is started with the first call; same tokens as the per-op path, no context left busy;
+    a training step in between and a short last batch are taken in stride."""
+    _need_gpu()
+    a, cfg = _model(std=1.0, E=8)
+    b, _ = _model(std=1.0, E=8, fused=False)
+    a.eval(); b.eval()
+    g = torch.Generator().manual_seed(33)
+    with torch.no_grad():
+        for i, B in enumerate((4, 4, 4, 4, 2, 4)):
+            x = torch.randn(B, 3, 32, 48, generator=g).cuda()
+            for task in (0, 1):
+                ta, ca = a(x, task_id=task)
+                tb, _ = b(x, task_id=task)
+                assert a.fused_fallback_reason is None and rel(ta, tb) < 1e-5 and float(ca) == 0.0, (i, task)
+            del x
+    fb = a._fused
+    assert fb.prefetch_hits >= 3 and not any(s.busy for s in fb.slots) and not fb.e_spec
+    a.train()                                               # a training step on the same model afterwards
+    img = torch.randn(4, 3, 32, 48).cuda()
+    tok, cv = a(img, task_id=0)
+    (tok.sum() + cv).backward()
+    assert not any(s.busy for s in fb.slots)
+
+
 def test_fused_module_drop_path_matches_oracle():
     """stochastic depth on the fused node: the per-sample factors it drew (slot.path_scales) fed to the oracle"""
     _need_gpu()
