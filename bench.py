@@ -38,6 +38,24 @@ SHARED_WATCHDOG_S = 240       # the optional dp_shared_stem leg (the plain dp le
 _JSON_OUT = sys.stdout
 CV_WEIGHT = 0.01                           # --moe_noisy_gate_loss_weight default (train_fastmoe.py:118; applied at train/train_utils.py:277)
 
+# The workloads a line can be quoted on.  configs[1] is BASELINE.json's metric configuration (the default and the driver's line);
+# configs[3] / configs[4] are the ViT-Base configurations in their single-GPU form (all experts local):
+# the regime where the expert grouped GEMMs contract over K = 768 / 3072 and the MFMA roof, not operand delivery, is the bound.
+# They are timed in the default run as the sub-objects "configs3" / "configs4" (own roofline), or alone with --config 3 / 4.
+WORKLOADS = {
+    1: dict(name="configs[1]: ViT-Small/16 + MoE E=16 top-k=4 multi_gate, synthetic 224x224", batch=128,
+            cfg=dict(img_size=(224, 224), embed_dim=384, depth=12, num_heads=12, mlp_ratio=4.0, moe_mlp_ratio=1.0,
+                     moe_experts=16, moe_top_k=4, gate_dim=386, multi_gate=True)),
+    3: dict(name="configs[3], single-GPU form (all 64 experts local): ViT-Base/16 + MoE E=64 top-k=4, synthetic 224x224, one pass",
+            batch=128,
+            cfg=dict(img_size=(224, 224), embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0, moe_mlp_ratio=1.0,
+                     moe_experts=64, moe_top_k=4, gate_dim=768, multi_gate=False)),
+    4: dict(name="configs[4], single-GPU form: ViT-Base/16 + MoE E=16 top-k=4 moe_mlp_ratio=4, NYUD 2-task multi_gate, "
+                 "synthetic 480x640", batch=8,
+            cfg=dict(img_size=(480, 640), embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0, moe_mlp_ratio=4.0,
+                     moe_experts=16, moe_top_k=4, gate_dim=770, multi_gate=True)),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -45,7 +63,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)       # >= 10 warm-up + >= 50 timed steps
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", choices=["f16", "bf16", "f32"], default="f16")
-    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU and step (default: the workload's own - 128, 128, 8)")
+    ap.add_argument("--config", type=int, choices=sorted(WORKLOADS), default=1, help="which BASELINE.json configuration the line is "
+                    "quoted on: 1 = the metric's (default); 3 / 4 = the ViT-Base configurations, single-GPU form (N = 1 only)")
+    ap.add_argument("--no-vitb", action="store_true", help="N = 1, --config 1: skip the configs[3] / configs[4] sub-objects")
+    ap.add_argument("--no-skew", action="store_true", help="N = 1, --config 1: skip the skewed-routing sub-object \"skew\"")
     ap.add_argument("--checkpoint", action="store_true",
                     help="the reference's default memory mode: keep block inputs only, recompute each block in backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -84,6 +106,10 @@ def parse():
         ap.error("--checkpoint re-uses the activation buffers a wgrad stream may still read: pick one of the two")
     if a.ep and a.dp_only:
         ap.error("--ep and --dp-only exclude each other")
+    if a.config != 1 and a.gpus > 1:
+        ap.error("--config 3 / 4 are single-GPU forms (the multi-GPU legs are quoted on configs[1])")
+    if a.batch is None:
+        a.batch = WORKLOADS[a.config]["batch"]
     return a
 
 
@@ -146,7 +172,7 @@ def cpu_baseline(cfg_kwargs, batch, threads):
 
     def step():
         loss = 0.0
-        for task in range(cfg.num_tasks):
+        for task in (range(cfg.num_tasks) if (cfg.multi_gate or cfg.gate_task_specific_dim >= 0) else [None]):
             tok, cv, _ = R.backbone_forward(P, cfg, img, task)
             loss = loss + (tok * dtok).sum() + CV_WEIGHT * cv
         loss.backward()
@@ -201,7 +227,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from m3vit_amd import ops
-    from m3vit_amd.config import VIT_SMALL_MOE, BackboneConfig, init_params
+    from m3vit_amd.config import BackboneConfig, init_params
     from m3vit_amd.step import MultiTaskStep
 
     def barrier():
@@ -216,31 +242,37 @@ def main():
     # the library that really moves the bytes: backend "nccl" is RCCL on ROCm; gloo only in CPU-side rehearsals
     coll = {"nccl": "RCCL"}.get(backend, backend)
 
-    def run_mode(dtype_name, expert_parallel, want_roofline, share_stem=False):
+    def run_mode(dtype_name, expert_parallel, want_roofline, share_stem=False, workload=None, batch=None, skew=None, steps=None,
+                 warmup=None):
         """One timed configuration: W untimed warm-up steps, exactly K timed steps between barriers, max over ranks.
         Returns the fields of the JSON line that depend on the mode."""
-        cfg = BackboneConfig(**VIT_SMALL_MOE)
+        wl = WORKLOADS[args.config if workload is None else workload]
+        batch = (args.batch if workload is None else wl["batch"]) if batch is None else batch
+        skew = args.skew if skew is None else skew
+        steps = args.steps if steps is None else steps
+        warmup = args.warmup if warmup is None else warmup
+        cfg = BackboneConfig(**wl["cfg"])
         torch.cuda.reset_peak_memory_stats(dev)
         dtype = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[dtype_name]
         params = init_params(cfg, seed=1)                       # same weights on every rank
         # m3vit_amd/step.py: one engine context + HIP stream per task pass, hipGraph capture, and for N > 1 the
         # all-reduce of the upper blocks' gradients overlapped with the lower blocks' backward
-        runner = MultiTaskStep(cfg, params, batch=args.batch, dtype=dtype, device=str(dev), cv_weight=CV_WEIGHT,
+        runner = MultiTaskStep(cfg, params, batch=batch, dtype=dtype, device=str(dev), cv_weight=CV_WEIGHT,
                                parallel_tasks=not args.serial_tasks, graph=not args.no_graph, world=world, rank=rank,
                                expert_parallel=expert_parallel, wgrad_streams=args.wgrad_streams, dp_parts=args.dp_parts,
                                checkpoint=args.checkpoint, share_stem=share_stem,
                                ep_capacity=args.ep_capacity if expert_parallel else 0.0)
         use_ep, par_tasks, ntasks = runner.use_ep, runner.par or runner.par_ep, len(runner.tasks)
         g = torch.Generator().manual_seed(1000 + rank)          # each rank its own images
-        images = torch.randn(args.batch, 3, *cfg.img_size, generator=g).to(dev)
-        dtok = (torch.randn(args.batch, cfg.num_tokens, cfg.embed_dim, generator=g) * 0.05).to(dev)
+        images = torch.randn(batch, 3, *cfg.img_size, generator=g).to(dev)
+        dtok = (torch.randn(batch, cfg.num_tokens, cfg.embed_dim, generator=g) * 0.05).to(dev)
         noises = bias = None
         if args.noisy:          # SURVEY section 8(d): second run with std = 1 and a caller-supplied noise tensor (seed 2)
             cfg.vmoe_noisy_std = 1.0
             gn = torch.Generator().manual_seed(2)
-            noises = {t: {i: torch.randn(args.batch * cfg.num_tokens, cfg.moe_experts, generator=gn).to(dev)
+            noises = {t: {i: torch.randn(batch * cfg.num_tokens, cfg.moe_experts, generator=gn).to(dev)
                           for i in range(cfg.depth) if i % 2 == 1} for t in runner.tasks}
-        if args.skew:           # routing-skew variant: one expert receives ~4x the mean load
+        if skew:           # routing-skew variant: one expert receives ~4x the mean load
             b = torch.zeros(cfg.moe_experts); b[0] = 8.0
             bias = {i: b.to(dev) for i in range(cfg.depth) if i % 2 == 1}
         runner.bind(images, dtok, noises=noises, logit_bias=bias)     # inputs resident in HBM before anything is timed
@@ -257,27 +289,27 @@ def main():
         elif runner.want_graph:
             log(f"{tag}: graph capture unavailable ({runner.capture_error}); running eagerly")
         run = runner.step
-        for i in range(args.warmup):
+        for i in range(warmup):
             run()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             run()
         t_host = time.perf_counter() - t0
         barrier()
         dt = time.perf_counter() - t0
-        log(f"{tag}: host launch time {1e3 * t_host / args.steps:.2f} ms/step")
+        log(f"{tag}: host launch time {1e3 * t_host / steps:.2f} ms/step")
         if world > 1:
             t = torch.tensor([dt], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t)
-        ms_per_step = 1e3 * dt / args.steps
+        ms_per_step = 1e3 * dt / steps
         log(f"{tag}: timed region done: {ms_per_step:.2f} ms/step")
-        step_flops = 3.0 * cfg.fwd_flops_per_image() * args.batch * ntasks
+        step_flops = 3.0 * cfg.fwd_flops_per_image() * batch * ntasks
         if runner.share_stem:      # FLOPs actually executed: the stem (patch embedding + blocks below the first MoE block) once
-            step_flops -= 3.0 * cfg.stem_flops_per_image() * args.batch * (ntasks - 1)
-        res = {"value": round(world * args.batch * args.steps / dt, 2), "ms_per_step": round(ms_per_step, 3),
-               "model_tflops": round(step_flops * args.steps / dt / 1e12 * world, 2), "launch": runner.launch,
+            step_flops -= 3.0 * cfg.stem_flops_per_image() * batch * (ntasks - 1)
+        res = {"value": round(world * batch * steps / dt, 2), "ms_per_step": round(ms_per_step, 3),
+               "model_tflops": round(step_flops * steps / dt / 1e12 * world, 2), "launch": runner.launch,
                "task_streams": ntasks if par_tasks else 1,
                "wgrad_streams": sum(1 for e in runner.engs if e.wg_stream is not None),
                "capture_refused": runner.capture_refused,
@@ -289,12 +321,14 @@ def main():
                "parallelism": "single" if world == 1 else (f"dp{world}+ep{world} (experts sharded, {coll} all-to-all + all-reduce)"
                                                             if use_ep else f"dp{world} (replicated experts, {coll} all-reduce)")}
         if want_roofline:
-            res["roofline"] = roofline_of(ops, runner, dtype_name, step, serial_step, par_tasks, ntasks)
+            res["roofline"] = roofline_of(ops, runner, dtype_name, step, serial_step, par_tasks, ntasks,
+                                          replay_traffic=(wl is WORKLOADS[1] and batch == 128 and not skew and not args.noisy))
+        res["workload"], res["batch"], res["steps"], res["warmup"] = wl["name"], batch, steps, warmup
         del runner
         torch.cuda.empty_cache()
         return res
 
-    def roofline_of(ops, runner, dtype_name, step, serial_step, par_tasks, ntasks):
+    def roofline_of(ops, runner, dtype_name, step, serial_step, par_tasks, ntasks, replay_traffic=True):
         # ---- roofline of the dominant kernel (m3_gemm_nt: every Linear / FMoELinear forward + input-gradient GEMM;
         # two device kernels behind it, gemm_nt_dma_kernel for short K and gemm_nt_kernel), measured with HIP events
         # around each launch, on the launch stream, in a few extra instrumented steps.  Primary figures: the launches
@@ -326,7 +360,7 @@ def main():
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
                 with open(f) as fh:
                     pm = json.load(fh)
-                if pm.get("dtype") != dtype_name or args.batch != 128:
+                if pm.get("dtype") != dtype_name or not replay_traffic:
                     continue
                 where = f"profiles/{os.path.basename(f)} (rocprofv3 --pmc passes" + \
                         (f", taken at commit {pm['head']}" if pm.get("head") else "")
@@ -372,17 +406,17 @@ def main():
     #  N > 1: north_star's expert-parallel form (experts sharded E/N per rank, all-to-all over RCCL) is the primary
     #         when the experts divide over the ranks, and the replicated-experts data-parallel form (the reference's
     #         --moe_data_distributed mode) is timed as well: both appear as the sub-objects "ep" and "dp".
-    E = VIT_SMALL_MOE["moe_experts"]
+    E = WORKLOADS[args.config]["cfg"]["moe_experts"]
     extra = {}
 
     def emit(main_res, final=False):
         """rank 0 prints THE JSON line (once: at the end, or from the watchdog)"""
         out = {
-            "metric": METRIC,
+            "metric": METRIC if args.config == 1 else "images/sec fwd+bwd, " + WORKLOADS[args.config]["name"],
             "value": main_res["value"], "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "configs[1]: ViT-Small/16 + MoE E=16 top-k=4 multi_gate, synthetic 224x224",
+            "config": {"workload": WORKLOADS[args.config]["name"],
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "task_passes": main_res["task_passes"],
                        "tokens_per_image": main_res["tokens_per_image"], "cv_loss_weight": CV_WEIGHT,
                        "launch": main_res["launch"],
@@ -405,10 +439,11 @@ def main():
             except AttributeError:
                 cores = os.cpu_count() or 1
             cores = max(1, min(cores, 16))          # the GPU box gives one GPU a 16-core share
-            v, n = cpu_baseline(VIT_SMALL_MOE, args.cpu_batch, cores)
+            cpu_b = min(args.cpu_batch, args.batch) if args.config != 4 else 1
+            v, n = cpu_baseline(WORKLOADS[args.config]["cfg"], cpu_b, cores)
             out["cpu_baseline"] = {"value": round(v, 3), "unit": "images/s", "cores": cores, "kind": "port",
-                                   "sample": f"{n} full steps (2 task passes fwd+bwd, fp32 torch CPU oracle) at batch "
-                                             f"{args.cpu_batch}, scaled per image"}
+                                   "sample": f"{n} full steps ({main_res['task_passes']} task pass(es) fwd+bwd, fp32 torch CPU oracle) at "
+                                             f"batch {cpu_b}, scaled per image"}
         if rank == 0:
             print(json.dumps(out), file=_JSON_OUT, flush=True)
 
@@ -450,7 +485,7 @@ def main():
     main_res = None
     if world == 1 and args.module_path:
         mp = module_leg(args.dtype)
-        cfg0 = BackboneConfig(**VIT_SMALL_MOE)
+        cfg0 = BackboneConfig(**WORKLOADS[1]["cfg"])
         main_res = {"value": mp["value"], "ms_per_step": mp["ms_per_step"], "model_tflops": mp["model_tflops"],
                     "launch": mp["path"], "task_streams": cfg0.num_tasks, "wgrad_streams": 0, "capture_refused": None,
                     "task_passes": cfg0.num_tasks, "tokens_per_image": cfg0.num_tokens, "activation_checkpointing": False,
@@ -464,7 +499,8 @@ def main():
         # tests/test_engine.py::test_shared_stem_step_matches_per_task_stems) - 23 instead of 24 block passes.  That step is
         # timed too and reported BESIDE the headline as "shared_stem" (or as the headline with --share-stem, then with the
         # reference's schedule beside it as "per_task_stems").
-        can_share = not args.serial_tasks and not args.no_share_stem
+        base1 = args.config == 1          # shared stem, fp32, module path and the sub-objects below belong to the metric's configuration
+        can_share = not args.serial_tasks and not args.no_share_stem and base1
         share = bool(args.share_stem) and can_share
         main_res = run_mode(args.dtype, False, True, share_stem=share)
         if can_share:
@@ -477,12 +513,33 @@ def main():
                                          "patch embedding + block 0 computed once per step for both task passes, their backward once on "
                                          "the summed d x: same gradients, 23 instead of 24 block passes (model_tflops counts the FLOPs "
                                          "executed)")}
-        if args.dtype == "f16" and not args.no_f32:
+        if args.dtype == "f16" and not args.no_f32 and base1:
             f32 = attempt("f32", lambda: run_mode("f32", False, True, share_stem=share))
             if f32 is not None:
                 extra["f32"] = {k: f32[k] for k in ("value", "ms_per_step", "model_tflops", "launch", "roofline")}
                 extra["f32"]["dtype"] = "f32"
-        if not args.no_module_path and not args.serial_tasks and not args.checkpoint and not (args.noisy or args.skew):
+        plain = base1 and not args.serial_tasks and not args.checkpoint and not (args.noisy or args.skew) and not args.no_graph
+        sub_steps, sub_warm = min(args.steps, 20), min(args.warmup, 5)
+        if plain and not args.no_skew and args.batch == WORKLOADS[1]["batch"]:
+            # routing-skew variant beside the headline: +8 on expert 0's gate logit puts it into EVERY token's top-k
+            # (4x the mean load) - what the device-side load balancing of the grouped weight gradients and the tile prefix of the
+            # grouped GEMMs are for; same work, same FLOPs, only the distribution over the experts changes
+            sk = attempt("skew", lambda: run_mode(args.dtype, False, False, share_stem=share, skew=True, steps=sub_steps, warmup=sub_warm))
+            if sk is not None:
+                extra["skew"] = {"value": sk["value"], "ms_per_step": sk["ms_per_step"], "steps": sk["steps"], "warmup": sk["warmup"],
+                                 "ratio_to_value": round(sk["value"] / main_res["value"], 4),
+                                 "routing": "expert 0 in every token's top-k (4x the mean load), the other three picks as routed"}
+        if plain and not args.no_vitb and args.dtype in ("f16", "bf16"):
+            # the ViT-Base configurations, single-GPU form: the expert grouped GEMMs contract over K = 768 / 3072 there
+            for w in (3, 4):
+                vb = attempt(f"configs{w}", lambda w=w: run_mode(args.dtype, False, True, workload=w, skew=False, steps=sub_steps,
+                                                                  warmup=sub_warm))
+                if vb is not None:
+                    extra[f"configs{w}"] = {k: vb[k] for k in ("workload", "batch", "value", "ms_per_step", "model_tflops", "launch",
+                                                               "task_passes", "tokens_per_image", "steps", "warmup",
+                                                               "peak_hbm_gib", "roofline")}
+                    extra[f"configs{w}"]["unit"] = "images/s"
+        if not args.no_module_path and plain:
             # The number above is the executor driven directly (m3vit_amd.step.MultiTaskStep).  What a maintainer who drops
             # the library in calls is the MODULE API - install_fmoe_shim() + VisionTransformerMoE.forward(x, task_id) per task +
             # one loss.backward() (models/models.py:299-320, train/train_utils.py:423-457): timed here on the same

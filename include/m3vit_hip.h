@@ -221,6 +221,12 @@ int m3_gemm_nt(const m3_gemm_args *args, void *stream);
  * call: measured faster inside the training step); -1 re-reads M3_GEMM_WS from the environment.  Results are the same
  * up to fp32 summation order either way. */
 int m3_gemm_set_variant(int ws_mask);
+/* Tuning knob, no reference counterpart: which calls of m3_gemm_nt take the 256 x 256-tile kernel for long contractions
+ * (16-bit operands, K * 2 bytes a multiple of 128 and >= 1024, at most 64 groups; csrc/gemm_big.hip - the ViT-Base shapes
+ * of BASELINE configs[3] / configs[4]).  0 never, 1 every call the kernel can run, 2 (default) those that also have enough
+ * tiles to fill the chip about twice; -1 re-reads M3_GEMM_BIG from the environment.  Results are the same up to fp32
+ * summation order either way. */
+int m3_gemm_set_big(int mode);
 
 /* Fused FFN forward (fp16 activations):
  *   Y[crow(m), :] = (residual[crow(m), :] +) GELU(X[arow(m), :] W1[g]^T + b1[g]) W2[g]^T + b2[g]

@@ -19,7 +19,7 @@
 //     never stored;
 //   - tile ids are remapped so that the n-tiles of one m-tile run on the same XCD (A rows
 //     come from HBM once, then from that XCD's L2).
-#include "common.h"
+#include "gemm_dev.h"
 #include <type_traits>
 
 namespace m3 {
@@ -37,64 +37,6 @@ __device__ unsigned long long g_gemm_stamps[STAMP_WGS][STAMP_N];
 #else
 #define M3_STAMP(i) do { } while (0)
 #endif
-
-constexpr int BM = 128, BN = 128, ROWB = 128;  // ROWB: bytes of K per row per step
-constexpr int GEMM_THREADS = 256;
-
-struct GemmDev {
-  const char *A; int64_t lda_b;                 // byte strides
-  const int32_t *a_row_idx; int32_t a_row_div; int32_t a_row_sh;   // a_row_sh: log2(a_row_div) if a power of two, else -1
-  const char *B; int64_t ldb_b; int64_t b_group_b;
-  char *C; int64_t ldc; int32_t c_f32;
-  const int32_t *c_row_idx;
-  const float *bias;
-  char *pre_out; int64_t ld_pre;
-  const char *gpre; int64_t ld_gpre;
-  const float *residual; int64_t ld_res;
-  const float *row_scale; int32_t row_scale_div;   // value *= row_scale[srow / div] in front of the residual add,
-  const int32_t *row_scale_idx;                    // srow = row_scale_idx ? row_scale_idx[m] : crow
-  int32_t act;
-  int64_t M; int32_t N; int32_t K;
-  int32_t G;
-  const int32_t *group_offsets;
-  const int32_t *tile_starts;
-  int32_t n_tiles;
-  int32_t m_tiles_max;
-  int32_t vec8;                                 // N and all leading dims multiples of 8: staged epilogue
-};
-
-// Grouped call: which (group, first row, end row) owns row tile mt, and how many workgroups are live.  G <= 64: ONE
-// vector load of the tile prefix (lane l holds tile_starts[l + 1]) + a ballot instead of a chain of up to G dependent
-// scalar loads in front of every tile (the expert GEMMs run ~800 row tiles x 3 column tiles per launch).
-struct TileOwner { int g; int64_t m_begin, m_end; };
-__device__ __forceinline__ int grouped_live_tiles(const int32_t *tile_starts, int G, int lane, int &ts_lane) {
-  if (G <= 64) {
-    ts_lane = lane < G ? tile_starts[lane + 1] : 0x7fffffff;
-    return __builtin_amdgcn_readfirstlane(__shfl(ts_lane, G - 1, 64));
-  }
-  ts_lane = 0;
-  return tile_starts[G];
-}
-__device__ __forceinline__ TileOwner grouped_tile_owner(const int32_t *tile_starts, const int32_t *group_offsets, int G,
-                                                        int mt, int lane, int ts_lane) {
-  TileOwner o;
-  int g = 0, t0;
-  if (G <= 64) {
-    // groups whose END prefix is <= mt lie wholly before the tile (the prefix is monotone; the last group never counts)
-    g = __popcll(__ballot(lane < G - 1 && ts_lane <= mt));
-    t0 = g ? __shfl(ts_lane, g - 1, 64) : 0;
-  } else {
-    while (g + 1 < G && tile_starts[g + 1] <= mt) ++g;
-    t0 = tile_starts[g];
-  }
-  // (everything here is wave-uniform: say so, or the compiler carries the tile bounds in vector registers)
-  g = __builtin_amdgcn_readfirstlane(g);
-  t0 = __builtin_amdgcn_readfirstlane(t0);
-  o.g = g;
-  o.m_begin = (int64_t)__builtin_amdgcn_readfirstlane(group_offsets[g]) + (int64_t)(mt - t0) * 128;
-  o.m_end = __builtin_amdgcn_readfirstlane(group_offsets[g + 1]);
-  return o;
-}
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4);
@@ -374,7 +316,6 @@ constexpr int DMA_RB = 128;                // bytes of a row slice = one cache l
 constexpr int DMA_LDS = 2 * BM * DMA_RB;   // A + B image: 32 KiB
 constexpr int DMA_LDS_ALL = DMA_LDS + BM * 4;   // + the tile's 128 per-row epilogue factors (row_scale)
 
-__device__ __forceinline__ int dma_swz(int row) { return (row >> 1) & 7; }
 
 // EPI: the epilogue's kind as a template constant.  DMA_EPI_ANY keeps every option behind run-time flags: each
 // `if (p.gpre)` / `if (p.residual)` / `if (m >= m_end) break` is then a basic-block boundary, the loads of a store pass are
@@ -389,7 +330,7 @@ __device__ __forceinline__ int dma_swz(int row) { return (row >> 1) & 7; }
 //   GELU   pre_out = acc + bias ; C = GELU(pre_out)                fc1 / expert FC1 forward
 //   GPRE   C = acc * GELU'(gpre)                                   fc2 / expert FC2 input gradient
 //   RES    C(fp32) = acc (+ bias) + residual                       proj, fc2 forward
-enum { DMA_EPI_ANY = 0, DMA_EPI_GPRE = 1, DMA_EPI_RES = 2, DMA_EPI_PLAIN = 3, DMA_EPI_GELU = 4 };
+// (the kinds' enum: gemm_dev.h)
 
 template <typename T, int EPI = DMA_EPI_ANY>
 __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const GemmDev p) {
@@ -1044,6 +985,13 @@ extern "C" int m3_gemm_set_variant(int ws_mask) {
   return M3_OK;
 }
 
+static int g_big_mode = -1;
+extern "C" int m3_gemm_set_big(int mode) {
+  M3_REQUIRE(mode >= -1 && mode <= 2, "m3_gemm_set_big: mode %d out of range", mode);
+  g_big_mode = mode;
+  return M3_OK;
+}
+
 extern "C" int m3_gemm_nt(const m3_gemm_args *a, void *stream) {
   M3_REQUIRE(a && a->A && a->B && a->C, "m3_gemm_nt: null operand");
   M3_REQUIRE(dtype_ok(a->dtype), "m3_gemm_nt: bad dtype %d", a->dtype);
@@ -1128,23 +1076,27 @@ extern "C" int m3_gemm_nt(const m3_gemm_args *a, void *stream) {
     else if (epi == WS_EPI_RES) hipLaunchKernelGGL(gemm_nt_ws_kernel<WS_EPI_RES>, wg, wb, WS_LDS, s, d);
     if (epi >= 0) return check_launch("m3_gemm_nt");
   }
+  // epilogue kinds (16-bit dtypes; anything else takes the generic epilogue)
+  int epi = DMA_EPI_ANY;
+  static int epi_mode = -1;                    // M3_GEMM_EPI=0: generic epilogue everywhere (diagnostics)
+  if (epi_mode < 0) { const char *e = getenv("M3_GEMM_EPI"); epi_mode = e ? atoi(e) : 1; }
+  if (epi_mode && es == 2) {
+    const bool none = a->act == M3_ACT_NONE && !a->pre_out;
+    if (none && a->gelu_grad_pre && !a->residual && !d.c_f32 && !a->bias) epi = DMA_EPI_GPRE;
+    else if (none && a->residual && !a->gelu_grad_pre && d.c_f32) epi = DMA_EPI_RES;
+    else if (none && !a->gelu_grad_pre && !a->residual && !d.c_f32) epi = DMA_EPI_PLAIN;
+    else if (a->act == M3_ACT_GELU && a->pre_out && !a->gelu_grad_pre && !a->residual && !d.c_f32) epi = DMA_EPI_GELU;
+  }
+  // long contractions (the ViT-Base shapes): 256 x 256 tiles, gemm_big.hip.  m3_gemm_set_big / M3_GEMM_BIG: 0 never,
+  // 1 whenever the kernel can run the shape, 2 (default) when the shape also has enough tiles to fill the chip twice
+  if (g_big_mode < 0) { const char *e = getenv("M3_GEMM_BIG"); g_big_mode = e ? atoi(e) : 2; }
+  if (g_big_mode && gemm_big_eligible(d, es, g_big_mode == 1)) return launch_gemm_big(d, a->dtype, epi, s);
   // variant: fp16 -> LDS-DMA kernel, fp32 (MFMA-bound, measured 2 % slower there) and odd shapes ->
   // register-staged kernel; M3_GEMM_DMA=1/0 forces one or the other (diagnostics)
   static int dma_mode = -1;
   if (dma_mode < 0) { const char *e = getenv("M3_GEMM_DMA"); dma_mode = e ? (atoi(e) ? 1 : 0) : 2; }
   const bool dma_ok = d.vec8 && (a->K * es) % DMA_RB == 0;
   if (dma_ok && (dma_mode == 1 || (dma_mode == 2 && es == 2))) {
-    // epilogue kinds (16-bit dtypes; anything else takes the generic epilogue)
-    int epi = DMA_EPI_ANY;
-    static int epi_mode = -1;                    // M3_GEMM_EPI=0: generic epilogue everywhere (diagnostics)
-    if (epi_mode < 0) { const char *e = getenv("M3_GEMM_EPI"); epi_mode = e ? atoi(e) : 1; }
-    if (epi_mode && es == 2) {
-      const bool none = a->act == M3_ACT_NONE && !a->pre_out;
-      if (none && a->gelu_grad_pre && !a->residual && !d.c_f32 && !a->bias) epi = DMA_EPI_GPRE;
-      else if (none && a->residual && !a->gelu_grad_pre && d.c_f32) epi = DMA_EPI_RES;
-      else if (none && !a->gelu_grad_pre && !a->residual && !d.c_f32) epi = DMA_EPI_PLAIN;
-      else if (a->act == M3_ACT_GELU && a->pre_out && !a->gelu_grad_pre && !a->residual && !d.c_f32) epi = DMA_EPI_GELU;
-    }
 #define M3_DMA_GO(TT)                                                                                                  \
     do {                                                                                                               \
       if (epi == DMA_EPI_GPRE) hipLaunchKernelGGL((gemm_nt_dma_kernel<TT, DMA_EPI_GPRE>), grid, block, DMA_LDS_ALL, s, d);  \

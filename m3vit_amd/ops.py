@@ -293,6 +293,12 @@ def gemm_set_variant(ws_mask: int):
     check(lib().m3_gemm_set_variant(int(ws_mask)), "m3_gemm_set_variant")
 
 
+def gemm_set_big(mode: int):
+    """which gemm_nt calls take the 256 x 256-tile kernel for long contractions (include/m3vit_hip.h: m3_gemm_set_big):
+    0 never, 1 every call it can run, 2 (default) those with enough tiles to fill the chip, -1 re-read M3_GEMM_BIG"""
+    check(lib().m3_gemm_set_big(int(mode)), "m3_gemm_set_big")
+
+
 def ffn_supported(D: int, H: int, dtype: torch.dtype, G: int = 1) -> bool:
     """shapes the fused FFN kernels take (anything else runs the unfused m3_gemm_nt pair)"""
     return dtype == torch.float16 and D in (384, 768) and H % 64 == 0 and 64 <= H <= 8192 and G <= 64 and \
