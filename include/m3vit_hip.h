@@ -301,6 +301,13 @@ typedef struct {
   const m3_wgrad_reduce_desc *prev; /* optional (host pointer, read during the call): the PREVIOUS call's slab reduction, whose
                                       slabs must live in another buffer than `ws`; its blocks run first in this launch.  The
                                       caller reduces the last call of a sequence itself (m3_wgrad_reduce*). */
+  float *direct_dW;                /* optional: DIRECT mode (needs splits == 1, chunk_rows == 0, bias_ws NULL): every (group, tile)
+                                      then belongs to exactly one workgroup, which adds its result into dW [G][N][K] itself
+                                      (direct_beta 1: dW += result, 0: dW = result) - no slabs (ws may be NULL), no reduction
+                                      call.  For weights whose gradient is large against the rows contracted (the ViT-Base
+                                      experts: 151 MB per layer), where slabs + reduction move four times the result. */
+  float *direct_db;                /* direct mode, optional: the bias gradient [G][N] (column sums of dC) likewise */
+  int32_t direct_beta, direct_beta_db;
 } m3_wgrad_args;
 int m3_wgrad_tn(const m3_wgrad_args *args, void *stream);
 /* The output tile (n x k) m3_wgrad_tn uses for a shape - 128 x 128, or, with the wide tiles switched on, for fp16
@@ -311,6 +318,11 @@ int m3_wgrad_tn(const m3_wgrad_args *args, void *stream);
  * (default: measured no faster inside the training step), -1 = re-read M3_WGRAD_WIDE from the environment.  Switch it
  * before sizing any workspace. */
 int m3_wgrad_set_wide(int on);
+/* Tuning knob, no reference counterpart: 1 (default) = 16-bit weight-gradient launches without a per-row factor take the
+ * LDS-DMA kernel (wgrad_dma_kernel, csrc/wgrad.hip: four workgroups per CU, operands global -> LDS directly), 0 = the
+ * register-staged kernel everywhere, -1 = re-read M3_WGRAD_DMA from the environment.  Same results up to fp32 summation
+ * order (64 instead of 32 contraction rows per accumulation step). */
+int m3_wgrad_set_dma(int on);
 int m3_wgrad_tile(int N, int K, int dtype, int *tn, int *tk);
 /* balanced mode: dW[g] (+)= sum over group g's units of ws[u] (elems = N*K per group), unit order; optionally the
  * same for the bias slabs (bias_elems = N per group) */

@@ -64,6 +64,7 @@ class WgradArgs(Structure):
         ("chunk_rows", c_int32), ("units", c_int32),
         ("c_row_div", c_int32), ("c_row_scale", c_void_p),
         ("prev", POINTER(WgradReduceDesc)),
+        ("direct_dW", c_void_p), ("direct_db", c_void_p), ("direct_beta", c_int32), ("direct_beta_db", c_int32),
     ]
 
 
@@ -141,6 +142,7 @@ SIGNATURES = {
     "m3_wgrad_tn": (c_int, [POINTER(WgradArgs), _V]),
     "m3_wgrad_tile": (c_int, [_I, _I, _I, POINTER(c_int), POINTER(c_int)]),
     "m3_wgrad_set_wide": (c_int, [_I]),
+    "m3_wgrad_set_dma": (c_int, [_I]),
     "m3_wgrad_reduce": (c_int, [_V, _I, _L, _V, _I, _V, _L, _V, _I, _V]),
     "m3_wgrad_reduce_grouped": (c_int, [_V, _V, _I, _I, _L, _V, _I, _V, _L, _V, _I, _V]),
     "m3_wgrad_bias_reduce": (c_int, [_V, _I, _L, _V, _I, _V]),

@@ -15,6 +15,9 @@ Formats (reference file:line):
     a single `mlp.gate.w_gate` is copied to every `mlp.gate.{t}.w_gate` of a multi-gate model; for task-one-hot /
     task-conditioned gates zero rows are appended to w_gate for the extra gate-input dimensions.
   * position-embedding resize for a different token grid (utils/common_config.py:71-92).
+  * DeiT dense-MLP -> experts upcycling and the virtual-group gate initialisation of the pretrained-weight loader
+    (utils/helpers.py:481-713, :714-867): `upcycle_dense_mlp_to_experts`, `auto_virtual_group_size`,
+    `virtual_group_gate_init` (pinned to the reference functions' outputs by tests/golden/g11_upcycling.npz).
 """
 from collections import OrderedDict
 import os
@@ -229,3 +232,117 @@ def to_backbone_state(checkpoint, rank: int = 0, world_size: int = 1, expected_g
                 raise ValueError(f"{d0} global experts do not divide over {world_size} ranks")
             state = shard_experts(state, rank, d0 // world_size)
     return state, fmt
+
+
+# ------------------------------------------------------------- dense checkpoint -> experts (upcycling)
+def upcycle_dense_mlp_to_experts(state, moe_blocks, num_local_experts: int, expert_hidden: Optional[int] = None, *,
+                                 total_experts: Optional[int] = None, top_k: int = 4, moe_mlp_ratio: float = 1.0,
+                                 use_weight_scaling: bool = False, mode: str = "deit_upcycling"):
+    """Fill `blocks.{i}.mlp.experts.{htoh4,h4toh}.{weight,bias}` of every block in `moe_blocks` from that block's dense
+    `mlp.fc1 / fc2` tensors (a DeiT checkpoint), in place, the way the reference's pretrained-weight loader does
+    (utils/helpers.py:481-713 `_inject_moe_expert_from_deit_mlp`; tensor layout :579-662):
+
+      * split upcycling (moe_mlp_ratio == 1, or mode == "deit_warm_start"): the dense hidden dimension is cut into
+        G = dense_hidden / expert_hidden chunks (G = 4 when expert_hidden is unknown) - fc1 rows, fc1 bias, fc2 columns -
+        giving a template group of G experts; fc2's bias is repeated whole.  With `use_weight_scaling` fc1.weight, fc1.bias
+        and fc2.weight (NOT fc2.bias) are multiplied by sqrt((total_experts / G) * G^2 / top_k) first (:617-634, the GELU
+        form).  `num_local_experts` a multiple of G: the template is repeated; otherwise the first `num_local_experts`
+        template experts are taken (:655-670).  total_experts must be a multiple of G; deit_warm_start insists on G == 4.
+      * otherwise (moe_mlp_ratio == 4): fc1 / fc2 are copied to every local expert (:672-681).
+    Blocks without dense MLP keys are skipped (:528-535).  The dense keys stay in the dict, as in the reference (the model's
+    non-strict load ignores them).  Returns `state`."""
+    mode = str(mode).lower()
+    if mode not in ("deit_upcycling", "deit_warm_start"):
+        raise ValueError(f"upcycling mode '{mode}': expected deit_upcycling or deit_warm_start")
+    forced = mode == "deit_warm_start"
+    E = int(num_local_experts)
+    tot = int(total_experts) if total_experts else E
+    for i in moe_blocks:
+        kf1w, kf1b, kf2w, kf2b = (f"blocks.{i}.mlp.{n}" for n in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"))
+        if kf1w not in state or kf2w not in state:
+            continue
+        f1w, f1b, f2w, f2b = state[kf1w], state[kf1b], state[kf2w], state[kf2b]
+        if forced or float(moe_mlp_ratio) == 1.0:
+            hidden = f1w.shape[0]
+            G = hidden // int(expert_hidden) if expert_hidden else 4
+            if G <= 0 or hidden % G != 0:
+                raise ValueError(f"block {i}: granularity {G} does not divide the dense hidden dimension {hidden}")
+            if tot % G != 0:
+                raise ValueError(f"block {i}: total_experts = {tot} must be a multiple of the granularity {G}")
+            if forced and G != 4:
+                raise ValueError(f"deit_warm_start needs dense_hidden / expert_hidden == 4, got {G}")
+            scale = ((tot // G) * G * G / float(max(int(top_k), 1))) ** 0.5 if use_weight_scaling else 1.0
+            t1w = torch.stack((f1w * scale).chunk(G, dim=0), dim=0)            # [G, hidden / G, D]
+            t1b = torch.stack((f1b * scale).chunk(G, dim=0), dim=0)            # [G, hidden / G]
+            t2w = torch.stack((f2w * scale).chunk(G, dim=1), dim=0)            # [G, D, hidden / G]
+            if E % G == 0:
+                r = E // G
+                e1w, e1b, e2w = t1w.repeat(r, 1, 1), t1b.repeat(r, 1), t2w.repeat(r, 1, 1)
+            else:
+                e1w, e1b, e2w = t1w[:E], t1b[:E], t2w[:E]
+            e2b = f2b.unsqueeze(0).repeat(E, 1)
+        else:
+            e1w, e1b = f1w.unsqueeze(0).repeat(E, 1, 1), f1b.unsqueeze(0).repeat(E, 1)
+            e2w, e2b = f2w.unsqueeze(0).repeat(E, 1, 1), f2b.unsqueeze(0).repeat(E, 1)
+        state[f"blocks.{i}.mlp.experts.htoh4.weight"] = e1w.contiguous()
+        state[f"blocks.{i}.mlp.experts.htoh4.bias"] = e1b.contiguous()
+        state[f"blocks.{i}.mlp.experts.h4toh.weight"] = e2w.contiguous()
+        state[f"blocks.{i}.mlp.experts.h4toh.bias"] = e2b.contiguous()
+    return state
+
+
+def auto_virtual_group_size(tot_experts, *, local_experts=None, world_size=None, dense_hidden=None, expert_hidden=None) -> int:
+    """How many experts form one virtual group of the gate initialisation (utils/helpers.py:714-753): the upcycling
+    granularity dense_hidden / expert_hidden when that divides, else the local expert count, else tot / world_size, else 1;
+    then reduced to a common divisor of the local and the total expert count."""
+    import math
+    tot = int(tot_experts)
+    if tot <= 0:
+        return 1
+    g = None
+    if dense_hidden is not None and expert_hidden is not None and expert_hidden > 0 and dense_hidden % expert_hidden == 0:
+        g = int(dense_hidden // expert_hidden)
+    if g is None or g <= 0:
+        if local_experts is not None and int(local_experts) > 0:
+            g = int(local_experts)
+        elif world_size is not None and int(world_size) > 0 and tot % int(world_size) == 0:
+            g = tot // int(world_size)
+        else:
+            g = 1
+    if local_experts is not None and int(local_experts) > 0:
+        g = math.gcd(g, int(local_experts))
+    g = math.gcd(g, tot)
+    return g if (g > 0 and tot % g == 0) else 1
+
+
+_GATE_KEY = re.compile(r"^blocks\.(\d+)\.(?:mlp\.)?(?:gate(?:\.\d+)?|shared_gate)\.w_gate$")
+
+
+def virtual_group_gate_init(state, gate_shapes, *, local_experts=None, world_size: int = 1, expert_hidden=None,
+                            std: float = 0.02, generator: Optional[torch.Generator] = None):
+    """Virtual-group initialisation of every gate matrix (utils/helpers.py:756-867, used with deit_upcycling when
+    `use_virtual_group_initialization` is set, :453-458): w_gate [d_gate, E_tot] ~ N(0, std), then the first group of
+    `auto_virtual_group_size` expert columns is repeated over all groups - experts that start as copies of the same dense
+    MLP chunk start with the same routing logits.  `gate_shapes`: ordered {key: (d_gate, E_tot)} (or tensors) of the MODEL's
+    gate parameters, in state_dict order - the normal draws are consumed key by key, so the same seed gives the reference's
+    tensors; `local_experts` / `expert_hidden`: ints, or {block index: int}.  Writes `state[key]`, returns `state`."""
+    def per_block(v, b):
+        return v.get(b) if isinstance(v, dict) else v
+    keys = [k for k in gate_shapes if _GATE_KEY.search(k)]
+    if not keys:
+        raise KeyError("no gate w_gate keys (blocks.{i}[.mlp].gate[.{t}].w_gate / blocks.{i}.shared_gate.w_gate) given")
+    for k in keys:
+        shp = gate_shapes[k]
+        d_gate, tot = (int(shp.shape[0]), int(shp.shape[1])) if torch.is_tensor(shp) else (int(shp[0]), int(shp[1]))
+        b = int(_GATE_KEY.search(k).group(1))
+        kf1 = f"blocks.{b}.mlp.fc1.weight"
+        dense_hidden = int(state[kf1].shape[0]) if kf1 in state else None
+        ws = max(1, int(world_size or 1))
+        G = auto_virtual_group_size(tot, local_experts=per_block(local_experts, b), world_size=ws, dense_hidden=dense_hidden,
+                                    expert_hidden=per_block(expert_hidden, b))
+        w = torch.empty(d_gate, tot)
+        torch.nn.init.normal_(w, mean=0.0, std=std, generator=generator)
+        if G > 1:
+            w = torch.cat([w[:, :G]] * (tot // G), dim=1).contiguous()
+        state[k] = w
+    return state

@@ -18,6 +18,7 @@
 // each split writes an fp32 slab, m3_wgrad_reduce adds the slabs in a fixed order
 // (deterministic, unlike atomics).
 #include "common.h"
+#include <type_traits>
 
 namespace m3 {
 
@@ -45,7 +46,45 @@ struct WgradDev {
   const int32_t *rd_off; int32_t rd_G, rd_chunk;
   float *rd_dW; int32_t rd_beta;
   const float *rd_bws; int64_t rd_b4; float *rd_db; int32_t rd_beta_db;
+  // direct mode (splits == 1, no balanced units: every (group, tile) belongs to exactly ONE workgroup): the result tiles are
+  // added into dW [G][N][K] (the column sums into db [G][N]) by the kernel itself - no slabs, no reduction
+  float *direct_dW; float *direct_db; int32_t direct_beta, direct_beta_db;
 };
+
+// the result of a workgroup: one 128 x 128 fp32 tile (lane holds k = kb + 4 lg + r, n = nb + li) to its slab, or - direct
+// mode - read-add-written into dW
+__device__ __forceinline__ void wgrad_store_tile(const WgradDev &p, const f32x4 (&acc)[4][4], int64_t slab_id, int g, int n0, int k0,
+                                                 int wr, int wc, int li, int lg) {
+  float *out = p.direct_dW ? p.direct_dW + (int64_t)g * p.N * p.K : p.ws + slab_id * (int64_t)p.N * p.K;
+  const bool add = p.direct_dW && p.direct_beta;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int n = n0 + wc * 64 + ni * 16 + li;
+    if (n >= p.N) continue;
+    f32x4 old[4];
+    if (add) {
+#pragma unroll
+      for (int ki = 0; ki < 4; ++ki) {
+        const int k = k0 + wr * 64 + ki * 16 + 4 * lg;
+        old[ki] = k < p.K ? *(const f32x4 *)(out + (int64_t)n * p.K + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int ki = 0; ki < 4; ++ki) {
+      const int k = k0 + wr * 64 + ki * 16 + 4 * lg;
+      if (k >= p.K) continue;
+      *(f32x4 *)(out + (int64_t)n * p.K + k) = add ? acc[ki][ni] + old[ki] : acc[ki][ni];
+    }
+  }
+}
+__device__ __forceinline__ void wgrad_store_bias(const WgradDev &p, float v, int64_t slab_id, int g, int n) {
+  if (p.direct_db) {
+    float *d = p.direct_db + (int64_t)g * p.N + n;
+    *d = p.direct_beta_db ? *d + v : v;
+  } else {
+    p.bias_ws[slab_id * p.N + n] = v;
+  }
+}
 
 // balanced grouped mode: units are dealt to the groups in order, n_g = ceil(rows_g / chunk) each, a group's rows
 // divided evenly over its units (a hot expert gets proportionally more units; the slab of unit u is ws[u]).
@@ -293,7 +332,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
   };
   // Bias gradient fused as one extra MFMA row: with an all-ones A operand the product is the column
   // sum of dC over the contraction rows.  Done once per n-tile (k-tile 0, waves wr == 0).
-  const bool do_bias = p.bias_ws && tk == 0 && wr == 0;
+  const bool do_bias = (p.bias_ws || p.direct_db) && tk == 0 && wr == 0;
   f32x4 acc_b[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc_b[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -374,26 +413,226 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
   }
 
   if (do_bias && lg == 0) {                       // every row of the ones-product is the column sum: take row 0
-    float *bs = p.bias_ws + slab_id * p.N;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int n = n0 + wc * 64 + ni * 16 + li;
-      if (n < p.N) bs[n] = acc_b[ni][0];
+      if (n < p.N) wgrad_store_bias(p, acc_b[ni][0], slab_id, g, n);
     }
   }
-  // slab[sp][g][n][k]; lane holds k = kb + 4*lg + r, n = nb + li
-  float *slab = p.ws + slab_id * (int64_t)p.N * p.K;
+  wgrad_store_tile(p, acc, slab_id, g, n0, k0, wr, wc, li, lg);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (16-bit operands; round 5): the same 128 x 128 tile, wave layout, work units, slabs and ride-along
+// reduce, but the operands go global -> LDS directly (global_load_lds_dwordx4), as in gemm_nt_dma_kernel:
+//   - no staging registers, no ds_write pass, no second register set to spill: <= 128 VGPRs and ONE 32 KiB buffer (64
+//     contraction rows x 128 columns of each operand), so FOUR workgroups share a CU instead of two and their DMA / MFMA
+//     phases interleave; 32 MFMAs per wave between barriers instead of 16;
+//   - the image rows are unpadded (a wave's DMA instruction fills 1 KiB = four 256-byte rows, lane-linear), so the
+//     transposed reads are made conflict free by an XOR swizzle instead of the 288-byte stride: the 32-byte granule g of row
+//     r sits at granule g ^ (r & 7) - the eight rows a half-wave's ds_read_b64_tr_b16 touches land on eight different
+//     8-bank windows - applied to the per-lane SOURCE address on the way in and to the fragment addresses on the way out
+//     (four address registers per operand, one per 16-column tile of the wave: an XOR does not fold into an offset field);
+//   - rows past the end of a unit must contribute nothing: their source is a zero row in device memory (a DMA cannot be
+//     masked into zeros at the LDS store the way the register-staged kernel does it);
+//   - gather indices of step t + 1 are loaded under step t's MFMAs.
+// Not for c_row_scale (the per-row factor is applied in registers on the way into LDS): those launches keep
+// wgrad_tn_kernel<.., SC = true>.
+__device__ __attribute__((aligned(256))) const uint32_t g_wgrad_zero_row[64] = {0};      // 256 bytes of zeros: the source of rows past a unit's end
+
+template <typename T, bool GC, bool GA>
+__global__ __launch_bounds__(WG_THREADS, 4) void wgrad_dma_kernel(const WgradDev p) {
+  typedef Mma<T> MM;
+  typedef typename MM::frag frag;
+  static_assert(sizeof(T) == 2, "16-bit operands");
+  constexpr int ROWS = 64;                                  // contraction rows per step
+  constexpr int RS = WG_T * 2;                              // image row: 128 columns = 256 bytes
+  constexpr int OPB = ROWS * RS;                            // one operand image: 16 KiB
+  constexpr int NPC = ROWS / 4 / 4;                         // DMA pieces (4 rows each) per wave per operand per step: 4
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [dC image | A image]
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int tiles = gridDim.x;
+  int bz, gz;
+  if (wgrad_ride_along(p, tid, bz, gz)) return;
+  const int lin = blockIdx.x + tiles * (blockIdx.y + gridDim.y * bz);
+  int tile, gs, g, sp, nst;
+  int64_t r0, r1, s_begin;
+  if (p.chunk_rows) {                          // gs = work unit; its slab is ws[gs]
+    if (!wgrad_unit(p.group_offsets, p.G, p.chunk_rows, lin, tiles, lane, tile, gs, g, r0, r1)) return;
+    sp = gs; s_begin = 0;
+    nst = (int)((r1 - r0 + ROWS - 1) / ROWS);
+  } else {
+    const int log_id = xcd_remap(lin, tiles * gridDim.y * gz);
+    tile = log_id % tiles; gs = log_id / tiles;
+    g = gs % (int)gridDim.y; sp = gs / (int)gridDim.y;
+    if (p.group_offsets) { r0 = p.group_offsets[g]; r1 = p.group_offsets[g + 1]; }
+    else { r0 = 0; r1 = p.M; }
+    const int64_t nsteps_all = (r1 - r0 + ROWS - 1) / ROWS;
+    const int64_t per = (nsteps_all + p.splits - 1) / p.splits;
+    s_begin = (int64_t)sp * per;
+    int64_t s_end = s_begin + per;
+    if (s_end > nsteps_all) s_end = nsteps_all;
+    nst = (int)(s_end > s_begin ? s_end - s_begin : 0);
+  }
+  const int tn = tile / p.tiles_k, tk = tile - tn * p.tiles_k;
+  const int n0 = tn * WG_T, k0 = tk * WG_T;
+  const int64_t slab_id = p.chunk_rows ? (int64_t)sp : (int64_t)sp * p.G + g;
+
+  f32x4 acc[4][4];   // [ki][ni]: MFMA rows = k, cols = n
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    const int n = n0 + wc * 64 + ni * 16 + li;
-    if (n >= p.N) continue;
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int ki = 0; ki < 4; ++ki) {
-      const int k = k0 + wr * 64 + ki * 16 + 4 * lg;
-      if (k >= p.K) continue;
-      *(f32x4 *)(slab + (int64_t)n * p.K + k) = acc[ki][ni];
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // DMA assignment: wave w, piece j fills image rows (4 w + j) * 4 .. + 3; lane l -> row + (l >> 4), physical 16-byte chunk
+  // l & 15, which holds logical chunk (l & 15) ^ ((row & 7) << 1).  (row & 7) only depends on the parity of j and on the
+  // lane, so a lane has two column offsets per operand.  Columns beyond N / K are clamped (outputs never stored).
+  // Every step but a unit's last is 64 whole rows: its sources are (wave-uniform operand base) + (32-bit per-lane offset:
+  // the host checks the 4 GiB reach), one address register per piece and no 64-bit arithmetic.  The last step (rows past the
+  // end read a zero row, which lives in another buffer) takes 64-bit addresses picked by a bit mask - a `ok ? a : b` between
+  // the two becomes a branch around each load, a basic block per piece with its own vmcnt(0).
+  const int prow = lane >> 4;                                // row of this lane inside a piece
+  uint32_t colC[2], colA[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int c = (lane & 15) ^ ((((4 * q + prow) & 7)) << 1);
+    int nc = n0 + c * 8, kc = k0 + c * 8;
+    if (nc > p.N - 8) nc = p.N - 8;
+    if (kc > p.K - 8) kc = p.K - 8;
+    colC[q] = (uint32_t)nc * 2; colA[q] = (uint32_t)kc * 2;
+  }
+  const int rbase = (int)(r0 + s_begin * ROWS) + (NPC * wave) * 4 + prow;      // row of piece 0 in local step 0 (M < 2^31)
+  const int rlast = (int)r1 - 1;
+  const uint32_t ldc = (uint32_t)p.lddc_b, lda = (uint32_t)p.lda_b;
+  int32_t ic[NPC], ia[NPC];
+  auto load_index = [&](int step) {
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int m = min(rbase + step * ROWS + 4 * j, rlast);
+      if (GC) ic[j] = p.c_row_idx[m];
+      if (GA) ia[j] = p.a_row_idx[m];
+    }
+  };
+  char *const dma_dst = smem + (NPC * wave) * 1024;
+  auto dma_full = [&](int step) {
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int m = rbase + step * ROWS + 4 * j;
+      // (gather divisors are powers of two here: the host sends anything else to the register-staged kernel)
+      const uint32_t cr = GC ? (uint32_t)(ic[j] >> p.c_row_sh) : (uint32_t)m;
+      const uint32_t ar = GA ? (uint32_t)(ia[j] >> p.a_row_sh) : (uint32_t)m;
+      __builtin_amdgcn_global_load_lds((glb_void *)(p.dC + (cr * ldc + colC[j & 1])), (lds_void *)(dma_dst + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void *)(p.A + (ar * lda + colA[j & 1])), (lds_void *)(dma_dst + j * 1024 + OPB), 16, 0, 0);
+    }
+  };
+  auto dma_tail = [&](int step) {
+    const uint64_t zero_row = (uint64_t)(uintptr_t)g_wgrad_zero_row + (lane & 15) * 16;
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int m = rbase + step * ROWS + 4 * j;
+      const uint64_t ok = m <= rlast ? ~(uint64_t)0 : (uint64_t)0;
+      const uint32_t cr = GC ? (uint32_t)(ic[j] >> p.c_row_sh) : (uint32_t)min(m, rlast);
+      const uint32_t ar = GA ? (uint32_t)(ia[j] >> p.a_row_sh) : (uint32_t)min(m, rlast);
+      const uint64_t sc = (((uint64_t)(uintptr_t)p.dC + (cr * ldc + colC[j & 1])) & ok) | (zero_row & ~ok);
+      const uint64_t sa = (((uint64_t)(uintptr_t)p.A + (ar * lda + colA[j & 1])) & ok) | (zero_row & ~ok);
+      __builtin_amdgcn_global_load_lds((glb_void *)(uintptr_t)sc, (lds_void *)(dma_dst + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void *)(uintptr_t)sa, (lds_void *)(dma_dst + j * 1024 + OPB), 16, 0, 0);
+    }
+  };
+
+  // fragment addresses: lane (li, lg) supplies row 4 lg + (li >> 2) (+ 16 for the second half of a fragment, + 32 for the
+  // second chunk of a step), columns col + 4 (li & 3) .. + 3 of the 16-column tile starting at col
+  const int s3 = (4 * (lg & 1) + (li >> 2)) & 7;
+  const int frow = (4 * lg + (li >> 2)) * RS + 8 * (li & 1);
+  int adK[4], adN[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ck = (wr * 8 + 2 * i + ((li & 3) >> 1)) ^ (s3 << 1);
+    const int cn = (wc * 8 + 2 * i + ((li & 3) >> 1)) ^ (s3 << 1);
+    adK[i] = OPB + frow + ck * 16;
+    adN[i] = frow + cn * 16;
+  }
+  typedef __attribute__((address_space(3))) fp16x4_t lds_h4;
+  auto read_frag = [&](int ad, int rb) -> frag {
+    const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4 *)(smem + ad + rb * RS));
+    const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4 *)(smem + ad + (rb + 16) * RS));
+    f16x8 f;
+    f[0] = (half_t)lo[0]; f[1] = (half_t)lo[1]; f[2] = (half_t)lo[2]; f[3] = (half_t)lo[3];
+    f[4] = (half_t)hi[0]; f[5] = (half_t)hi[1]; f[6] = (half_t)hi[2]; f[7] = (half_t)hi[3];
+    return __builtin_bit_cast(frag, f);
+  };
+
+  // Bias gradient (column sums of dC over the contraction rows; once per n-tile: k-tile 0, waves wr == 0): a lane's dC
+  // fragment holds 8 contraction rows of ITS column, so four v_dot2 with a pair of ones add them up - one fp32 register per
+  // 16-column tile instead of the register-staged kernel's extra MFMA row (16 accumulator registers + a ones fragment:
+  // at 128 registers they spilled); the four lane groups' partial sums meet in two shuffles at the end.
+  const bool do_bias = (p.bias_ws || p.direct_db) && tk == 0 && wr == 0;
+  float acc_b[4] = {0.f, 0.f, 0.f, 0.f};
+  typedef T t2 __attribute__((ext_vector_type(2)));
+  auto colsum8 = [&](const frag &f, float a) -> float {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const t2 pr = t2{f[2 * j], f[2 * j + 1]};
+      if constexpr (std::is_same<T, half_t>::value)
+        a = __builtin_amdgcn_fdot2(pr, t2{(T)1, (T)1}, a, false);
+      else
+        a = __builtin_amdgcn_fdot2_f32_bf16(pr, t2{(T)1.f, (T)1.f}, a, false);
+    }
+    return a;
+  };
+
+  auto compute = [&]() {
+#pragma unroll
+    for (int kc = 0; kc < ROWS / 32; ++kc) {
+      frag fk[4], fn[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fk[i] = read_frag(adK[i], kc * 32);
+        fn[i] = read_frag(adN[i], kc * 32);
+      }
+#pragma unroll
+      for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[ki][ni] = MM::mma(fk[ki], fn[ni], acc[ki][ni]);
+      if (do_bias) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc_b[ni] = colsum8(fn[ni], acc_b[ni]);
+      }
+    }
+  };
+
+  if (nst > 0) {
+    if (GC || GA) load_index(0);
+    for (int t = 0; t + 1 < nst; ++t) {
+      dma_full(t);
+      if (GC || GA) load_index(t + 1);                       // (arrives under this step's MFMAs; the barrier's vmcnt(0) covers it)
+      __syncthreads();          // vmcnt(0) + barrier: the step's rows have landed
+      compute();
+      __syncthreads();          // everyone has read them
+    }
+    dma_tail(nst - 1);
+    __syncthreads();
+    compute();
+  }
+
+  if (do_bias) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      float v = acc_b[ni];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int n = n0 + wc * 64 + ni * 16 + li;
+      if (lg == 0 && n < p.N) wgrad_store_bias(p, v, slab_id, g, n);
     }
   }
+  wgrad_store_tile(p, acc, slab_id, g, n0, k0, wr, wc, li, lg);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -532,7 +771,7 @@ __global__ __launch_bounds__(WW_THREADS, 2) void wgrad_wide_kernel(const WgradDe
       *(u32x4 *)(base + i * st_step) = ok ? rq[i] : u32x4{0u, 0u, 0u, 0u};
     }
   };
-  const bool do_bias = p.bias_ws && tk == 0 && wr == 0;    // column sums of dC as one extra MFMA row of ones
+  const bool do_bias = (p.bias_ws || p.direct_db) && tk == 0 && wr == 0;    // column sums of dC as one extra MFMA row of ones
   f32x4 acc_b[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) acc_b[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -761,6 +1000,13 @@ extern "C" int m3_debug_wgrad_clock(unsigned long long *dst) {
 }
 #endif
 
+static int g_wgrad_dma = -1;
+extern "C" int m3_wgrad_set_dma(int on) {
+  M3_REQUIRE(on >= -1 && on <= 1, "m3_wgrad_set_dma: %d", on);
+  g_wgrad_dma = on;
+  return M3_OK;
+}
+
 static int g_wgrad_wide = -1;
 extern "C" int m3_wgrad_set_wide(int on) {
   M3_REQUIRE(on >= -1 && on <= 1, "m3_wgrad_set_wide: %d", on);
@@ -780,7 +1026,7 @@ extern "C" int m3_wgrad_tile(int N, int K, int dtype, int *tn, int *tk) {
 }
 
 extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
-  M3_REQUIRE(a && a->dC && a->A && a->ws, "m3_wgrad_tn: null operand");
+  M3_REQUIRE(a && a->dC && a->A && (a->ws || a->direct_dW), "m3_wgrad_tn: null operand");
   M3_REQUIRE(dtype_ok(a->dtype), "m3_wgrad_tn: bad dtype");
   const int es = dtype_size(a->dtype);
   M3_REQUIRE(a->N > 0 && a->K > 0 && a->M >= 0 && a->G >= 1 && a->splits >= 1, "m3_wgrad_tn: bad shape");
@@ -788,6 +1034,9 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   M3_REQUIRE((a->N * es) % 16 == 0 && (a->K * es) % 16 == 0, "m3_wgrad_tn: N*elem and K*elem must be multiples of 16 bytes");
   M3_REQUIRE((a->lddc * es) % 16 == 0 && (a->lda * es) % 16 == 0, "m3_wgrad_tn: rows must be 16-byte aligned");
   M3_REQUIRE(((uintptr_t)a->dC % 16) == 0 && ((uintptr_t)a->A % 16) == 0 && ((uintptr_t)a->ws % 16) == 0, "m3_wgrad_tn: alignment");
+  M3_REQUIRE(!a->direct_dW || (a->splits == 1 && a->chunk_rows == 0 && ((uintptr_t)a->direct_dW % 16) == 0 && !a->bias_ws),
+             "m3_wgrad_tn: direct mode needs splits == 1, no balanced units, a 16-byte aligned dW and no bias slabs");
+  M3_REQUIRE(!a->direct_db || a->direct_dW, "m3_wgrad_tn: direct_db goes with direct_dW");
   M3_REQUIRE(a->G == 1 || a->group_offsets, "m3_wgrad_tn: grouped call needs group_offsets");
   M3_REQUIRE(!a->a_row_idx || a->a_row_div >= 1, "m3_wgrad_tn: a_row_div");
   WgradDev d;
@@ -801,6 +1050,8 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   d.a_row_sh = div_shift(d.a_row_div);
   d.M = a->M; d.N = a->N; d.K = a->K; d.G = a->G; d.group_offsets = a->group_offsets;
   d.splits = a->splits; d.ws = a->ws; d.bias_ws = a->bias_ws;
+  d.direct_dW = a->direct_dW; d.direct_db = a->direct_dW ? a->direct_db : nullptr;
+  d.direct_beta = a->direct_beta; d.direct_beta_db = a->direct_beta_db;
   M3_REQUIRE(a->chunk_rows >= 0 && (a->chunk_rows == 0 || (a->group_offsets && a->chunk_rows % WG_ROWS == 0 && a->units >= 1 && a->G <= 64)),
              "m3_wgrad_tn: balanced mode needs group_offsets, G <= 64, chunk_rows a multiple of %d and units >= 1", WG_ROWS);
   d.chunk_rows = a->chunk_rows;
@@ -809,7 +1060,8 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   // wide tiles (fp16): the shapes m3_wgrad_tile() names; the caller sized `splits` / `units` for that tile count
   int tn_w = 0, tk_w = 0;
   m3_wgrad_tile(a->N, a->K, a->dtype, &tn_w, &tk_w);
-  const bool wide = (tn_w != WG_T || tk_w != WG_T) && (d.a_row_div & (d.a_row_div - 1)) == 0 && !d.c_row_scale && d.c_row_div == 1;
+  const bool wide = (tn_w != WG_T || tk_w != WG_T) && (d.a_row_div & (d.a_row_div - 1)) == 0 && !d.c_row_scale && d.c_row_div == 1 &&
+                    !d.direct_dW;
   // the previous call's slab reduction (a->prev): in front of this launch (128 x 128 kernel), or as its own launch
   d.rd_blocks = 0; d.rd_zslices = 0;
   if (a->prev) {
@@ -866,6 +1118,24 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   M3_REQUIRE(a->N * es >= 16 && a->K * es >= 16, "m3_wgrad_tn: N, K too small");
   const size_t lds16 = 4 * WgLds<half_t>::ROWS * WgLds<half_t>::STRIDE, lds32 = 4 * WgLds<float>::ROWS * WgLds<float>::STRIDE;
   const bool sc = a->c_row_scale != nullptr;
+  // LDS-DMA variant: 16-bit operands, whole 16-byte column chunks on both sides, no per-row factor.
+  // m3_wgrad_set_dma / M3_WGRAD_DMA = 0 keeps the register-staged kernel (diagnostics, A/B)
+  if (g_wgrad_dma < 0) { const char *e = getenv("M3_WGRAD_DMA"); g_wgrad_dma = e ? (atoi(e) ? 1 : 0) : 1; }
+  if (g_wgrad_dma && es == 2 && !sc && a->N >= 8 && a->K >= 8 && d.a_row_sh >= 0 && d.c_row_sh >= 0 &&
+      (a->M + 1) * d.lddc_b < ((int64_t)1 << 32) && (a->M + 1) * d.lda_b < ((int64_t)1 << 32)) {       // 32-bit lane offsets
+    const size_t ldsd = 2 * 64 * WG_T * 2;       // 32 KiB
+#define M3_WD(TT)                                                                                    \
+    do {                                                                                             \
+      if (gc && ga) hipLaunchKernelGGL((wgrad_dma_kernel<TT, true, true>), grid, block, ldsd, s, d); \
+      else if (gc) hipLaunchKernelGGL((wgrad_dma_kernel<TT, true, false>), grid, block, ldsd, s, d); \
+      else if (ga) hipLaunchKernelGGL((wgrad_dma_kernel<TT, false, true>), grid, block, ldsd, s, d); \
+      else hipLaunchKernelGGL((wgrad_dma_kernel<TT, false, false>), grid, block, ldsd, s, d);        \
+    } while (0)
+    if (a->dtype == M3_F16) M3_WD(half_t);
+    else M3_WD(bf16_t);
+#undef M3_WD
+    return check_launch("m3_wgrad_tn");
+  }
 #define M3_WG(TT, LDS)                                                                               \
   do {                                                                                               \
     if (sc && ga) hipLaunchKernelGGL((wgrad_tn_kernel<TT, true, true, true>), grid, block, LDS, s, d);    \

@@ -398,15 +398,19 @@ def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None,
         return dW
     if splits is None:
         splits = default_wgrad_splits(M, N, K, G, dC.dtype)
-    balanced = group_offsets is not None
+    # direct mode (include/m3vit_hip.h: m3_wgrad_args.direct_dW): with ONE part per group every (group, tile) belongs to one
+    # workgroup, which adds its tile into dW itself - no slabs, no reduction.  The default split rule says 1 exactly when the
+    # tiles alone fill the chip (the ViT-Base experts: 2304 tiles, 151 MB of gradient per layer)
+    direct = _WGRAD_DIRECT and splits == 1 and wgrad_tile(N, K, dC.dtype) == (128, 128) and dW.data_ptr() % 16 == 0
+    balanced = group_offsets is not None and not direct
     chunk, units = wgrad_plan(M, G, splits, balanced)
     balanced = chunk > 0
-    need = units * N * K + (units * N if db is not None else 0)
+    need = 0 if direct else units * N * K + (units * N if db is not None else 0)
     if queue is not None:
         ws = queue.ws[queue.i]
         assert ws.numel() >= need, "WgradQueue workspace too small for this shape"
     elif ws is None or ws.numel() < need:
-        ws = torch.empty(need, dtype=torch.float32, device=dW.device)
+        ws = torch.empty(max(need, 4), dtype=torch.float32, device=dW.device)
     a = WgradArgs()
     a.dC = dC.data_ptr(); a.lddc = dC.stride(0)
     a.c_row_idx = c_row_idx.data_ptr() if c_row_idx is not None else None
@@ -424,9 +428,24 @@ def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None,
     a.chunk_rows = chunk; a.units = units
     a.ws = ws.data_ptr()
     a.dtype = dt_code(dC.dtype)
-    bias_ws = ws[units * N * K:] if db is not None else None
+    bias_ws = ws[units * N * K:] if (db is not None and not direct) else None
     a.bias_ws = bias_ws.data_ptr() if bias_ws is not None else None
     bdb = beta if beta_db is None else beta_db
+    if direct:
+        if db is not None:
+            _req(db, torch.float32, "db")
+        a.direct_dW = dW.data_ptr(); a.direct_beta = 1 if beta else 0
+        a.direct_db = db.data_ptr() if db is not None else None
+        a.direct_beta_db = 1 if bdb else 0
+        if queue is not None and queue.pending is not None:      # the previous call's reduction still rides in front
+            if queue.pending[0].dW == dW.data_ptr():              # ... unless it writes the tensor this launch read-add-writes
+                queue.flush()
+            else:
+                a.prev = ctypes.pointer(queue.pending[0])
+        check(lib().m3_wgrad_tn(byref(a), _stream()), "m3_wgrad_tn")
+        if queue is not None:
+            queue.pending = None                                  # (this call left nothing to reduce; its slab buffer was not used)
+        return dW
     fuse = False
     if db is not None:
         _req(db, torch.float32, "db")
@@ -483,12 +502,18 @@ def wgrad_ws_elems(M, N, K, G, grouped, bias=True, dtype=None):
 
 _WGRAD_MIN_STEPS = 16      # 32-row steps per split at least (measured on the 8-image configs; no effect at batch 128)
 import os as _os
+_WGRAD_DIRECT = _os.environ.get("M3_WGRAD_DIRECT", "1") != "0"      # splits == 1: the kernel accumulates into dW itself (no slabs)
 _WGRAD_SLOTS = int(_os.environ.get("M3_WGRAD_SLOTS", "512"))      # workgroup slots a weight-gradient launch is split to fill (2 per CU)
 
 
 def wgrad_set_wide(on: int):
     """wide weight-gradient tiles on / off (include/m3vit_hip.h: m3_wgrad_set_wide); switch before sizing workspaces"""
     check(lib().m3_wgrad_set_wide(int(on)), "m3_wgrad_set_wide")
+
+
+def wgrad_set_dma(on: int):
+    """LDS-DMA weight-gradient kernel on (1, default) / off (0) / from M3_WGRAD_DMA (-1) (include/m3vit_hip.h: m3_wgrad_set_dma)"""
+    check(lib().m3_wgrad_set_dma(int(on)), "m3_wgrad_set_dma")
 
 
 def wgrad_tile(N, K, dtype=None):

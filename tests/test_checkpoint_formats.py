@@ -128,3 +128,67 @@ def test_a_local_shard_without_meta_is_not_sliced_again():
     assert fmt == "global" and st["blocks.1.mlp.experts.htoh4.weight"].shape[0] == 2
     with pytest.raises(ValueError, match="do not divide"):
         C.to_backbone_state({"state_dict": P, "meta": {"expert_format": "global"}}, rank=0, world_size=3)
+
+
+def test_upcycling_matches_the_reference_fixture(golden_dir):
+    """g11: utils/helpers.py:481-713 `_inject_moe_expert_from_deit_mlp` run on tiny dense state dicts (split upcycling at
+    ratio 1 with / without the GELU weight scaling, expert parallel local counts, replicate at ratio 4, truncate mode,
+    deit_warm_start, granularity 2) - bit-identical expert tensors; :714-753 `_auto_virtual_group_size` over 480 argument
+    combinations; :756-867 `_inject_virtual_group_init_for_gates` under the same seed - bit-identical w_gate tensors."""
+    import json
+    from collections import OrderedDict
+
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, "g11_upcycling.npz"))
+    tab = json.loads(str(g["table"]))
+    assert len(tab["cases"]) == 6
+    for c in tab["cases"]:
+        sd = OrderedDict((k.split("/in/")[1], torch.tensor(g[k])) for k in g.files if k.startswith(c["name"] + "/in/"))
+        dense_before = {k: v.clone() for k, v in sd.items()}
+        out = C.upcycle_dense_mlp_to_experts(sd, c["moe"], c["e_local"], c["eh"], total_experts=c["e_local"] * c["world"],
+                                             top_k=c["top_k"], moe_mlp_ratio=c["ratio"],
+                                             use_weight_scaling=bool(c["cfg"].get("use_weight_scaling")), mode=c["mode"])
+        assert out is sd
+        want = {k.split("/out/")[1]: g[k] for k in g.files if k.startswith(c["name"] + "/out/")}
+        assert set(want) == {k for k in sd if C.is_expert_key(k)}, c["name"]
+        for k, v in want.items():
+            assert torch.equal(sd[k], torch.tensor(v)), (c["name"], k)
+        assert all(torch.equal(sd[k], v) for k, v in dense_before.items())          # the dense tensors stay, untouched
+    for s in tab["group_sizes"]:
+        got = C.auto_virtual_group_size(s["tot"], local_experts=s["local_experts"], world_size=s["world_size"],
+                                        dense_hidden=s["dense_hidden"], expert_hidden=s["expert_hidden"])
+        assert got == s["out"], s
+    for v in tab["gate_init"]:
+        sd = OrderedDict((f"blocks.{i}.mlp.fc1.weight", torch.zeros(v["Hd"], v["D"])) for i in range(v["depth"]))
+        keys = [k.split("/out/")[1] for k in g.files if k.startswith(v["name"] + "/out/")]
+        shapes = OrderedDict((k, (v["D"], v["e_local"] * v["world"])) for k in keys)
+        torch.manual_seed(v["seed"])
+        C.virtual_group_gate_init(sd, shapes, local_experts=v["e_local"], world_size=v["world"], expert_hidden=v["expert_hidden"])
+        for k in keys:
+            w = sd[k]
+            assert torch.equal(w, torch.tensor(g[v["name"] + "/out/" + k])), k
+            G = C.auto_virtual_group_size(w.shape[1], local_experts=v["e_local"], world_size=v["world"], dense_hidden=v["Hd"],
+                                          expert_hidden=v["expert_hidden"])
+            assert all(torch.equal(w[:, :G], w[:, j:j + G]) for j in range(0, w.shape[1], G))
+
+
+def test_upcycled_experts_reproduce_the_dense_mlp():
+    """what upcycling is for: with every gate score 1 / G over one whole template group, the split experts' outputs add up
+    to the dense MLP's (fc2's bias is repeated per expert, so it appears G times: the reference's 'official-style' choice)"""
+    torch.manual_seed(0)
+    D, Hd, G = 8, 32, 4
+    sd = {"blocks.1.mlp.fc1.weight": torch.randn(Hd, D), "blocks.1.mlp.fc1.bias": torch.randn(Hd),
+          "blocks.1.mlp.fc2.weight": torch.randn(D, Hd), "blocks.1.mlp.fc2.bias": torch.randn(D)}
+    C.upcycle_dense_mlp_to_experts(sd, [1], 8, Hd // G, total_experts=8, moe_mlp_ratio=1.0)
+    x = torch.randn(5, D)
+    gelu = torch.nn.functional.gelu
+    dense = gelu(x @ sd["blocks.1.mlp.fc1.weight"].t() + sd["blocks.1.mlp.fc1.bias"]) @ sd["blocks.1.mlp.fc2.weight"].t()
+    w1, b1 = sd["blocks.1.mlp.experts.htoh4.weight"], sd["blocks.1.mlp.experts.htoh4.bias"]
+    w2, b2 = sd["blocks.1.mlp.experts.h4toh.weight"], sd["blocks.1.mlp.experts.h4toh.bias"]
+    parts = sum(gelu(x @ w1[e].t() + b1[e]) @ w2[e].t() for e in range(G))
+    assert torch.allclose(parts, dense, atol=1e-5)
+    assert torch.equal(w1[:G], w1[G:]) and torch.equal(b2[0], sd["blocks.1.mlp.fc2.bias"])
+    with pytest.raises(ValueError):
+        C.upcycle_dense_mlp_to_experts(dict(sd), [1], 8, 8, total_experts=6, moe_mlp_ratio=1.0)      # 6 experts, granularity 4
+    with pytest.raises(ValueError):
+        C.upcycle_dense_mlp_to_experts(dict(sd), [1], 4, 16, total_experts=4, mode="deit_warm_start")  # granularity 2
