@@ -44,6 +44,10 @@ int m3_version(void);
 const char *m3_last_error(void);
 /* fills name[0..len) with the gcnArchName of the current device; returns CU count or <0 */
 int m3_device_query(char *name, int len);
+/* 1 when the library was built with `make EXPERIMENTAL=1` (the opt-in kernels the training step never takes are compiled in:
+ * m3_ffn_fwd, the weight-stationary variant behind m3_gemm_set_variant, the wide tiles behind m3_wgrad_set_wide), else 0:
+ * those three entry points then exist but refuse (M3_ERR_ARG).  No reference counterpart. */
+int m3_experimental(void);
 
 /* ---------------------------------------------------------------- gate (a1-a3)
  * NoisyGate_VMoE.forward, models/moe/ckpt/noisy_gate_vmoe.py:91-93,168,197-207:

@@ -136,6 +136,7 @@ SIGNATURES = {
     "m3_relu_up2x_bwd": (c_int, [_V, _I, _V, _I, _L, _I, _I, _I, _I, _V, _V]),
     "m3_ep_plan_fixed": (c_int, [_V, _V, _I, _I, _I, _V, _V, _L, _V, _V, _V, _V, _V, _V, _V, _V]),
     "m3_gemm_nt": (c_int, [POINTER(GemmArgs), _V]),
+    "m3_experimental": (c_int, []),
     "m3_gemm_set_variant": (c_int, [_I]),
     "m3_gemm_set_big": (c_int, [_I]),
     "m3_ffn_fwd": (c_int, [POINTER(FfnArgs), _V]),

@@ -75,5 +75,7 @@ enum { DMA_EPI_ANY = 0, DMA_EPI_GPRE = 1, DMA_EPI_RES = 2, DMA_EPI_PLAIN = 3, DM
 // gemm_big.hip: 256 x 256 tiles, eight waves, LDS-DMA ring.  Returns false when the call is not one it takes.
 bool gemm_big_eligible(const GemmDev &d, int dtype_size_bytes, bool force);
 int launch_gemm_big(const GemmDev &d, int dtype, int epi, hipStream_t s);
+// gemm_ws.hip (EXPERIMENTAL builds): 0 launched, 1 not a call it takes, < 0 error
+int launch_gemm_ws(const GemmDev &d, const m3_gemm_args *a, int64_t mt, int ws_mode, hipStream_t s);
 
 }  // namespace m3

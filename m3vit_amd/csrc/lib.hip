@@ -29,6 +29,24 @@ extern "C" int m3_version(void) { return 100; }   // 0.1.0
 
 extern "C" const char *m3_last_error(void) { return m3::g_err; }
 
+// 1 when the library was built with `make EXPERIMENTAL=1`: the opt-in kernels the engine never takes (fused FFN, weight-stationary
+// GEMM, wide weight-gradient tiles) are then compiled in; the default build carries only what the training step runs
+extern "C" int m3_experimental(void) {
+#ifdef M3_EXPERIMENTAL
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+#ifndef M3_EXPERIMENTAL
+extern "C" int m3_ffn_fwd(const m3_ffn_args *, void *) {
+  m3::set_error("m3_ffn_fwd: the fused FFN kernel is only in EXPERIMENTAL builds (make EXPERIMENTAL=1); the default path is "
+                "two m3_gemm_nt launches");
+  return M3_ERR_ARG;
+}
+#endif
+
 extern "C" int m3_device_query(char *name, int len) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { m3::set_error("m3_device_query: no HIP device"); return M3_ERR_LAUNCH; }

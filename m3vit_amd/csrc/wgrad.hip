@@ -635,6 +635,7 @@ __global__ __launch_bounds__(WG_THREADS, 4) void wgrad_dma_kernel(const WgradDev
   wgrad_store_tile(p, acc, slab_id, g, n0, k0, wr, wc, li, lg);
 }
 
+#ifdef M3_EXPERIMENTAL      // the wide-tile kernel: built only by `make EXPERIMENTAL=1` (measured no faster in the step; the engine never takes it)
 // ------------------------------------------------------------------------------------------------
 // Wide tiles (fp16): 128(n) x 384(k) for the K = 384 weights (qkv, fc1, expert FC1) and 384(n) x 128(k) for the
 // N = 384 ones (fc2, expert FC2, patch embedding), eight waves per workgroup, one workgroup per CU.
@@ -883,6 +884,8 @@ __global__ __launch_bounds__(WW_THREADS, 2) void wgrad_wide_kernel(const WgradDe
 #endif
 }
 
+#endif  // M3_EXPERIMENTAL
+
 // slabs -> dW (blocks [0, nb_w)) and, in the same launch, bias slabs -> db (blocks [nb_w, ...)); splits in order
 __device__ __forceinline__ void wgrad_reduce_block(int64_t blk, int tid, const float *ws, int splits, int64_t elems4, float *dW,
                                                    int beta, int nb_w, const float *bias_ws, int64_t belems4, float *db, int beta_db) {
@@ -1010,6 +1013,9 @@ extern "C" int m3_wgrad_set_dma(int on) {
 static int g_wgrad_wide = -1;
 extern "C" int m3_wgrad_set_wide(int on) {
   M3_REQUIRE(on >= -1 && on <= 1, "m3_wgrad_set_wide: %d", on);
+#ifndef M3_EXPERIMENTAL
+  M3_REQUIRE(on <= 0, "m3_wgrad_set_wide: the wide-tile kernel is only in EXPERIMENTAL builds (make EXPERIMENTAL=1)");
+#endif
   g_wgrad_wide = on;
   return M3_OK;
 }
@@ -1018,6 +1024,9 @@ extern "C" int m3_wgrad_tile(int N, int K, int dtype, int *tn, int *tk) {
   M3_REQUIRE(tn && tk, "m3_wgrad_tile: null output");
   if (g_wgrad_wide < 0) { const char *e = getenv("M3_WGRAD_WIDE"); g_wgrad_wide = e ? (atoi(e) ? 1 : 0) : 0; }
   *tn = WG_T; *tk = WG_T;
+#ifndef M3_EXPERIMENTAL
+  g_wgrad_wide = 0;
+#endif
   if (g_wgrad_wide && dtype == M3_F16) {
     if (K == 384 && N % 128 == 0 && N >= 768) { *tn = 128; *tk = 384; }
     else if (N == 384 && K % 128 == 0 && K >= 768) { *tn = 384; *tk = 128; }
@@ -1086,6 +1095,7 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
       }
     }
   }
+#ifdef M3_EXPERIMENTAL
   if (wide) {
     constexpr int WR = M3_WGRAD_WIDE_ROWS;
     const bool wide_k = tk_w == 384;
@@ -1107,6 +1117,7 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
 #undef M3_WW_ALL
     return check_launch("m3_wgrad_tn");
   }
+#endif
   const int tiles_n = (a->N + WG_T - 1) / WG_T;
   d.tiles_k = (a->K + WG_T - 1) / WG_T;
   dim3 grid(tiles_n * d.tiles_k, a->chunk_rows ? a->units : a->G, a->chunk_rows ? 1 : a->splits), block(WG_THREADS);

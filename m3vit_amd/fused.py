@@ -50,6 +50,9 @@ class _Slot:
         self.noises = self.path_scales = None
         self.add_done = None                          # event: slot 0's stream has read this slot's gradient buffer
         self.main = None                              # the stream forward() was called on
+        self.out = {}                                 # per task: the forward graph's output tensors
+        self.py_owner = None                          # which Python-level eng.forward ran last on this context: ("eager" | "fcap"
+                                                      # | "eval", key) - the engine's per-call tensors are that call's
 
 
 class _BackboneFn(torch.autograd.Function):
@@ -122,6 +125,8 @@ class FusedBackbone:
             return model._fused_static_why
         if torch.is_grad_enabled() and not model.training:
             return "eval mode with autograd on"
+        if torch.is_grad_enabled() and x.requires_grad:
+            return "the images require a gradient (the executor's node returns none for them)"
         if x.dim() != 4 or tuple(x.shape[2:]) != tuple(model.img_size):
             return "image size differs from the constructor's"
         if model.multi_gate and task_id is None:
@@ -254,7 +259,11 @@ class FusedBackbone:
             self.base_eng.prepare_weights()
             self.dirty = False
         if not train:
-            return self._forward_nograd(images, task_id, model, main)
+            return self._forward_nograd(images, task_id, model, main, refreshed)
+        if self.e_spec:                                  # evaluation passes nobody claimed keep their contexts no longer
+            for sl, _, _ in self.e_spec.values():
+                sl.busy = False
+            self.e_spec = {}
         # a new step begins with the first training forward after the parameters changed (an optimizer step), or after a
         # backward when this call cannot belong to the calls before it (other images, or a task that was already run): so
         # both the joint schedule (all forwards, one backward) and one task at a time (forward / backward per task on the
@@ -300,6 +309,7 @@ class FusedBackbone:
         slot.calls_e[key] = n + 1
         if not self.graph or n == 0:
             tok, cv = self._forward_eager(slot, task_id, images.float().contiguous(), False)
+            slot.py_owner = ("eval", key)
         else:
             if slot.images is None:
                 slot.images = torch.empty(images.shape, dtype=torch.float32, device=self.device)
@@ -310,11 +320,12 @@ class FusedBackbone:
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     out = slot.eng.forward(slot.images, task_id, noises=noises, path_scales=ps)
                 slot.graphs_e[key] = (g, out)
+                slot.py_owner = ("eval", key)
             g, (tok, cv) = slot.graphs_e[key]
             g.replay()
         return tok.clone(), (tok.new_zeros(()) if not model.training else cv.clone())
 
-    def _forward_nograd(self, images, task_id, model, main):
+    def _forward_nograd(self, images, task_id, model, main, refreshed=False):
         """Evaluation (model.eval() under torch.no_grad()) or a no_grad probe: every call runs on a free context's stream and
         the caller's stream waits for it.  An evaluation loop calls the backbone once per task on the same batch
         (models/models.py:299-320) just like training: when the previous batch saw tasks [t0, t1, ..] on one tensor, the first
@@ -334,6 +345,10 @@ class FusedBackbone:
         else:
             new_batch = False
         self.e_hist.append(task_id)
+        if refreshed and self.e_spec:                    # the parameters changed since those passes were started: stale
+            for slot, _, _ in self.e_spec.values():
+                slot.busy = False
+            self.e_spec = {}
         hit = self.e_spec.pop(task_id, None) if images._version == self.e_version else None
         if hit is None:
             if self.e_spec:                              # the batch tensor was written to: started passes are stale
@@ -390,6 +405,13 @@ class FusedBackbone:
 
     def _close_step(self):
         """first training forward after a backward: the calls since the last boundary were one step"""
+        # The end-of-backward callback (_join_caller) is queued once per backward pass and clears its own latch - unless
+        # the pass raised (an out-of-memory in a head's backward ...): autograd then never runs the callback, the latch would
+        # stay set and no later backward would make the caller's stream wait for the gradient stream.  A step boundary
+        # clears it, and - as a backstop for exactly that case - joins the gradient stream here (a no-op when the callback ran).
+        if self._join_queued:
+            self._join_queued = False
+            torch.cuda.current_stream().wait_stream(self.gstream)
         if self.spec:
             self._drop_prefetched()
         tasks = [t for t, _ in self.hist]
@@ -456,6 +478,7 @@ class FusedBackbone:
             img = images.float().contiguous()
             img.record_stream(torch.cuda.current_stream())
             tok, cv = self._forward_eager(slot, task_id, img, zero)      # (the backward re-reads eng.rows, not the images)
+            slot.py_owner = ("eager", task_id)
             return tok.clone(), cv
         if slot.images is None:
             slot.images = torch.empty(images.shape, dtype=torch.float32, device=self.device)
@@ -463,6 +486,15 @@ class FusedBackbone:
         slot.images.copy_(images)
         self._draw(slot, eng)
         g = slot.graphs_f.get(task_id)
+        if g is not None and task_id not in slot.graphs_b and slot.py_owner != ("fcap", task_id):
+            # The backward graph of this (slot, task) is still to be captured, and capturing it runs eng.backward at Python
+            # level: it reads the engine's per-call tensors (gate outputs, routes) by reference - those of the LAST Python-level
+            # eng.forward on this slot.  That was this task's forward capture only if nothing else ran on the slot since (a
+            # dropped prefetched pass, another task, an evaluation pass): if not, the replayed forward would write the old
+            # addresses while the new backward graph reads another forward's tensors.  Capture the forward again.
+            slot.graphs_f.pop(task_id)
+            slot.out.pop(task_id, None)
+            g = None
         if g is None:
             noises = slot.noises if (self.cfg.vmoe_noisy_std > 0 and self.model().training) else None
             ps = slot.path_scales if (self.drop and self.model().training) else None
@@ -472,8 +504,8 @@ class FusedBackbone:
                     eng.zero_grad()
                 out = eng.forward(slot.images, task_id, noises=noises, path_scales=ps)
             slot.graphs_f[task_id] = g
-            slot.out = getattr(slot, "out", {})
             slot.out[task_id] = out
+            slot.py_owner = ("fcap", task_id)
         g.replay()
         tok, cv = slot.out[task_id]
         return tok.clone(), cv.clone()
@@ -487,6 +519,8 @@ class FusedBackbone:
         plist, views, vptrs = self.plist, self.views, self.view_ptrs
         fresh, foreign = [], []
         for i, p in enumerate(plist):
+            if not p.requires_grad:                   # frozen parameters keep .grad = None, as on the per-op path: an optimizer
+                continue                              # then skips them (no weight decay / momentum on a zero gradient)
             g = p.grad
             if g is None:
                 fresh.append(i)

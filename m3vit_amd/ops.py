@@ -503,7 +503,17 @@ def wgrad_ws_elems(M, N, K, G, grouped, bias=True, dtype=None):
 _WGRAD_MIN_STEPS = 16      # 32-row steps per split at least (measured on the 8-image configs; no effect at batch 128)
 import os as _os
 _WGRAD_DIRECT = _os.environ.get("M3_WGRAD_DIRECT", "1") != "0"      # splits == 1: the kernel accumulates into dW itself (no slabs)
-_WGRAD_SLOTS = int(_os.environ.get("M3_WGRAD_SLOTS", "512"))      # workgroup slots a weight-gradient launch is split to fill (2 per CU)
+# workgroup slots a weight-gradient launch is split to fill: the LDS-DMA kernel (16-bit operands) runs four workgroups per CU,
+# the register-staged one (fp32) two.  Measured with the row splits sized for 1024 instead of 512 slots (tools/wgrad_ab_bench.py,
+# profiles/r05_wgrad_ab.txt): the dense ViT-Base weight gradients 520 -> 780 TFLOP/s, configs[1]'s expert FC1 363 -> 485
+_WGRAD_SLOTS = int(_os.environ.get("M3_WGRAD_SLOTS", "0"))         # 0: by kernel (1024 / 512)
+_WGRAD_DMA = _os.environ.get("M3_WGRAD_DMA", "1") != "0"
+
+
+def _wgrad_slots(dtype):
+    if _WGRAD_SLOTS:
+        return _WGRAD_SLOTS
+    return 1024 if (_WGRAD_DMA and dtype in (torch.float16, torch.bfloat16)) else 512
 
 
 def wgrad_set_wide(on: int):
@@ -512,8 +522,11 @@ def wgrad_set_wide(on: int):
 
 
 def wgrad_set_dma(on: int):
-    """LDS-DMA weight-gradient kernel on (1, default) / off (0) / from M3_WGRAD_DMA (-1) (include/m3vit_hip.h: m3_wgrad_set_dma)"""
+    """LDS-DMA weight-gradient kernel on (1, default) / off (0) / from M3_WGRAD_DMA (-1) (include/m3vit_hip.h: m3_wgrad_set_dma);
+    switch before sizing workspaces (the default row splits follow the kernel's workgroups per CU)"""
+    global _WGRAD_DMA
     check(lib().m3_wgrad_set_dma(int(on)), "m3_wgrad_set_dma")
+    _WGRAD_DMA = (_os.environ.get("M3_WGRAD_DMA", "1") != "0") if int(on) < 0 else bool(on)
 
 
 def wgrad_tile(N, K, dtype=None):
@@ -536,7 +549,8 @@ def default_wgrad_splits(M, N, K, G, dtype=None):
     steps = max(1, (M // max(G, 1) + 31) // 32)
     cap = max(1, steps // _WGRAD_MIN_STEPS)
     if (tn, tk) == (128, 128):
-        return int(max(1, min(cap, 32, _WGRAD_SLOTS // tiles if tiles <= _WGRAD_SLOTS else 1)))
+        nslots = _wgrad_slots(dtype)
+        return int(max(1, min(cap, 32, nslots // tiles if tiles <= nslots else 1)))
     slots = 256
     if 3 * tiles <= slots:
         return int(max(1, min(cap, slots // tiles)))

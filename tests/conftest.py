@@ -12,6 +12,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "experimental: opt-in kernels of `make EXPERIMENTAL=1` builds (fused FFN, weight-stationary "
+                            "GEMM, wide weight-gradient tiles); skipped by themselves in a default build")
 
 
 @pytest.fixture(scope="session")

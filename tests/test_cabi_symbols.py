@@ -68,12 +68,20 @@ def test_wide_wgrad_tile_rule_and_splits_on_the_host():
     """m3_wgrad_tile / m3_wgrad_set_wide are host code: the tile rule (128 x 384 for K = 384, 384 x 128 for N = 384, fp16
     only, off by default) and the split heuristic that goes with it (256 one-per-CU slots; grouped calls with many tiles
     prefer one unit per expert) - and the slab workspace the planner reserves always covers what the kernel indexes"""
+    import pytest
     import torch
-    from m3vit_amd import ops
+    from m3vit_amd import _lib, ops
     h = torch.float16
+    assert ops.wgrad_tile(1536, 384, h) == (128, 128)
+    # the default split rule follows the kernel's workgroups per CU: 1024 slots for the LDS-DMA kernel (16-bit), 512 for fp32
+    assert ops.default_wgrad_splits(25216, 1536, 384, 1, h) == 28 and ops.default_wgrad_splits(25216, 1536, 384, 1, torch.float32) == 14
+    assert ops.default_wgrad_splits(38432, 3072, 768, 16, h) == 1                  # the ViT-Base experts: tiles fill the chip -> direct mode
+    if not _lib.lib().m3_experimental():
+        with pytest.raises(_lib.M3Error):
+            ops.wgrad_set_wide(1)                                                   # the wide kernel is not in a default build
+        return
     try:
         ops.wgrad_set_wide(0)
-        assert ops.wgrad_tile(1536, 384, h) == (128, 128) and ops.default_wgrad_splits(25216, 1536, 384, 1, h) == 14
         ops.wgrad_set_wide(1)
         assert ops.wgrad_tile(1536, 384, h) == (128, 384) and ops.wgrad_tile(384, 1536, h) == (384, 128)
         assert ops.wgrad_tile(384, 384, h) == (128, 128) and ops.wgrad_tile(1536, 384, torch.float32) == (128, 128)

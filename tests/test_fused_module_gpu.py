@@ -540,3 +540,109 @@ def test_fused_module_with_sharded_experts_two_ranks_one_gpu():
     for p in procs:
         p.join(timeout=30)
     assert all(r[1] == "ok" for r in res), res
+
+
+def test_fused_module_backward_capture_after_a_dropped_forward_and_an_evaluation_pass():
+    """a forward is captured, its output dropped (no backward), another Python-level forward runs on the same
+    context (an evaluation pass, another task) - the backward graph captured afterwards must not read that other forward's
+    routing tensors: the step after the interleave equals the per-op path's."""
+    _need_gpu()
+    m, cfg = _model()
+    ref, _ = _model(fused=False)
+    ref.load_state_dict(m.state_dict())
+    img = torch.randn(3, 3, 32, 48).cuda()
+    img2 = torch.randn(3, 3, 32, 48).cuda()
+    dtok = (torch.randn(3, cfg.num_tokens, 64) * 0.1).cuda()
+
+    def one(model, x, task):
+        tok, cv = model(x, task_id=task)
+        ((tok * dtok).sum() + 0.01 * cv).backward()
+
+    m.zero_grad(set_to_none=True)
+    one(m, img, 0)                                        # call 1 of task 0 on slot 0: eager
+    m.zero_grad(set_to_none=True)
+    tok, cv = m(img, task_id=0)                           # call 2: the forward graph is captured ...
+    del tok, cv                                           # ... and its output dropped: no backward, no backward graph
+    m.eval()
+    with torch.no_grad():
+        m(img2, task_id=1)                                # another Python-level forward on the freed context
+        m(img2, task_id=1)                                # (and its evaluation graph)
+    m.train()
+    tok, cv = m(img2, task_id=1)                          # yet another one: task 1, eager, dropped
+    del tok, cv
+    m.zero_grad(set_to_none=True)
+    one(m, img, 0)                                        # task 0 again: replayed forward, backward captured NOW
+    torch.cuda.synchronize()
+    got = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+    ref.zero_grad(set_to_none=True)
+    one(ref, img, 0)
+    for n, p in ref.named_parameters():
+        if p.grad is not None and float(p.grad.abs().max()) > 0:
+            assert rel(got[n], p.grad) < 1e-5, n
+    m.zero_grad(set_to_none=True)
+    one(m, img, 0)                                        # and the replayed pair stays right
+    torch.cuda.synchronize()
+    for n, p in ref.named_parameters():
+        if p.grad is not None and float(p.grad.abs().max()) > 0:
+            assert rel(dict(m.named_parameters())[n].grad, p.grad) < 1e-5, n
+
+
+def test_fused_module_survives_an_exception_in_the_backward_pass_and_frozen_parameters():
+    """(1) a backward pass that raises behind the fused node never runs the end-of-backward callback: the next
+    step must still hand finished gradients to the caller's stream; (2) frozen parameters keep .grad = None; (3) images that
+    require a gradient take the per-op path."""
+    _need_gpu()
+    m, cfg = _model()
+    ref, _ = _model(fused=False)
+    ref.load_state_dict(m.state_dict())
+    img = torch.randn(3, 3, 32, 48).cuda()
+    dtok = (torch.randn(3, cfg.num_tokens, 64) * 0.1).cuda()
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    def step(model, fail=False):
+        loss = 0.0
+        for task in (0, 1):
+            tok, cv = model(img, task_id=task)
+            if fail and task == 0:
+                tok = Boom.apply(tok)
+            loss = loss + (tok * dtok).sum() + 0.01 * cv
+        loss.backward()
+
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        step(m)
+    m.zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError, match="boom"):
+        step(m, fail=True)
+    m.zero_grad(set_to_none=True)
+    step(m)                                               # a trainer that caught the exception and went on
+    g = {n: p.grad.detach().clone() for n, p in m.named_parameters()}       # (read on the caller's stream, no synchronize)
+    ref.zero_grad(set_to_none=True)
+    step(ref)
+    for n, p in ref.named_parameters():
+        if p.grad is not None and float(p.grad.abs().max()) > 0:
+            assert rel(g[n], p.grad) < 1e-5, n
+    # frozen parameters
+    frozen = [p for n, p in m.named_parameters() if n.startswith("blocks.0.")]
+    for p in frozen:
+        p.requires_grad_(False)
+    m.zero_grad(set_to_none=True)
+    step(m)
+    assert all(p.grad is None for p in frozen)
+    assert all(p.grad is not None for n, p in m.named_parameters() if p.requires_grad)
+    for p in frozen:
+        p.requires_grad_(True)
+    # images that require a gradient: per-op path, with a gradient
+    x = img.clone().requires_grad_()
+    tok, cv = m(x, task_id=0)
+    assert m.fused_fallback_reason is not None and "images require" in m.fused_fallback_reason
+    (tok * dtok).sum().backward()
+    assert x.grad is not None and float(x.grad.abs().max()) > 0

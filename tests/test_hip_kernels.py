@@ -239,7 +239,10 @@ def test_wgrad_queue_rides_the_reduction_on_the_next_launch(ops):
             ops.wgrad_tn(c["dC"], c["A"], dW, beta=1, db=db, queue=queue, **c["kw"])
             outs.append((dW, db))
         if queue is not None:
-            assert queue.pending is not None
+            # (the last call contracts over few rows: one part per group, so it accumulates into dW itself - direct mode -
+            # and leaves nothing pending; with M3_WGRAD_DIRECT=0 its reduction is the one flush() runs)
+            import m3vit_amd.ops as O
+            assert queue.pending is not None or O._WGRAD_DIRECT
             queue.flush()
             assert queue.pending is None
         torch.cuda.synchronize()
