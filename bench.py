@@ -95,6 +95,9 @@ def parse():
                     "capacity of this multiple of the uniform share per (source, destination) pair (e.g. 1.25) instead of the exact "
                     "a2a-v: no host read inside the step, one flag read at its end, the step repeated on the exact path on overflow "
                     "(MultiTaskStep ep_capacity); default 0 = exact exchange")
+    ap.add_argument("--ep-chunks", type=int, default=2, help="N > 1: the third leg \"ep_overlap\" cuts every expert-parallel exchange "
+                    "into this many chunks of local experts and overlaps them with the experts' GEMMs inside one pass (MultiTaskStep "
+                    "ep_chunks; same results bit for bit); 1 = no such leg")
     ap.add_argument("--dp-only", action="store_true", help="N > 1: time only the replicated-experts data-parallel form")
     ap.add_argument("--no-f32", action="store_true", help="N = 1: skip the fp32 run reported as the sub-object \"f32\"")
     ap.add_argument("--module-path", action="store_true", help="N = 1: time ONLY the drop-in module path (install_fmoe_shim() + "
@@ -243,7 +246,7 @@ def main():
     coll = {"nccl": "RCCL"}.get(backend, backend)
 
     def run_mode(dtype_name, expert_parallel, want_roofline, share_stem=False, workload=None, batch=None, skew=None, steps=None,
-                 warmup=None):
+                 warmup=None, ep_chunks=1):
         """One timed configuration: W untimed warm-up steps, exactly K timed steps between barriers, max over ranks.
         Returns the fields of the JSON line that depend on the mode."""
         wl = WORKLOADS[args.config if workload is None else workload]
@@ -261,7 +264,8 @@ def main():
                                parallel_tasks=not args.serial_tasks, graph=not args.no_graph, world=world, rank=rank,
                                expert_parallel=expert_parallel, wgrad_streams=args.wgrad_streams, dp_parts=args.dp_parts,
                                checkpoint=args.checkpoint, share_stem=share_stem,
-                               ep_capacity=args.ep_capacity if expert_parallel else 0.0)
+                               ep_capacity=args.ep_capacity if expert_parallel else 0.0,
+                               ep_chunks=ep_chunks if expert_parallel else 1)
         use_ep, par_tasks, ntasks = runner.use_ep, runner.par or runner.par_ep, len(runner.tasks)
         g = torch.Generator().manual_seed(1000 + rank)          # each rank its own images
         images = torch.randn(batch, 3, *cfg.img_size, generator=g).to(dev)
@@ -316,7 +320,9 @@ def main():
                "task_passes": ntasks, "tokens_per_image": cfg.num_tokens,
                "activation_checkpointing": bool(args.checkpoint), "shared_stem": bool(runner.share_stem),
                "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
-               "ep_exchange": (None if not use_ep else ("exact a2a-v (2 W split sizes read per MoE layer and pass)" if not runner.ep_capacity
+               "ep_exchange": (None if not use_ep else ((f"exact a2a-v in {runner.ep_chunks} chunks of local experts, overlapped with the expert "
+                                                         "GEMMs inside a pass" if runner.ep_chunks > 1 else
+                                                         "exact a2a-v (2 W split sizes read per MoE layer and pass)") if not runner.ep_capacity
                                else f"fixed capacity {runner.ep_capacity} x R / W per pair, {runner.ep_repeats} step(s) repeated on the exact path")),
                "parallelism": "single" if world == 1 else (f"dp{world}+ep{world} (experts sharded, {coll} all-to-all + all-reduce)"
                                                             if use_ep else f"dp{world} (replicated experts, {coll} all-reduce)")}
@@ -571,6 +577,8 @@ def main():
             legs.append(("dp", False, lambda: run_mode(args.dtype, False, False, share_stem=False), DP_WATCHDOG_S))
         if want_ep:
             legs.append(("ep", True, lambda: run_mode(args.dtype, True, False), EP_WATCHDOG_S))
+            if args.ep_chunks > 1 and not args.ep_capacity and (E // world) % args.ep_chunks == 0:
+                legs.append(("ep_overlap", "ep_overlap", lambda: run_mode(args.dtype, True, False, ep_chunks=args.ep_chunks), EP_WATCHDOG_S))
         if want_dp and args.share_stem and not args.serial_tasks:
             legs.append(("dp_shared_stem", "dp_shared_stem", lambda: run_mode(args.dtype, False, False, share_stem=True),
                          SHARED_WATCHDOG_S))
@@ -623,8 +631,8 @@ def main():
         # ~3.7 GB of routed rows per step and rank through the xGMI links (DESIGN.md section 6 has the predicted table) where
         # data parallelism moves one 172 MB gradient all-reduce - north_star asks for the all-to-all "only where experts shard"
         # (the shared-stem leg is reported, and eligible as the primary only with --share-stem: same policy as at N = 1)
-        ran = [r for r in (results.get(True), results.get(False), results.get("dp_shared_stem") if args.share_stem else None)
-               if r is not None]
+        ran = [r for r in (results.get(True), results.get("ep_overlap"), results.get(False),
+                           results.get("dp_shared_stem") if args.share_stem else None) if r is not None]
         main_res = max(ran, key=lambda r: r["value"]) if ran else None
         if main_res is None:
             if rank == 0:

@@ -44,7 +44,7 @@ class BackboneEngine:
     def __init__(self, cfg, params: Dict[str, torch.Tensor], batch: int, dtype=torch.float16,
                  device="cuda:0", ep_group=None, ep_world: int = 1, ep_rank: int = 0, share: "BackboneEngine" = None,
                  wgrad_stream: bool = False, checkpoint: bool = False, ep_capacity: float = 0.0,
-                 experts_are_local: bool = False):
+                 experts_are_local: bool = False, ep_chunks: int = 1):
         """params: GLOBAL parameters (all E experts).  With ep_world > 1 this rank keeps experts
         [ep_rank*E/W, (ep_rank+1)*E/W) (utils/common_config.py:179-185) and exchanges routed rows with
         the other ranks over torch.distributed (RCCL) - see _experts_fwd_ep.
@@ -67,6 +67,9 @@ class BackboneEngine:
         of one per MoE layer and pass, and a step that a collective library can capture.  A pair that routes more rows than
         the capacity raises the flag; the step's results are then incomplete and the caller repeats it on the exact path
         (MultiTaskStep does).
+        ep_chunks (with ep_world > 1, exact exchange; 1 = one all-to-all-v each way): cut every exchange into this many
+        chunks of E_loc / ep_chunks local experts (on every destination) and overlap them with the experts' GEMMs inside ONE
+        pass - see _experts_fwd_ep_chunked.  Same results bit for bit.
         experts_are_local (with ep_world > 1): the expert tensors in `params` are already this rank's slice [E / W, ..] (a
         module built the way utils/common_config.py:179-185 builds it: moe_experts // world_size experts per rank) and are
         taken as they are - in place - instead of being cut out of global tensors."""
@@ -97,6 +100,8 @@ class BackboneEngine:
         self.depth = cfg.depth
         assert self.E % self.ep_world == 0, "experts must divide evenly over the EP ranks"
         self.E_loc = self.E // self.ep_world
+        self.ep_chunks = int(ep_chunks) if (self.ep_world > 1 and int(ep_chunks) > 1) else 1
+        assert self.E_loc % self.ep_chunks == 0, "ep_chunks must divide the experts per rank"
         is_exp = lambda n: ".mlp.experts." in n                                  # noqa: E731
         lo, hi = self.ep_rank * self.E_loc, (self.ep_rank + 1) * self.E_loc
         if share is not None:
@@ -261,6 +266,17 @@ class BackboneEngine:
             self.ep_regroup = {i: torch.empty(self.ep_world * R, dtype=torch.int32, device=self.dev)
                                for i in range(self.depth) if self.is_moe[i]}
             self.ep_splits_host = torch.empty(2 * self.ep_world, dtype=torch.int64, pin_memory=True)
+            if self.ep_chunks > 1:
+                # chunked exchange: rows are routed by a CHUNK-MAJOR key - (chunk of the local expert, destination rank,
+                # expert inside the chunk) - so that what goes to every rank for one chunk of its experts is one
+                # contiguous run of the send buffer, in destination order (one all_to_all_single per chunk)
+                C, W, Ec = self.ep_chunks, self.ep_world, self.E_loc // self.ep_chunks
+                e = torch.arange(self.E)
+                d_, rest = e // self.E_loc, e % self.E_loc
+                self.ep_key = ((rest // Ec) * (W * Ec) + d_ * Ec + rest % Ec).to(torch.int32).to(self.dev)
+                self.ep_regroup_c = {i: torch.empty(C, W * R, dtype=torch.int32, device=self.dev)
+                                     for i in range(self.depth) if self.is_moe[i]}
+                self.ep_splits_host_c = torch.empty(C, 2 * W, dtype=torch.int64, pin_memory=True)
             if self.ep_capacity:
                 W = self.ep_world
                 self.ep_cap = -(-int(self.ep_capacity * R + W - 1) // W)                # rows per (source, destination) pair
@@ -523,6 +539,8 @@ class BackboneEngine:
         p, k, D, dev = self.params, self.k, self.D, self.dev
         if self.ep_fixed:
             return self._experts_fwd_ep_fixed(i, a, g)
+        if self.ep_chunks > 1 and not recompute:
+            return self._experts_fwd_ep_chunked(i, a, g)
         if recompute:
             ep = a["ep"]
             n = ep["n"]
@@ -560,6 +578,118 @@ class BackboneEngine:
         if self.checkpoint:                                          # local hidden activations: recomputed in backward
             ep["hid_pre"] = ep["hid"] = None
         a["ep"] = ep
+
+    # ------------------------------------------------------------------ expert parallel, exchange overlapped inside ONE pass
+    def _a2a_async(self, out, x, out_splits, in_splits):
+        import torch.distributed as dist
+        return dist.all_to_all_single(out, x, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.ep_group,
+                                      async_op=True)
+
+    def _experts_fwd_ep_chunked(self, i, a, g):
+        """_experts_fwd_ep with every exchange cut into ep_chunks all-to-all-v's, chunk c = the rows for local experts
+        [c E_loc / C, (c + 1) E_loc / C) of EVERY rank (custom_moe_layer.py:263-265): all chunks' row
+        exchanges are queued on the collective library's stream at once; the grouped FC1 / FC2 of chunk c start when ITS rows
+        have arrived - the later chunks are still in flight - and its outputs start their way home under the next chunk's GEMMs.
+        Exposed per direction: one chunk's exchange instead of the whole.  The count exchange and the plans (C m3_ep_plan
+        launches, ONE host read of the C * 2 W split sizes) are as before.  What the backward and a checkpoint recompute need
+        is kept in the unchunked form - one received buffer (the chunks side by side), one regroup index, offsets and tile
+        prefix over all local experts - so every row keeps its expert-major position and the results are bit-identical to the
+        one-exchange path."""
+        import torch.distributed as dist
+        b = f"blocks.{i}."
+        p, k, D, dev = self.params, self.k, self.D, self.dev
+        C, W = self.ep_chunks, self.ep_world
+        Ec = self.E_loc // C
+        key = self.ep_key[g["idx32"].reshape(-1).long()].view(-1, k).contiguous()          # chunk-major routing keys
+        r = ops.route_build(key, self.E, want_counts64=True)
+        a["route"] = r
+        x_send = self._e(self.R, D)
+        ops.gather_rows(a["h2"], r.row_of_slot, x_send, div=k)
+        send = r.counts64.view(C, W, Ec)
+        snd_dm = send.permute(1, 0, 2).contiguous()                                         # destination-major for the count exchange
+        rcv_dm = torch.empty_like(snd_dm)
+        dist.all_to_all_single(rcv_dm.view(-1), snd_dm.view(-1), group=self.ep_group)
+        recv = rcv_dm.permute(1, 0, 2).contiguous()                                         # [C][source][expert of the chunk]
+        plans = ops.ep_plan_chunks(send.contiguous(), recv, W, Ec, self.ep_regroup_c[i], self.ep_splits_host_c)
+        ns = [sum(pl.in_splits) for pl in plans]
+        nr = [pl.n_recv for pl in plans]
+        sb = [sum(ns[:c]) for c in range(C + 1)]
+        rb = [sum(nr[:c]) for c in range(C + 1)]
+        n = rb[C]
+        x_recv, y_recv = self._e(n, D), self._e(n, D)
+        hid_pre, hid = self._e(n, self.Hm), self._e(n, self.Hm)
+        y_send = self._e(self.R, D)
+        works = [self._a2a_async(x_recv[rb[c]:rb[c + 1]], x_send[sb[c]:sb[c + 1]], plans[c].out_splits, plans[c].in_splits)
+                 for c in range(C)]
+        back = []
+        w1, b1 = self.wc[b + "mlp.experts.htoh4"], p[b + "mlp.experts.htoh4.bias"]
+        w2, b2 = self.wc[b + "mlp.experts.h4toh"], p[b + "mlp.experts.h4toh.bias"]
+        for c in range(C):
+            works[c].wait()
+            pl, es = plans[c], slice(c * Ec, (c + 1) * Ec)
+            if nr[c] > 0:
+                ops.gemm_nt(x_recv[rb[c]:rb[c + 1]], w1[es], hid[rb[c]:rb[c + 1]], M=nr[c], bias=b1[es], act=M3_ACT_GELU,
+                            pre_out=hid_pre[rb[c]:rb[c + 1]], a_row_idx=pl.regroup, a_row_div=1, group_offsets=pl.offsets,
+                            tile_starts=pl.tile_starts)
+                ops.gemm_nt(hid[rb[c]:rb[c + 1]], w2[es], y_recv[rb[c]:rb[c + 1]], M=nr[c], bias=b2[es], c_row_idx=pl.regroup,
+                            group_offsets=pl.offsets, tile_starts=pl.tile_starts)
+            back.append(self._a2a_async(y_send[sb[c]:sb[c + 1]], y_recv[rb[c]:rb[c + 1]], pl.in_splits, pl.out_splits))
+        # the unchunked view of the plan for the backward / a checkpoint recompute: chunk c's rows sit at rb[c] of the received
+        # buffer and its experts at c * Ec of the local experts
+        rg = torch.cat([plans[c].regroup + rb[c] for c in range(C)]) if n else self.ep_regroup_c[i][0, :0]
+        offs = torch.cat([plans[c].offsets[:-1] + rb[c] for c in range(C)] +
+                         [torch.full((1,), n, dtype=torch.int32, device=dev)])
+        tb = [0]
+        tsc = [plans[c].tile_starts for c in range(C)]
+        ts_all, base_t = [], torch.zeros((), dtype=torch.int32, device=dev)
+        for c in range(C):
+            ts_all.append(tsc[c][:-1] + base_t)
+            base_t = base_t + tsc[c][-1]
+        ts_all.append(base_t.reshape(1))
+        ep = dict(plan=None, chunked=True, plans=plans, sb=sb, rb=rb, n=n, rg=rg.contiguous(), offsets=offs.contiguous(),
+                  tile_starts=torch.cat(ts_all).contiguous(), x_recv=x_recv, hid_pre=hid_pre, hid=hid)
+        for w_ in back:
+            w_.wait()
+        ops.gather_rows(y_send, r.pos, a["y"])                       # back to token-major [T*k, D]
+        if self.checkpoint:                                          # local hidden activations: recomputed in backward
+            ep["hid_pre"] = ep["hid"] = None
+        a["ep"] = ep
+
+    def _experts_bwd_ep_chunked(self, i, a):
+        """mirror of _experts_fwd_ep_chunked: the d y rows travel in the same chunks; chunk c's input-gradient GEMMs run while the
+        later chunks are in flight and its d x rows go home under the next chunk's GEMMs; the weight gradients (all local
+        experts at once, on the side-by-side buffers - the same launches as the one-exchange path) run last, under the
+        returning exchanges."""
+        b = f"blocks.{i}."
+        D, r, ep = self.D, a["route"], a["ep"]
+        C, Ec = self.ep_chunks, self.E_loc // self.ep_chunks
+        plans, sb, rb, n = ep["plans"], ep["sb"], ep["rb"], ep["n"]
+        dy_send = ops.gather_rows(self.s_dy, r.row_of_slot, self._e(self.R, D))
+        dy_recv, dx_recv, dhp = self._e(n, D), self._e(n, D), self._e(n, self.Hm)
+        dx_send = self._e(self.R, D)
+        works = [self._a2a_async(dy_recv[rb[c]:rb[c + 1]], dy_send[sb[c]:sb[c + 1]], plans[c].out_splits, plans[c].in_splits)
+                 for c in range(C)]
+        back = []
+        wt2, wt1 = self.wt[b + "mlp.experts.h4toh"], self.wt[b + "mlp.experts.htoh4"]
+        for c in range(C):
+            works[c].wait()
+            pl, es = plans[c], slice(c * Ec, (c + 1) * Ec)
+            rows = slice(rb[c], rb[c + 1])
+            if rb[c + 1] > rb[c]:
+                ops.gemm_nt(dy_recv[rows], wt2[es], dhp[rows], M=rb[c + 1] - rb[c], gelu_grad_pre=ep["hid_pre"][rows],
+                            a_row_idx=pl.regroup, a_row_div=1, group_offsets=pl.offsets, tile_starts=pl.tile_starts)
+                ops.gemm_nt(dhp[rows], wt1[es], dx_recv[rows], M=rb[c + 1] - rb[c], c_row_idx=pl.regroup,
+                            group_offsets=pl.offsets, tile_starts=pl.tile_starts)
+            back.append(self._a2a_async(dx_send[sb[c]:sb[c + 1]], dx_recv[rows], pl.in_splits, pl.out_splits))
+        if n > 0:
+            rg = ep["rg"]
+            self._wgrad(dy_recv, ep["hid"], b + "mlp.experts.h4toh.weight", M=n, c_row_idx=rg,
+                        group_offsets=ep["offsets"], bias=b + "mlp.experts.h4toh.bias")
+            self._wgrad(dhp, ep["x_recv"], b + "mlp.experts.htoh4.weight", M=n, a_row_idx=rg, a_row_div=1,
+                        group_offsets=ep["offsets"], bias=b + "mlp.experts.htoh4.bias")
+        for w_ in back:
+            w_.wait()
+        ops.gather_rows(dx_send, r.pos, self.s_dxe)
 
     def _a2a_equal(self, x, out):
         """all-to-all with equal splits (the fixed-capacity exchange): no sizes, nothing for the host to read"""
@@ -628,6 +758,8 @@ class BackboneEngine:
         self.s_dxe (token-major d of the routed input copies)."""
         if a["ep"].get("fixed"):
             return self._experts_bwd_ep_fixed(i, a)
+        if a["ep"].get("chunked"):
+            return self._experts_bwd_ep_chunked(i, a)
         b = f"blocks.{i}."
         k, D, r, ep = self.k, self.D, a["route"], a["ep"]
         plan, n = ep["plan"], ep["n"]

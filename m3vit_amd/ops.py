@@ -211,6 +211,40 @@ def ep_plan(send_counts64, recv_counts64, world: int, e_loc: int, regroup_buf: t
     return p
 
 
+def ep_plan_chunks(send_counts64, recv_counts64, world: int, e_chunk: int, regroup_bufs: torch.Tensor, splits_host=None):
+    """The plans of an exchange cut into C chunks of e_chunk local experts each (send / recv counts laid out
+    [C][world][e_chunk]: the routing keys are chunk-major, BackboneEngine ep_chunks): C m3_ep_plan launches, then ONE host read
+    of all C * 2 * world split sizes.  regroup_bufs: i32 [C, capacity].  Returns a list of EpPlan."""
+    _req(send_counts64, torch.int64, "send_counts"); _req(recv_counts64, torch.int64, "recv_counts")
+    _req(regroup_bufs, torch.int32, "regroup_bufs")
+    C = regroup_bufs.shape[0]
+    assert send_counts64.numel() == C * world * e_chunk == recv_counts64.numel()
+    dev = send_counts64.device
+    send, recv = send_counts64.view(C, world * e_chunk), recv_counts64.view(C, world * e_chunk)
+    splits = torch.empty(C, 2 * world, dtype=torch.int64, device=dev)
+    plans = []
+    for c in range(C):
+        p = EpPlan()
+        p.splits = splits[c]
+        p.offsets = torch.empty(e_chunk + 1, dtype=torch.int32, device=dev)
+        p.tile_starts = torch.empty(e_chunk + 1, dtype=torch.int32, device=dev)
+        check(lib().m3_ep_plan(_p(send[c]), _p(recv[c]), world, e_chunk, _p(p.splits), _p(regroup_bufs[c]),
+                               regroup_bufs.shape[1], _p(p.offsets), _p(p.tile_starts), _stream()), "m3_ep_plan")
+        plans.append(p)
+    if splits_host is None:
+        splits_host = torch.empty(C, 2 * world, dtype=torch.int64, pin_memory=True)
+    splits_host.copy_(splits, non_blocking=True)
+    torch.cuda.current_stream().synchronize()          # the one host read of the exchange: C * 2 * world integers
+    sp = splits_host.tolist()
+    for c, p in enumerate(plans):
+        p.in_splits, p.out_splits = sp[c][:world], sp[c][world:]
+        p.n_recv = sum(p.out_splits)
+        if p.n_recv > regroup_bufs.shape[1]:
+            raise _lib.M3Error(f"ep_plan_chunks: {p.n_recv} received rows exceed the regroup buffer ({regroup_bufs.shape[1]})")
+        p.regroup = regroup_bufs[c, : p.n_recv]
+    return plans
+
+
 class EpPlanFixed:
     """Device-resident plan of a fixed-capacity exchange (m3_ep_plan_fixed): nothing of it is read by the host."""
     __slots__ = ("cap", "world", "regroup", "offsets", "tile_starts", "pad_idx", "unpad_idx", "splits")

@@ -28,7 +28,7 @@ class MultiTaskStep:
     def __init__(self, cfg, params, batch: int, dtype=torch.float16, device="cuda:0", tasks=None, cv_weight: float = 0.01,
                  parallel_tasks: bool = True, graph: bool = True, world: int = 1, rank: int = 0, expert_parallel: bool = False,
                  wgrad_streams: bool = False, dp_parts: int = 6, checkpoint: bool = False, share_stem: bool = False,
-                 ep_capacity: float = 0.0):
+                 ep_capacity: float = 0.0, ep_chunks: int = 1):
         """ep_capacity (expert parallel only; 0 = the exact exchange): fixed row capacity of the exchange as a multiple of
         the uniform share R / W per (source, destination) pair (BackboneEngine ep_capacity).  The step then reads ONE flag
         on the host, at its end, instead of 2 W split sizes per MoE layer and pass, and repeats itself on the exact path
@@ -40,10 +40,15 @@ class MultiTaskStep:
         self.use_ep = bool(expert_parallel) and self.world > 1
         wg = bool(wgrad_streams) and not self.use_ep
         self.ep_capacity = float(ep_capacity) if self.use_ep else 0.0
+        # exact exchange cut into chunks of local experts and overlapped with the experts' GEMMs inside one pass
+        # (BackboneEngine ep_chunks; only where the experts per rank divide)
+        E_loc = cfg.moe_experts // max(1, int(world))
+        self.ep_chunks = int(ep_chunks) if (self.use_ep and not self.ep_capacity and int(ep_chunks) > 1 and
+                                            E_loc % int(ep_chunks) == 0) else 1
         self.ep_repeats = 0                              # steps repeated on the exact path after a capacity overflow
         self.eng = BackboneEngine(cfg, params, batch=batch, dtype=dtype, device=str(self.dev),
                                   ep_world=self.world if self.use_ep else 1, ep_rank=rank if self.use_ep else 0,
-                                  wgrad_stream=wg, checkpoint=checkpoint, ep_capacity=self.ep_capacity)
+                                  wgrad_stream=wg, checkpoint=checkpoint, ep_capacity=self.ep_capacity, ep_chunks=self.ep_chunks)
         self.par = bool(parallel_tasks) and not self.use_ep and len(self.tasks) > 1
         # expert parallel: the task passes still get their own engine contexts and streams, but their blocks are
         # interleaved on the host (_ep_interleaved): each pass stops once per MoE layer to read its exchange's split
@@ -51,7 +56,7 @@ class MultiTaskStep:
         self.par_ep = bool(parallel_tasks) and self.use_ep and len(self.tasks) > 1
         self.engs = [self.eng] + ([BackboneEngine(cfg, None, batch=batch, dtype=dtype, device=str(self.dev), share=self.eng,
                                                    ep_world=self.world if self.use_ep else 1, ep_rank=rank if self.use_ep else 0,
-                                                   wgrad_stream=wg, checkpoint=checkpoint, ep_capacity=self.ep_capacity)
+                                                   wgrad_stream=wg, checkpoint=checkpoint, ep_capacity=self.ep_capacity, ep_chunks=self.ep_chunks)
                                     for _ in self.tasks[1:]]
                                     if (self.par or self.par_ep) else [])
         # (measured and dropped in round 3, profiles/r03_stream_experiments.txt: a high-priority side stream serialises the

@@ -111,6 +111,29 @@ class DropPath(nn.Module):
         return x * scale
 
 
+class _Im2Row(torch.autograd.Function):
+    """patchify (m3_im2row): images [B, C, H, W] -> rows [B * patches, C * P * P].  The patches do not overlap, so the
+    gradient with respect to the images (the reference's Conv2d provides one; no trainer of the reference asks for it) is the
+    inverse permutation of d rows - only computed when the images require a gradient."""
+
+    @staticmethod
+    def forward(ctx, x, P, num_patches, act_dtype):
+        from . import ops
+        B, C, H, W = x.shape
+        rows = torch.empty(B * num_patches, C * P * P, dtype=act_dtype, device=x.device)
+        ops.im2row(x.detach().contiguous().float(), P, rows)
+        ctx.geom = (B, C, H, W, P, x.dtype)
+        return rows
+
+    @staticmethod
+    def backward(ctx, d_rows):
+        B, C, H, W, P, dt = ctx.geom
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None
+        d = d_rows.float().view(B, H // P, W // P, C, P, P).permute(0, 3, 1, 4, 2, 5).reshape(B, C, H, W)
+        return d.to(dt), None, None, None
+
+
 class PatchEmbed(nn.Module):
     def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
         super().__init__()
@@ -123,12 +146,10 @@ class PatchEmbed(nn.Module):
     def forward(self, x, act_dtype=torch.float32):
         """-> [B, num_patches, D] (the reference returns the conv map; flatten(2).transpose(1,2) is done
         by the caller at :783-784 - folded in here)."""
-        from . import ops
         B, C, H, W = x.shape
         assert H == self.img_size[0] and W == self.img_size[1]
         P = self.patch_size[0]
-        rows = torch.empty(B * self.num_patches, C * P * P, dtype=act_dtype, device=x.device)
-        ops.im2row(x.contiguous().float(), P, rows)
+        rows = _Im2Row.apply(x, P, self.num_patches, act_dtype)
         w2 = self.proj.weight.reshape(self.proj.weight.shape[0], -1)
         y = PlainLinearFn.apply(rows, w2, self.proj.bias)
         return y.view(B, self.num_patches, -1)

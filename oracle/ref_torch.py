@@ -55,7 +55,7 @@ def gate_vmoe(x: torch.Tensor, w_gate: torch.Tensor, top_k: int,
     score = top_logits[:, :top_k]
     idx = top_idx[:, :top_k]
     if idx_override is not None:
-        idx = idx_override.to(torch.int64)
+        idx = idx_override.to(device=p.device, dtype=torch.int64)
         score = p.gather(1, idx)
     gates = torch.zeros_like(p).scatter(1, idx, score)
     return (idx, score), clean, noisy, std, top_logits, gates
@@ -73,11 +73,11 @@ def prob_in_top_k(clean, noisy, noise_stddev, noisy_top_values, top_k):
     batch = clean.size(0)
     m = noisy_top_values.size(1)
     flat = noisy_top_values.flatten()
-    pos_in = torch.arange(batch) * m + top_k
+    pos_in = torch.arange(batch, device=clean.device) * m + top_k
     thr_in = flat.gather(0, pos_in).unsqueeze(1)
     is_in = noisy > thr_in
     thr_out = flat.gather(0, pos_in - 1).unsqueeze(1)
-    normal = Normal(torch.tensor([0.0], dtype=clean.dtype), torch.tensor([1.0], dtype=clean.dtype))
+    normal = Normal(torch.tensor([0.0], dtype=clean.dtype, device=clean.device), torch.tensor([1.0], dtype=clean.dtype, device=clean.device))
     p_in = normal.cdf((clean - thr_in) / noise_stddev)
     p_out = normal.cdf((clean - thr_out) / noise_stddev)
     return torch.where(is_in, p_in, p_out)
@@ -87,7 +87,7 @@ def cv_squared(x: torch.Tensor) -> torch.Tensor:
     """cv_squared, models/moe/ckpt/vision_transformer_moe.py:73-87:
     unbiased var / (mean^2 + 1e-10); zero for a single expert."""
     if x.shape[0] == 1:
-        return torch.zeros((), dtype=torch.float32)
+        return torch.zeros((), dtype=torch.float32, device=x.device)
     xf = x.float() if x.dtype not in (torch.float32, torch.float64) else x
     return xf.var() / (xf.mean() ** 2 + 1e-10)
 
@@ -105,11 +105,11 @@ def route_build(idx: torch.Tensor, num_expert: int):
     """
     flat = idx.reshape(-1).to(torch.int64)
     counts = torch.bincount(flat, minlength=num_expert)
-    offsets = torch.zeros(num_expert + 1, dtype=torch.int64)
+    offsets = torch.zeros(num_expert + 1, dtype=torch.int64, device=flat.device)
     offsets[1:] = counts.cumsum(0)
     row_of_slot = torch.sort(flat, stable=True).indices
     pos = torch.empty_like(row_of_slot)
-    pos[row_of_slot] = torch.arange(flat.numel(), dtype=torch.int64)
+    pos[row_of_slot] = torch.arange(flat.numel(), dtype=torch.int64, device=flat.device)
     return counts, offsets, pos, row_of_slot
 
 
@@ -214,7 +214,7 @@ def task_embedding(params: Dict[str, torch.Tensor], num_tasks: int, task_id: int
     """gate_task_represent(one_hot(task_id)), vision_transformer_moe.py:793-797 with
     new_Mlp :263-281 (fc1 -> GELU -> fc2 -> LayerNorm eps 1e-6)."""
     p = params
-    one_hot = torch.zeros(num_tasks, dtype=p["gate_task_represent.fc1.weight"].dtype)
+    one_hot = torch.zeros(num_tasks, dtype=p["gate_task_represent.fc1.weight"].dtype, device=p["gate_task_represent.fc1.weight"].device)
     one_hot[task_id] = 1.0
     h = gelu_erf(F.linear(one_hot, p["gate_task_represent.fc1.weight"], p["gate_task_represent.fc1.bias"]))
     h = F.linear(h, p["gate_task_represent.fc2.weight"], p["gate_task_represent.fc2.bias"])
@@ -396,7 +396,7 @@ def _backbone_forward(p, cfg, images, task_id, training, noises, route_override,
     tsf = None
     if task_id is not None and "gate_task_represent.fc1.weight" in p:
         tsf = task_embedding(p, cfg.num_tasks, task_id)
-    total_cv = torch.zeros((), dtype=x.dtype)
+    total_cv = torch.zeros((), dtype=x.dtype, device=x.device)
     aux_all = []
     for i in range(cfg.depth):
         noise = None if noises is None else noises.get(i)

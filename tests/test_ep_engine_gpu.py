@@ -386,3 +386,60 @@ def test_expert_parallel_with_activation_checkpointing_two_ranks_one_gpu():
     for p in procs:
         p.join(timeout=30)
     assert all(r[1] == "ok" for r in res), res
+
+
+def _chunk_worker(rank, world, port, q, case, chunks, checkpoint):
+    """the exchange overlapped inside one pass (BackboneEngine ep_chunks) against the one-exchange expert-parallel engine:
+    same routing, tokens, balance loss and EVERY gradient bit for bit (a row's result does not depend on which chunk
+    carried it, and the weight gradients run on the same expert-major rows in the same launches)"""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from m3vit_amd.config import BackboneConfig, init_params
+        from m3vit_amd.engine import BackboneEngine
+        torch.cuda.set_device(0)
+        c = EP_CASES[case]
+        cfg = BackboneConfig(**c["cfg"])
+        dtype, B = getattr(torch, c["dtype"]), c["B"]
+        P = init_params(cfg, seed=3, zero_bias=False)
+        g = torch.Generator().manual_seed(60 + rank)
+        img = torch.randn(B, 3, *cfg.img_size, generator=g).cuda()
+        dtok = (torch.randn(B, cfg.num_tokens, cfg.embed_dim, generator=g) * 0.1).cuda()
+        one = BackboneEngine(cfg, P, batch=B, dtype=dtype, ep_world=world, ep_rank=rank, checkpoint=checkpoint)
+        cut = BackboneEngine(cfg, P, batch=B, dtype=dtype, ep_world=world, ep_rank=rank, ep_chunks=chunks, checkpoint=checkpoint)
+        assert cut.ep_chunks == chunks
+        for task in (0, 1):
+            t1, cv1 = one.forward(img, task)
+            t2, cv2 = cut.forward(img, task)
+            assert torch.equal(t1, t2) and torch.equal(cv1, cv2), ("forward", task)
+            one.backward(dtok, cv_weight=0.01)
+            cut.backward(dtok, cv_weight=0.01)
+        torch.cuda.synchronize()
+        bad = [n for n in one.grads if not torch.equal(one.grads[n], cut.grads[n])]
+        assert not bad, bad
+        assert float(one.flat_grads.abs().max()) > 0
+        q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,chunks,checkpoint", [("toy_f32", 2, False), ("toy_f32", 2, True), ("config3_vit_base_e64_f16", 2, False),
+                                                    ("config3_vit_base_e64_f16", 4, False), ("config4_vit_base_ratio4_n1201_f16", 2, False)])
+def test_expert_parallel_exchange_overlapped_in_chunks_two_ranks_one_gpu(case, chunks, checkpoint):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chunk_worker, args=(r, 2, port, q, case, chunks, checkpoint)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert all(r[1] == "ok" for r in res), res

@@ -105,7 +105,10 @@ def test_grouped_linear_golden_parallel_linear(ops, dtype):
     R, Dout = x.shape[0], W.shape[1]
     y = torch.empty(R, Dout, dtype=dtype, device=dev())
     ops.gemm_nt(x, W, y, M=R, bias=b, group_offsets=r.offsets, tile_starts=r.tile_starts)
-    tol = TOL[dtype] * (3 if dtype == torch.float16 else 1)
+    # fp16: the golden comes from fp32 operands, the kernel is given their fp16 roundings - torch on the CPU with the same
+    # roundings (operands and output to fp16, fp32 accumulation) sits at 3.6e-4 (y, dx) / 3.0e-4 (dW) / 2.2e-4 (db) of the
+    # golden: the 1e-3 bound holds without a factor
+    tol = TOL[dtype]
     assert rel(y, torch.tensor(g["y"])) < tol
     # dgrad: dx = gy @ W  (NT with the transposed weight copy)
     Wt = W.transpose(1, 2).contiguous()

@@ -714,3 +714,22 @@ def test_head_multi_level_outputs_and_tam_wiring():
     m.eval()                                                             # inference: no TAM outputs, heads return tensors
     out_e, _ = m(x)
     assert set(out_e) == set(tasks)
+
+
+def test_patch_embed_mirror_matches_conv2d_including_the_image_gradient():
+    """PatchEmbed (vision_transformer_moe.py:315-341: Conv2d(kernel = stride = patch)) on m3_im2row + the GEMM: tokens, d weight,
+    d bias and - when the images require it - d images, against torch's convolution in float64"""
+    _need_gpu()
+    from m3vit_amd.vit import PatchEmbed
+    torch.manual_seed(3)
+    pe = PatchEmbed(img_size=(32, 48), patch_size=16, in_chans=3, embed_dim=64).cuda()
+    x = torch.randn(2, 3, 32, 48, device="cuda", requires_grad=True)
+    y = pe(x)
+    g = torch.randn_like(y)
+    (y * g).sum().backward()
+    x64 = x.detach().double().cpu().requires_grad_()
+    w64, b64 = pe.proj.weight.detach().double().cpu().requires_grad_(), pe.proj.bias.detach().double().cpu().requires_grad_()
+    y64 = torch.nn.functional.conv2d(x64, w64, b64, stride=16).flatten(2).transpose(1, 2)
+    (y64 * g.double().cpu()).sum().backward()
+    assert rel(y, y64) < 2e-5 and rel(x.grad, x64.grad) < 2e-5
+    assert rel(pe.proj.weight.grad, w64.grad) < 1e-4 and rel(pe.proj.bias.grad, b64.grad) < 1e-4
