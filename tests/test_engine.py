@@ -11,7 +11,12 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-GRAD_FACTOR = 3     # parameter gradients: relative L2 per tensor <= GRAD_FACTOR * the token bound (see F16_TOL)
+GRAD_FACTOR = 3     # parameter gradients: relative L2 per tensor <= GRAD_FACTOR * the token bound (see F16_TOL).  These are SMALL
+# configurations (a few hundred tokens): a gate matrix's gradient is a sum over few rows and its worst relative error is
+# larger than at the benchmarked size (measured round 5: w_gate 2.0e-3 here, 1.2e-3 at 128 x 224^2).  The yardstick that
+# replaces a hand-picked factor is at full size: tests/test_full_size.py::test_fp16_gradient_error_is_bounded_by_the_
+# reference_amp_arithmetic - every parameter tensor's error <= 1.25 x the error of the reference's own AMP arithmetic
+# (measured worst ratio 0.96; absolute bound there 2e-3).
 # fp16 activations: every stored activation / activation gradient is rounded to 11 bits (2^-11 = 4.9e-4 relative);
 # the residual stream, the statistics and all accumulations stay fp32.  Tokens after a whole backbone come out at
 # 3-5e-4 relative L2 (the BENCHMARKED size: tests/test_full_size.py, bound 1e-3 = north_star); gradients see the
