@@ -227,8 +227,8 @@ int m3_gemm_nt(const m3_gemm_args *args, void *stream);
 int m3_gemm_set_variant(int ws_mask);
 /* Tuning knob, no reference counterpart: which calls of m3_gemm_nt take the 256 x 256-tile kernel for long contractions
  * (16-bit operands, K * 2 bytes a multiple of 128 and >= 1024, at most 64 groups; csrc/gemm_big.hip - the ViT-Base shapes
- * of BASELINE configs[3] / configs[4]).  0 never, 1 every call the kernel can run, 2 (default) those that also have enough
- * tiles to fill the chip about twice; -1 re-reads M3_GEMM_BIG from the environment.  Results are the same up to fp32
+ * of BASELINE configs[3] / configs[4]).  0 never, 1 every call the kernel can run, 2 (default) those where it measured faster
+ * with streamed operands: K >= 2048 and at least 96 tiles; -1 re-reads M3_GEMM_BIG from the environment.  Results are the same up to fp32
  * summation order either way. */
 int m3_gemm_set_big(int mode);
 
@@ -322,10 +322,12 @@ int m3_wgrad_tn(const m3_wgrad_args *args, void *stream);
  * (default: measured no faster inside the training step), -1 = re-read M3_WGRAD_WIDE from the environment.  Switch it
  * before sizing any workspace. */
 int m3_wgrad_set_wide(int on);
-/* Tuning knob, no reference counterpart: 1 (default) = 16-bit weight-gradient launches without a per-row factor take the
- * LDS-DMA kernel (wgrad_dma_kernel, csrc/wgrad.hip: four workgroups per CU, operands global -> LDS directly), 0 = the
- * register-staged kernel everywhere, -1 = re-read M3_WGRAD_DMA from the environment.  Same results up to fp32 summation
- * order (64 instead of 32 contraction rows per accumulation step). */
+/* Tuning knob, no reference counterpart: which weight-gradient launches take the LDS-DMA kernel (wgrad_dma_kernel,
+ * csrc/wgrad.hip: four workgroups per CU, operands global -> LDS directly; fp16 / bf16 / fp32, power-of-two gather divisors, a
+ * per-row factor with fp16 / fp32 only).  0 = none (the register-staged kernel everywhere), 2 = every launch the kernel can
+ * run, 1 (default) = those where it measured faster with operands streamed from HBM: fp32 always; 16-bit when tiles x groups
+ * >= 1024 (one part per group: the ViT-Base experts) or N * K >= 1.5 M elements.  -1 = re-read M3_WGRAD_DMA.  Same results up to
+ * fp32 summation order (64 instead of 32 contraction rows per accumulation step in 16 bit). */
 int m3_wgrad_set_dma(int on);
 int m3_wgrad_tile(int N, int K, int dtype, int *tn, int *tk);
 /* balanced mode: dW[g] (+)= sum over group g's units of ws[u] (elems = N*K per group), unit order; optionally the

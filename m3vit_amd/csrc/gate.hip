@@ -57,6 +57,13 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
   __shared__ __attribute__((aligned(16))) float sx[2][GATE_TOK * LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) float sw[2][DC * EPAD];   // w_gate rows of the step, zero-padded to EPAD
   __shared__ float slog[NW > 1 ? GATE_TOK * (EPAD + 1) : 1];
+  // epilogue staging (round 5): the token-per-lane epilogue of wave 0 leaves the dense rows (clean, noisy, gates), the
+  // token's top-k mask and its two CDF thresholds here; ALL waves then store the rows coalesced and share the per-expert
+  // partial sums.  (Written from registers by lane = token, a dense [T, E] output was 64 four-byte stores to 64 different
+  // lines per instruction, E times per array, and the E butterfly sums ran in one wave: 213 us at E = 64, D = 768.)
+  __shared__ float sdense[3][GATE_TOK * (EPAD + 1)];
+  __shared__ unsigned long long ssel[GATE_TOK];
+  __shared__ float sthr[2][GATE_TOK];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -173,9 +180,10 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
 #pragma unroll
     for (int e = 0; e < EW; ++e) slog[lane * (EPAD + 1) + e0 + e] = acc[e];
     __syncthreads();
-    if (wave != 0) return;
+    if (wave == 0) {
 #pragma unroll
-    for (int e = 0; e < EPAD; ++e) cl[e] = slog[lane * (EPAD + 1) + e];
+      for (int e = 0; e < EPAD; ++e) cl[e] = slog[lane * (EPAD + 1) + e];
+    }
   } else {
 #pragma unroll
     for (int e = 0; e < EPAD; ++e) cl[e] = acc[e];
@@ -184,6 +192,8 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
   const int64_t t = t0 + lane;
   const bool tok_ok = t < T_;
   const int k = p.k;
+  const bool prob_load = p.part_load_prob != nullptr;   // host: only when noise_std != 0 and k < E
+  if (wave == 0) {
   // noisy logits
   float nz[EPAD];
 #pragma unroll
@@ -236,40 +246,62 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
     }
     if (j < k) sel_k |= 1ull << best;
   }
-  // dense outputs + load-balance partials
-  const bool prob_load = p.part_load_prob != nullptr;   // host: only when noise_std != 0 and k < E
-  const float inv_std = prob_load ? 1.f / p.noise_std : 0.f;
+  // dense values, top-k mask and thresholds of this token -> LDS
 #pragma unroll
   for (int e = 0; e < EPAD; ++e) {
-    if (EXACT || e < E) {
-      const bool sel = (sel_k >> e) & 1ull;
-      const float pr = q[e] / s;
-      const float gv = (sel && tok_ok) ? pr : 0.f;
-      if (tok_ok) {
-        if (p.clean) p.clean[t * E + e] = cl[e];
-        if (p.noisy) p.noisy[t * E + e] = nz[e];
-        if (p.gates) p.gates[t * E + e] = gv;
+    const bool sel = (sel_k >> e) & 1ull;
+    const float pr = q[e] / s;
+    sdense[0][lane * (EPAD + 1) + e] = cl[e];
+    sdense[1][lane * (EPAD + 1) + e] = nz[e];
+    sdense[2][lane * (EPAD + 1) + e] = ((EXACT || e < E) && sel && tok_ok) ? pr : 0.f;
+  }
+  ssel[lane] = tok_ok ? sel_k : 0ull;
+  sthr[0][lane] = thr_in;
+  sthr[1][lane] = thr_out;
+  }   // wave 0
+  __syncthreads();
+
+  // ---- all waves: the block's dense rows, coalesced (the 64 tokens' rows are one contiguous run of E floats each)
+  {
+    const int nvalid = (int)((T_ - t0 < GATE_TOK) ? (T_ - t0) : GATE_TOK);
+    const int nel = nvalid * E;
+    float *const outs[3] = {p.clean, p.noisy, p.gates};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (!outs[a]) continue;
+      float *dst = outs[a] + t0 * E;
+      for (int i = tid; i < nel; i += NT) {
+        const int row = EXACT ? i / EPAD : i / E, e = i - row * E;
+        dst[i] = sdense[a][row * (EPAD + 1) + e];
       }
-      const float wsum = wave_sum(gv);
-      const unsigned long long b = __ballot(gv > 0.f);
-      if (p.part_count) {
-        // routed entries per expert of this 64-token block: what m3_route_build's histogram pass would count from idx
-        // (NOT the load: a selected expert whose probability underflowed to 0 is routed all the same)
-        const unsigned long long bs = __ballot(sel && tok_ok);
-        if (lane == 0) p.part_count[(int64_t)blockIdx.x * E + e] = __popcll(bs);
-      }
-      float psum = 0.f;
-      if (prob_load) {
-        // _prob_in_top_k, vision_transformer_moe.py:33-71: thresholds are PROBABILITIES, clean/noisy are logits
-        const bool is_in = nz[e] > thr_in;
-        const float z = (cl[e] - (is_in ? thr_in : thr_out)) * inv_std;
-        psum = wave_sum(tok_ok ? normal_cdf(z) : 0.f);
-      }
-      if (lane == 0) {
-        p.part_imp[(int64_t)blockIdx.x * E + e] = wsum;
-        p.part_load[(int64_t)blockIdx.x * E + e] = __popcll(b);
-        if (prob_load) p.part_load_prob[(int64_t)blockIdx.x * E + e] = psum;
-      }
+    }
+  }
+  // ---- all waves: load-balance partials, expert e on wave e % NW (lane = token; the same butterfly sums as before)
+  const float inv_std = prob_load ? 1.f / p.noise_std : 0.f;
+  const unsigned long long my_sel = ssel[lane];
+  const float thr_in = sthr[0][lane], thr_out = sthr[1][lane];
+  for (int e = wave; e < E; e += NW) {
+    const float gv = sdense[2][lane * (EPAD + 1) + e];
+    const float wsum = wave_sum(gv);
+    const unsigned long long b = __ballot(gv > 0.f);
+    if (p.part_count) {
+      // routed entries per expert of this 64-token block: what m3_route_build's histogram pass would count from idx
+      // (NOT the load: a selected expert whose probability underflowed to 0 is routed all the same)
+      const unsigned long long bs = __ballot((my_sel >> e) & 1ull);
+      if (lane == 0) p.part_count[(int64_t)blockIdx.x * E + e] = __popcll(bs);
+    }
+    float psum = 0.f;
+    if (prob_load) {
+      // _prob_in_top_k, vision_transformer_moe.py:33-71: thresholds are PROBABILITIES, clean/noisy are logits
+      const float cle = sdense[0][lane * (EPAD + 1) + e], nze = sdense[1][lane * (EPAD + 1) + e];
+      const bool is_in = nze > thr_in;
+      const float z = (cle - (is_in ? thr_in : thr_out)) * inv_std;
+      psum = wave_sum(tok_ok ? normal_cdf(z) : 0.f);
+    }
+    if (lane == 0) {
+      p.part_imp[(int64_t)blockIdx.x * E + e] = wsum;
+      p.part_load[(int64_t)blockIdx.x * E + e] = __popcll(b);
+      if (prob_load) p.part_load_prob[(int64_t)blockIdx.x * E + e] = psum;
     }
   }
 }

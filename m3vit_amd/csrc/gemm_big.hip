@@ -356,21 +356,23 @@ __global__ __launch_bounds__(XT, 2) void gemm_nt_big_kernel(const GemmDev p) {
 
 // The 256 x 256 kernel takes a call when: 16-bit operands, an even number of whole 128-byte K slices and at least 8 of them (K >= 512), the staged
 // epilogue's alignment, at most 64 groups (one lane per group in the tile scan), and enough tiles to fill the chip about
-// twice (below that the 128 x 128 kernel's four workgroups per CU balance the tail better).
+// (measured rule below).
 bool gemm_big_eligible(const GemmDev &d, int es, bool force) {
   if (es != 2 || !d.vec8) return false;
   const int kb = d.K * es;
   if (kb % 256 != 0 || kb / 128 < 8) return false;      // an even number of 128-byte K tiles
   if (d.group_offsets && d.G > 64) return false;
   if (force) return true;
-  // measured (tools/vitb_gemm_bench.py, profiles/r05_vitb_gemm.txt): one workgroup owns a CU, so a tile's prologue and its
-  // store phase (256 KiB of outputs, the epilogue's GELU arithmetic) overlap with nothing - at K = 768 (12 K tiles) they
-  // cost more than the loop gains and the 128 x 128 kernel, four workgroups per CU, is faster; from K = 2048 on the loop wins
+  // measured with streamed operands (tools/vitb_gemm_bench.py, profiles/r05_vitb_gemm_streamed.txt): one workgroup owns a CU, so
+  // a tile's prologue and its store phase (256 KiB of outputs, the epilogue's GELU arithmetic) overlap with nothing - at
+  // K = 768 (12 K tiles) they cost what the loop gains (+-3 %, the GELU' input gradient -8..-15 %) and the 128 x 128 kernel,
+  // four workgroups per CU, keeps those launches; from K = 2048 on the loop wins (K = 3072: -25 % grouped, -6 % dense even
+  // with 114 tiles on 256 CUs)
   if (kb / 128 < 32) return false;
   const int64_t mt = (d.M + XB - 1) / XB;
   const int64_t ntl = (d.N + XB - 1) / XB;
   if (d.N % XB > 0 && d.N % XB <= 128 && ntl <= 2) return false;      // (a mostly empty column tile: N = 384 wastes a third of the MFMAs)
-  return mt * ntl >= 384;
+  return mt * ntl >= 96;
 }
 
 int launch_gemm_big(const GemmDev &d0, int dtype, int epi, hipStream_t s) {

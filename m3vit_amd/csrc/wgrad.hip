@@ -440,15 +440,18 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tn_kernel(const WgradDev 
 // wgrad_tn_kernel<.., SC = true>.
 __device__ __attribute__((aligned(256))) const uint32_t g_wgrad_zero_row[64] = {0};      // 256 bytes of zeros: the source of rows past a unit's end
 
-template <typename T, bool GC, bool GA>
-__global__ __launch_bounds__(WG_THREADS, 4) void wgrad_dma_kernel(const WgradDev p) {
+template <typename T, bool GC, bool GA, bool SC = false>
+__global__ __launch_bounds__(WG_THREADS, SC ? 3 : 4) void wgrad_dma_kernel(const WgradDev p) {
   typedef Mma<T> MM;
   typedef typename MM::frag frag;
-  static_assert(sizeof(T) == 2, "16-bit operands");
-  constexpr int ROWS = 64;                                  // contraction rows per step
-  constexpr int RS = WG_T * 2;                              // image row: 128 columns = 256 bytes
+  constexpr int ES = (int)sizeof(T);                        // 2 (f16 / bf16) or 4 (f32)
+  constexpr int ROWS = 128 / ES;                            // contraction rows per step: 64 (16-bit) / 32 (f32)
+  constexpr int RS = WG_T * ES;                             // image row: 128 columns = 256 / 512 bytes
   constexpr int OPB = ROWS * RS;                            // one operand image: 16 KiB
-  constexpr int NPC = ROWS / 4 / 4;                         // DMA pieces (4 rows each) per wave per operand per step: 4
+  constexpr int RPP = 1024 / RS;                            // image rows per DMA piece (1 KiB): 4 / 2
+  constexpr int LPR = 64 / RPP;                             // lanes (= 16-byte chunks) per image row: 16 / 32
+  constexpr int EPC = 16 / ES;                              // elements per 16-byte chunk
+  constexpr int NPC = ROWS / RPP / 4;                       // DMA pieces per wave per operand per step: 4
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [dC image | A image]
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
@@ -498,104 +501,164 @@ __global__ __launch_bounds__(WG_THREADS, 4) void wgrad_dma_kernel(const WgradDev
   // the host checks the 4 GiB reach), one address register per piece and no 64-bit arithmetic.  The last step (rows past the
   // end read a zero row, which lives in another buffer) takes 64-bit addresses picked by a bit mask - a `ok ? a : b` between
   // the two becomes a branch around each load, a basic block per piece with its own vmcnt(0).
-  const int prow = lane >> 4;                                // row of this lane inside a piece
+  // fp32: a piece is two 512-byte rows, lane l -> row + (l >> 5), chunk l & 31, which holds logical chunk
+  // (l & 31) ^ (((row >> 2) & 1) << 2): rows r and r + 4 - what a half-wave's ds_read_b32 touches - sit in different
+  // 64-byte halves of the 128-byte bank window; ((row >> 2) & 1) = (j >> 1) & 1 for the wave's piece j.
+  const int prow = lane / LPR;                               // row of this lane inside a piece
   uint32_t colC[2], colA[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    const int c = (lane & 15) ^ ((((4 * q + prow) & 7)) << 1);
-    int nc = n0 + c * 8, kc = k0 + c * 8;
-    if (nc > p.N - 8) nc = p.N - 8;
-    if (kc > p.K - 8) kc = p.K - 8;
-    colC[q] = (uint32_t)nc * 2; colA[q] = (uint32_t)kc * 2;
+    const int c = ES == 2 ? ((lane & 15) ^ ((((4 * q + prow) & 7)) << 1)) : ((lane & 31) ^ (q << 2));
+    int nc = n0 + c * EPC, kc = k0 + c * EPC;
+    if (nc > p.N - EPC) nc = p.N - EPC;
+    if (kc > p.K - EPC) kc = p.K - EPC;
+    colC[q] = (uint32_t)nc * ES; colA[q] = (uint32_t)kc * ES;
   }
-  const int rbase = (int)(r0 + s_begin * ROWS) + (NPC * wave) * 4 + prow;      // row of piece 0 in local step 0 (M < 2^31)
+  auto colq = [](int j) { return ES == 2 ? (j & 1) : ((j >> 1) & 1); };      // which of the two column offsets piece j takes
+  const int rbase = (int)(r0 + s_begin * ROWS) + (NPC * wave) * RPP + prow;    // row of piece 0 in local step 0 (M < 2^31)
   const int rlast = (int)r1 - 1;
   const uint32_t ldc = (uint32_t)p.lddc_b, lda = (uint32_t)p.lda_b;
   int32_t ic[NPC], ia[NPC];
   auto load_index = [&](int step) {
 #pragma unroll
     for (int j = 0; j < NPC; ++j) {
-      const int m = min(rbase + step * ROWS + 4 * j, rlast);
+      const int m = min(rbase + step * ROWS + RPP * j, rlast);
       if (GC) ic[j] = p.c_row_idx[m];
       if (GA) ia[j] = p.a_row_idx[m];
     }
   };
   char *const dma_dst = smem + (NPC * wave) * 1024;
+  // SC (the combine's backward without d y: dC row of slot m = c_row_scale[c_row_idx[m]] * d out[c_row_idx[m] / div]): the
+  // step's ROWS per-row factors go into a small LDS table behind the images - ONE 4-byte LDS-DMA of wave 0, lane l fetching
+  // row l's factor through the index it loaded a step ahead - and multiply the dC fragments on their way into the MFMAs
+  // (v_pk_mul_f16 with the factor rounded to fp16: one more 2^-11 rounding than the register-staged kernel's fp32 product,
+  // inside the fp16 bound).  The zero rows of a unit's last step make their factors irrelevant.
+  float *const s_sc = (float *)(smem + 2 * OPB);
+  static_assert(!SC || (GC && !std::is_same<T, bf16_t>::value), "per-row factors: gathered dC rows, fp16 or fp32");
+  int32_t sc_ix = 0;
+  auto load_sc_index = [&](int step) {
+    if (SC && wave == 0) sc_ix = p.c_row_idx[min((int)(r0 + s_begin * ROWS) + step * ROWS + (lane & (ROWS - 1)), rlast)];
+  };
+  auto dma_scores = [&]() {
+    if (SC && wave == 0 && lane < ROWS)
+      __builtin_amdgcn_global_load_lds((glb_void *)(p.c_row_scale + sc_ix), (lds_void *)s_sc, 4, 0, 0);
+  };
   auto dma_full = [&](int step) {
 #pragma unroll
     for (int j = 0; j < NPC; ++j) {
-      const int m = rbase + step * ROWS + 4 * j;
+      const int m = rbase + step * ROWS + RPP * j;
       // (gather divisors are powers of two here: the host sends anything else to the register-staged kernel)
       const uint32_t cr = GC ? (uint32_t)(ic[j] >> p.c_row_sh) : (uint32_t)m;
       const uint32_t ar = GA ? (uint32_t)(ia[j] >> p.a_row_sh) : (uint32_t)m;
-      __builtin_amdgcn_global_load_lds((glb_void *)(p.dC + (cr * ldc + colC[j & 1])), (lds_void *)(dma_dst + j * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void *)(p.A + (ar * lda + colA[j & 1])), (lds_void *)(dma_dst + j * 1024 + OPB), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void *)(p.dC + (cr * ldc + colC[colq(j)])), (lds_void *)(dma_dst + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void *)(p.A + (ar * lda + colA[colq(j)])), (lds_void *)(dma_dst + j * 1024 + OPB), 16, 0, 0);
     }
   };
   auto dma_tail = [&](int step) {
     const uint64_t zero_row = (uint64_t)(uintptr_t)g_wgrad_zero_row + (lane & 15) * 16;
 #pragma unroll
     for (int j = 0; j < NPC; ++j) {
-      const int m = rbase + step * ROWS + 4 * j;
+      const int m = rbase + step * ROWS + RPP * j;
       const uint64_t ok = m <= rlast ? ~(uint64_t)0 : (uint64_t)0;
       const uint32_t cr = GC ? (uint32_t)(ic[j] >> p.c_row_sh) : (uint32_t)min(m, rlast);
       const uint32_t ar = GA ? (uint32_t)(ia[j] >> p.a_row_sh) : (uint32_t)min(m, rlast);
-      const uint64_t sc = (((uint64_t)(uintptr_t)p.dC + (cr * ldc + colC[j & 1])) & ok) | (zero_row & ~ok);
-      const uint64_t sa = (((uint64_t)(uintptr_t)p.A + (ar * lda + colA[j & 1])) & ok) | (zero_row & ~ok);
+      const uint64_t sc = (((uint64_t)(uintptr_t)p.dC + (cr * ldc + colC[colq(j)])) & ok) | (zero_row & ~ok);
+      const uint64_t sa = (((uint64_t)(uintptr_t)p.A + (ar * lda + colA[colq(j)])) & ok) | (zero_row & ~ok);
       __builtin_amdgcn_global_load_lds((glb_void *)(uintptr_t)sc, (lds_void *)(dma_dst + j * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((glb_void *)(uintptr_t)sa, (lds_void *)(dma_dst + j * 1024 + OPB), 16, 0, 0);
     }
   };
 
-  // fragment addresses: lane (li, lg) supplies row 4 lg + (li >> 2) (+ 16 for the second half of a fragment, + 32 for the
-  // second chunk of a step), columns col + 4 (li & 3) .. + 3 of the 16-column tile starting at col
-  const int s3 = (4 * (lg & 1) + (li >> 2)) & 7;
-  const int frow = (4 * lg + (li >> 2)) * RS + 8 * (li & 1);
+  // fragment addresses.  16-bit: lane (li, lg) supplies row 4 lg + (li >> 2) (+ 16 for the second half of a fragment, + 32 for the
+  // second chunk of a step), columns col + 4 (li & 3) .. + 3 of the 16-column tile starting at col (ds_read_b64_tr_b16).
+  // fp32: lane (li, lg) reads the elements (row 4 lg + r, column col + li), r = 0..3, one ds_read_b32 each (+ 16 rows for
+  // the second chunk of a step); the swizzle swaps the 16-column tiles i and i ^ 1 for odd lg, so a lane has one base for
+  // even and one for odd tiles per operand and the tile index stays an offset.
   int adK[4], adN[4];
+  if constexpr (ES == 2) {
+    const int s3 = (4 * (lg & 1) + (li >> 2)) & 7;
+    const int frow = (4 * lg + (li >> 2)) * RS + 8 * (li & 1);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ck = (wr * 8 + 2 * i + ((li & 3) >> 1)) ^ (s3 << 1);
-    const int cn = (wc * 8 + 2 * i + ((li & 3) >> 1)) ^ (s3 << 1);
-    adK[i] = OPB + frow + ck * 16;
-    adN[i] = frow + cn * 16;
+    for (int i = 0; i < 4; ++i) {
+      const int ck = (wr * 8 + 2 * i + ((li & 3) >> 1)) ^ (s3 << 1);
+      const int cn = (wc * 8 + 2 * i + ((li & 3) >> 1)) ^ (s3 << 1);
+      adK[i] = OPB + frow + ck * 16;
+      adN[i] = frow + cn * 16;
+    }
+  } else {
+    const int frow = 4 * lg * RS + (li & 3) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ck = (wr * 16 + 4 * i + (li >> 2)) ^ ((lg & 1) << 2);
+      const int cn = (wc * 16 + 4 * i + (li >> 2)) ^ ((lg & 1) << 2);
+      adK[i] = OPB + frow + ck * 16;
+      adN[i] = frow + cn * 16;
+    }
   }
   typedef __attribute__((address_space(3))) fp16x4_t lds_h4;
   auto read_frag = [&](int ad, int rb) -> frag {
-    const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4 *)(smem + ad + rb * RS));
-    const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4 *)(smem + ad + (rb + 16) * RS));
-    f16x8 f;
-    f[0] = (half_t)lo[0]; f[1] = (half_t)lo[1]; f[2] = (half_t)lo[2]; f[3] = (half_t)lo[3];
-    f[4] = (half_t)hi[0]; f[5] = (half_t)hi[1]; f[6] = (half_t)hi[2]; f[7] = (half_t)hi[3];
-    return __builtin_bit_cast(frag, f);
+    if constexpr (ES == 2) {
+      const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4 *)(smem + ad + rb * RS));
+      const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4 *)(smem + ad + (rb + 16) * RS));
+      f16x8 f;
+      f[0] = (half_t)lo[0]; f[1] = (half_t)lo[1]; f[2] = (half_t)lo[2]; f[3] = (half_t)lo[3];
+      f[4] = (half_t)hi[0]; f[5] = (half_t)hi[1]; f[6] = (half_t)hi[2]; f[7] = (half_t)hi[3];
+      return __builtin_bit_cast(frag, f);
+    } else {
+      const char *q = smem + ad + rb * RS;
+      f32x4 f;
+      f[0] = *(const float *)(q);
+      f[1] = *(const float *)(q + RS);
+      f[2] = *(const float *)(q + 2 * RS);
+      f[3] = *(const float *)(q + 3 * RS);
+      return f;
+    }
   };
 
   // Bias gradient (column sums of dC over the contraction rows; once per n-tile: k-tile 0, waves wr == 0): a lane's dC
-  // fragment holds 8 contraction rows of ITS column, so four v_dot2 with a pair of ones add them up - one fp32 register per
-  // 16-column tile instead of the register-staged kernel's extra MFMA row (16 accumulator registers + a ones fragment:
-  // at 128 registers they spilled); the four lane groups' partial sums meet in two shuffles at the end.
+  // fragment holds 8 (fp32: 4) contraction rows of ITS column, so four v_dot2 with a pair of ones (fp32: three adds) sum
+  // them - one fp32 register per 16-column tile instead of the register-staged kernel's extra MFMA row (16 accumulator
+  // registers + a ones fragment: at 128 registers they spilled); the four lane groups' partial sums meet in two shuffles.
   const bool do_bias = (p.bias_ws || p.direct_db) && tk == 0 && wr == 0;
   float acc_b[4] = {0.f, 0.f, 0.f, 0.f};
   typedef T t2 __attribute__((ext_vector_type(2)));
   auto colsum8 = [&](const frag &f, float a) -> float {
+    if constexpr (ES == 4) {
+      return a + ((f[0] + f[1]) + (f[2] + f[3]));
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const t2 pr = t2{f[2 * j], f[2 * j + 1]};
-      if constexpr (std::is_same<T, half_t>::value)
-        a = __builtin_amdgcn_fdot2(pr, t2{(T)1, (T)1}, a, false);
-      else
-        a = __builtin_amdgcn_fdot2_f32_bf16(pr, t2{(T)1.f, (T)1.f}, a, false);
+      for (int j = 0; j < 4; ++j) {
+        const t2 pr = t2{f[2 * j], f[2 * j + 1]};
+        if constexpr (std::is_same<T, half_t>::value)
+          a = __builtin_amdgcn_fdot2(pr, t2{(T)1, (T)1}, a, false);
+        else if constexpr (std::is_same<T, bf16_t>::value)
+          a = __builtin_amdgcn_fdot2_f32_bf16(pr, t2{(T)1.f, (T)1.f}, a, false);
+      }
+      return a;
     }
-    return a;
   };
 
   auto compute = [&]() {
 #pragma unroll
-    for (int kc = 0; kc < ROWS / 32; ++kc) {
+    for (int kc = 0; kc < ROWS / MM::KC; ++kc) {
       frag fk[4], fn[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        fk[i] = read_frag(adK[i], kc * 32);
-        fn[i] = read_frag(adN[i], kc * 32);
+        fk[i] = read_frag(adK[i], kc * MM::KC);
+        fn[i] = read_frag(adN[i], kc * MM::KC);
+      }
+      if constexpr (SC) {
+        if constexpr (ES == 4) {
+          const f32x4 sv = *(const f32x4 *)(s_sc + kc * 16 + 4 * lg);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) fn[i] *= sv;
+        } else {
+          const f32x4 s0 = *(const f32x4 *)(s_sc + kc * 32 + 4 * lg), s1 = *(const f32x4 *)(s_sc + kc * 32 + 16 + 4 * lg);
+          const f16x8 sh = f16x8{(half_t)s0[0], (half_t)s0[1], (half_t)s0[2], (half_t)s0[3],
+                                 (half_t)s1[0], (half_t)s1[1], (half_t)s1[2], (half_t)s1[3]};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) fn[i] = __builtin_bit_cast(frag, __builtin_bit_cast(f16x8, fn[i]) * sh);
+        }
       }
 #pragma unroll
       for (int ki = 0; ki < 4; ++ki)
@@ -610,14 +673,18 @@ __global__ __launch_bounds__(WG_THREADS, 4) void wgrad_dma_kernel(const WgradDev
 
   if (nst > 0) {
     if (GC || GA) load_index(0);
+    load_sc_index(0);
     for (int t = 0; t + 1 < nst; ++t) {
       dma_full(t);
+      dma_scores();
       if (GC || GA) load_index(t + 1);                       // (arrives under this step's MFMAs; the barrier's vmcnt(0) covers it)
+      load_sc_index(t + 1);
       __syncthreads();          // vmcnt(0) + barrier: the step's rows have landed
       compute();
       __syncthreads();          // everyone has read them
     }
     dma_tail(nst - 1);
+    dma_scores();
     __syncthreads();
     compute();
   }
@@ -1005,7 +1072,7 @@ extern "C" int m3_debug_wgrad_clock(unsigned long long *dst) {
 
 static int g_wgrad_dma = -1;
 extern "C" int m3_wgrad_set_dma(int on) {
-  M3_REQUIRE(on >= -1 && on <= 1, "m3_wgrad_set_dma: %d", on);
+  M3_REQUIRE(on >= -1 && on <= 2, "m3_wgrad_set_dma: %d", on);
   g_wgrad_dma = on;
   return M3_OK;
 }
@@ -1129,12 +1196,19 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   M3_REQUIRE(a->N * es >= 16 && a->K * es >= 16, "m3_wgrad_tn: N, K too small");
   const size_t lds16 = 4 * WgLds<half_t>::ROWS * WgLds<half_t>::STRIDE, lds32 = 4 * WgLds<float>::ROWS * WgLds<float>::STRIDE;
   const bool sc = a->c_row_scale != nullptr;
-  // LDS-DMA variant: 16-bit operands, whole 16-byte column chunks on both sides, no per-row factor.
-  // m3_wgrad_set_dma / M3_WGRAD_DMA = 0 keeps the register-staged kernel (diagnostics, A/B)
-  if (g_wgrad_dma < 0) { const char *e = getenv("M3_WGRAD_DMA"); g_wgrad_dma = e ? (atoi(e) ? 1 : 0) : 1; }
-  if (g_wgrad_dma && es == 2 && !sc && a->N >= 8 && a->K >= 8 && d.a_row_sh >= 0 && d.c_row_sh >= 0 &&
-      (a->M + 1) * d.lddc_b < ((int64_t)1 << 32) && (a->M + 1) * d.lda_b < ((int64_t)1 << 32)) {       // 32-bit lane offsets
-    const size_t ldsd = 2 * 64 * WG_T * 2;       // 32 KiB
+  // LDS-DMA variant (wgrad_dma_kernel): whole 16-byte column chunks on both sides, power-of-two gather divisors, a per-row
+  // factor only with fp16 / fp32.  m3_wgrad_set_dma / M3_WGRAD_DMA: 0 never, 2 whenever the kernel can run the call, 1
+  // (default) where it measured faster with operands streamed from HBM as inside the training step
+  // (tools/wgrad_ab_bench.py, profiles/r05_wgrad_ab_streamed.txt): fp32 always (-12..-26 %); 16-bit when the launch has one
+  // part per group anyway - tiles x groups fill the 1024 workgroup slots: direct accumulation, the ViT-Base experts, -35 % -
+  // or the weight is large (N K >= 1.5 M elements: ViT-Base qkv / fc1 / fc2, -10..-24 %); at configs[1]'s 384-wide weights
+  // the register-staged kernel is level or ahead (+-5 %) and keeps them
+  if (g_wgrad_dma < 0) { const char *e = getenv("M3_WGRAD_DMA"); g_wgrad_dma = e ? atoi(e) : 1; }
+  const bool dma_can = (!sc || (gc && a->dtype != M3_BF16)) && a->N * es >= 16 && a->K * es >= 16 && d.a_row_sh >= 0 && d.c_row_sh >= 0 &&
+                       (a->M + 1) * d.lddc_b < ((int64_t)1 << 32) && (a->M + 1) * d.lda_b < ((int64_t)1 << 32);       // 32-bit lane offsets
+  const bool dma_pays = es == 4 || (int64_t)a->N * a->K >= 1500000 || (int64_t)tiles_n * d.tiles_k * a->G >= 1024;
+  if (dma_can && (g_wgrad_dma == 2 || (g_wgrad_dma == 1 && dma_pays))) {
+    const size_t ldsd = 2 * 64 * WG_T * 2 + 256;       // 32 KiB + the step's per-row factors
 #define M3_WD(TT)                                                                                    \
     do {                                                                                             \
       if (gc && ga) hipLaunchKernelGGL((wgrad_dma_kernel<TT, true, true>), grid, block, ldsd, s, d); \
@@ -1142,9 +1216,19 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
       else if (ga) hipLaunchKernelGGL((wgrad_dma_kernel<TT, false, true>), grid, block, ldsd, s, d); \
       else hipLaunchKernelGGL((wgrad_dma_kernel<TT, false, false>), grid, block, ldsd, s, d);        \
     } while (0)
-    if (a->dtype == M3_F16) M3_WD(half_t);
-    else M3_WD(bf16_t);
+#define M3_WDS(TT)                                                                                          \
+    do {                                                                                                    \
+      if (ga) hipLaunchKernelGGL((wgrad_dma_kernel<TT, true, true, true>), grid, block, ldsd, s, d);         \
+      else hipLaunchKernelGGL((wgrad_dma_kernel<TT, true, false, true>), grid, block, ldsd, s, d);          \
+    } while (0)
+    if (sc) {
+      if (a->dtype == M3_F16) M3_WDS(half_t);
+      else M3_WDS(float);
+    } else if (a->dtype == M3_F16) M3_WD(half_t);
+    else if (a->dtype == M3_BF16) M3_WD(bf16_t);
+    else M3_WD(float);
 #undef M3_WD
+#undef M3_WDS
     return check_launch("m3_wgrad_tn");
   }
 #define M3_WG(TT, LDS)                                                                               \

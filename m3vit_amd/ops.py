@@ -537,17 +537,25 @@ def wgrad_ws_elems(M, N, K, G, grouped, bias=True, dtype=None):
 _WGRAD_MIN_STEPS = 16      # 32-row steps per split at least (measured on the 8-image configs; no effect at batch 128)
 import os as _os
 _WGRAD_DIRECT = _os.environ.get("M3_WGRAD_DIRECT", "1") != "0"      # splits == 1: the kernel accumulates into dW itself (no slabs)
-# workgroup slots a weight-gradient launch is split to fill: the LDS-DMA kernel (16-bit operands) runs four workgroups per CU,
-# the register-staged one (fp32) two.  Measured with the row splits sized for 1024 instead of 512 slots (tools/wgrad_ab_bench.py,
-# profiles/r05_wgrad_ab.txt): the dense ViT-Base weight gradients 520 -> 780 TFLOP/s, configs[1]'s expert FC1 363 -> 485
+# workgroup slots a weight-gradient launch is split to fill: the LDS-DMA kernel runs four workgroups per CU, the
+# register-staged one two; which kernel takes a launch is m3_wgrad_tn's rule (include/m3vit_hip.h: m3_wgrad_set_dma),
+# mirrored in _wgrad_uses_dma (measured with streamed operands: tools/wgrad_ab_bench.py, profiles/r05_wgrad_ab_streamed.txt)
 _WGRAD_SLOTS = int(_os.environ.get("M3_WGRAD_SLOTS", "0"))         # 0: by kernel (1024 / 512)
-_WGRAD_DMA = _os.environ.get("M3_WGRAD_DMA", "1") != "0"
+_WGRAD_DMA = int(_os.environ.get("M3_WGRAD_DMA", "1"))              # 0 never, 1 where it pays (default), 2 wherever it can run
 
 
-def _wgrad_slots(dtype):
+def _wgrad_uses_dma(N, K, G, dtype, tiles_total):
+    if _WGRAD_DMA == 0:
+        return False
+    if _WGRAD_DMA == 2 or dtype == torch.float32:
+        return True
+    return N * K >= 1500000 or tiles_total >= 1024
+
+
+def _wgrad_slots(dtype, N=0, K=0, G=1, tiles_total=0):
     if _WGRAD_SLOTS:
         return _WGRAD_SLOTS
-    return 1024 if (_WGRAD_DMA and dtype in (torch.float16, torch.bfloat16)) else 512
+    return 1024 if _wgrad_uses_dma(N, K, G, dtype, tiles_total) else 512
 
 
 def wgrad_set_wide(on: int):
@@ -556,11 +564,12 @@ def wgrad_set_wide(on: int):
 
 
 def wgrad_set_dma(on: int):
-    """LDS-DMA weight-gradient kernel on (1, default) / off (0) / from M3_WGRAD_DMA (-1) (include/m3vit_hip.h: m3_wgrad_set_dma);
+    """LDS-DMA weight-gradient kernel: 0 never / 1 where it pays (default) / 2 wherever it can run / -1 from M3_WGRAD_DMA
+    (include/m3vit_hip.h: m3_wgrad_set_dma);
     switch before sizing workspaces (the default row splits follow the kernel's workgroups per CU)"""
     global _WGRAD_DMA
     check(lib().m3_wgrad_set_dma(int(on)), "m3_wgrad_set_dma")
-    _WGRAD_DMA = (_os.environ.get("M3_WGRAD_DMA", "1") != "0") if int(on) < 0 else bool(on)
+    _WGRAD_DMA = int(_os.environ.get("M3_WGRAD_DMA", "1")) if int(on) < 0 else int(on)
 
 
 def wgrad_tile(N, K, dtype=None):
@@ -583,7 +592,7 @@ def default_wgrad_splits(M, N, K, G, dtype=None):
     steps = max(1, (M // max(G, 1) + 31) // 32)
     cap = max(1, steps // _WGRAD_MIN_STEPS)
     if (tn, tk) == (128, 128):
-        nslots = _wgrad_slots(dtype)
+        nslots = _wgrad_slots(dtype, N, K, G, tiles)
         return int(max(1, min(cap, 32, nslots // tiles if tiles <= nslots else 1)))
     slots = 256
     if 3 * tiles <= slots:

@@ -7,9 +7,10 @@ The engine runs the whole batch; the float64 oracle (CPU) and the AMP run (the o
 torch.autocast, i.e. torch's own fp16 kernels with its cast policy: Linear / matmul / conv in fp16, LayerNorm / softmax in
 fp32, fp16 weight gradients cast back to fp32) run the two images whose d tokens are non-zero - images only interact through
 the balance loss, whose weight is 0 here (tests/test_full_size.py has the argument).  Both follow the ENGINE's routing
-(route_override), so the table isolates arithmetic.  Prints a table and a JSON line; used by
-tests/test_full_size.py::test_fp16_gradient_error_is_bounded_by_the_reference_amp_arithmetic.
-    python tools/amp_error_table.py [--out profiles/r05_amp_error_table.txt]
+(route_override), so the table isolates arithmetic.  Test infrastructure (it imports the oracle, hence it lives under
+tests/): used by tests/test_full_size.py::test_fp16_gradient_error_is_bounded_by_the_reference_amp_arithmetic, and as a
+script prints the table:
+    python tests/amp_error_table.py [--out profiles/r05_amp_error_table.txt]
 """
 import argparse
 import json

@@ -171,13 +171,13 @@ def test_fp16_gradient_error_is_bounded_by_the_reference_amp_arithmetic():
     1.5e-3).  The yardstick for those is the reference's OWN reduced-precision arithmetic: its AMP trainer
     (pretrain/engine/train_one_epoch.py:35 - torch autocast(fp16) + a scaled loss) run as the oracle's functions on the GPU
     under torch.autocast, on the same two images, following the same routing, against the same float64 oracle
-    (tools/amp_error_table.py; table in profiles/r05_amp_error_table.txt: worst ratio 0.96, worst engine error 1.51e-3, worst
+    (tests/amp_error_table.py; table in profiles/r05_amp_error_table.txt: worst ratio 0.96, worst engine error 1.51e-3, worst
     AMP error 2.34e-3).  Bound: per parameter tensor, engine error <= 1.25 x the AMP error; tokens likewise."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import os
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from amp_error_table import error_table
     t = error_table()
     assert t["tokens_engine"] < 1e-3 and t["tokens_engine"] <= 1.25 * t["tokens_amp"], (t["tokens_engine"], t["tokens_amp"])

@@ -1,4 +1,4 @@
-"""GPU: the LDS-DMA weight-gradient kernel (wgrad_dma_kernel, csrc/wgrad.hip: 16-bit operands, no per-row factor) against
+"""GPU: the LDS-DMA weight-gradient kernel (wgrad_dma_kernel, csrc/wgrad.hip: fp16 / bf16 / fp32 operands, no per-row factor) against
 torch fp64 on the same rounded operands and against the register-staged kernel on the same call: dense with row splits,
 ragged unit tails (rows past a unit's end read the zero row), partial column tiles, grouped with ragged and EMPTY experts,
 gathered dC rows (expert FC2: token-major d y), gathered A rows with a power-of-two divisor (expert FC1: tokens through
@@ -7,8 +7,8 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}
-DTYPES = [torch.float16, torch.bfloat16]
+TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3, torch.float32: 2e-5}
+DTYPES = [torch.float16, torch.bfloat16, torch.float32]
 
 
 @pytest.fixture(scope="module")
@@ -16,7 +16,7 @@ def ops():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from m3vit_amd import ops as _ops
-    _ops.wgrad_set_dma(1)
+    _ops.wgrad_set_dma(2)
     yield _ops
     _ops.wgrad_set_dma(-1)
 
@@ -51,8 +51,8 @@ def test_dense_against_fp64_and_the_register_staged_kernel(ops, dtype, M, N, K, 
         dW0 = base.clone(); db0 = torch.zeros(N, device=dev())
         ops.wgrad_tn(dC, A, dW0, beta=1, db=db0, beta_db=0, splits=splits)
     finally:
-        ops.wgrad_set_dma(1)
-    assert rel(dW - base, dW0 - base) < 1e-5 and rel(db, db0) < 1e-5        # same products, fp32 sums in another order
+        ops.wgrad_set_dma(2)
+    assert rel(dW - base, dW0 - base) < 2e-5 and rel(db, db0) < 2e-5        # same products, fp32 sums in another order
 
 
 def _route(ops, T, E, k, seed, skip=None):
@@ -91,8 +91,38 @@ def test_grouped_expert_weight_gradients(ops, dtype, E, k, T, D, H):
         assert rel(db2[e], dys.sum(0)) < max(TOL[dtype], 1e-4), e
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("E,k,T,D,H", [(16, 4, 1576, 384, 384), (8, 2, 333, 136, 264)])
+def test_expert_fc2_weight_gradient_through_the_gate_score(ops, dtype, E, k, T, D, H):
+    """the combine's backward without d y (custom_moe_layer.py:298-305): dW2[e] = sum_slot score[slot] * d out[slot / k]^T hid[slot]
+    - the per-row factor travels through a small LDS table and multiplies the dC fragments (fp16: v_pk_mul_f16 with the factor
+    rounded to fp16) - against fp64 and against the register-staged kernel (fp32 product, one rounding)"""
+    r, ros, off = _route(ops, T, E, k, seed=81)
+    R = T * k
+    dout, hid = rnd(T, D, dtype=dtype, seed=82), rnd(R, H, dtype=dtype, seed=83)
+    score = torch.rand(R, generator=torch.Generator().manual_seed(84)).to(dev())
+
+    def run():
+        dW, db = torch.zeros(E, D, H, device=dev()), torch.zeros(E, D, device=dev())
+        ops.wgrad_tn(dout, hid, dW, M=R, c_row_idx=r.row_of_slot, c_row_div=k, c_row_scale=score, group_offsets=r.offsets, db=db)
+        return dW, db
+    dW, db = run()
+    ops.wgrad_set_dma(0)
+    try:
+        dW0, db0 = run()
+    finally:
+        ops.wgrad_set_dma(2)
+    tol = TOL[dtype]
+    for e in range(E):
+        sl = slice(off[e], off[e + 1])
+        rows = dout.double().cpu()[ros[sl] // k] * score.double().cpu()[ros[sl]][:, None]
+        assert rel(dW[e], rows.t() @ hid.double().cpu()[sl]) < tol, e
+        assert rel(db[e], rows.sum(0)) < max(tol, 1e-4), e
+    assert rel(dW, dW0) < (1e-3 if dtype == torch.float16 else 2e-5) and rel(db, db0) < (1e-3 if dtype == torch.float16 else 2e-5)
+
+
 def test_calls_the_dma_kernel_does_not_take_still_work(ops):
-    """a per-row factor (c_row_scale) and a divisor that is not a power of two go to the register-staged kernel"""
+    """a divisor that is not a power of two (top-k = 3) goes to the register-staged kernel, with and without a per-row factor"""
     E, k, T, D, H = 6, 3, 300, 64, 96
     r, ros, off = _route(ops, T, E, k, seed=41)
     R = T * k

@@ -10,16 +10,20 @@ O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
 cd $R
 timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err
-B="--no-f32 --no-cpu-baseline"
+B="--no-f32 --no-cpu-baseline --no-vitb --no-skew --no-module-path"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof2 -o run -- python $R/bench.py --steps 8 --warmup 2 $B > $O/prof2.json 2> $O/prof2.err
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof1 -o run -- python $R/bench.py --steps 8 --warmup 2 $B --serial-tasks --no-graph > $O/prof1.json 2> $O/prof1.err
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof1f32 -o run -- python $R/bench.py --dtype f32 --steps 4 --warmup 1 --no-cpu-baseline --serial-tasks --no-graph > $O/prof1_f32.json 2> $O/prof1_f32.err
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof1f32 -o run -- python $R/bench.py --dtype f32 --steps 4 --warmup 1 --no-cpu-baseline --no-vitb --no-skew --no-module-path --serial-tasks --no-graph > $O/prof1_f32.json 2> $O/prof1_f32.err
 cp $(find $O/prof2 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_two_streams.csv
 cp $(find $O/prof1 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_serial.csv
 cp $(find $O/prof1f32 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_serial_f32.csv
 python $R/tools/prof_by_launch.py $(find $O/prof1 -name "*kernel_trace.csv" | head -1) --steps 14 > $O/by_launch_shape_serial.txt
+python $R/tools/prof_by_launch.py $(find $O/prof1f32 -name "*kernel_trace.csv" | head -1) --steps 9 > $O/by_launch_shape_serial_f32.txt
 rm -rf $O/prof1 $O/prof2 $O/prof1f32
+# the ViT-Base configurations (single-GPU forms): serial traces
+$R/tools/prof_config.sh 3 gpurun_out/final && $R/tools/prof_config.sh 4 gpurun_out/final
+cd /tmp
 for DT in f16 f32; do
   mkdir -p $O/fetch_$DT $O/write_$DT
   timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch_$DT -o run -- python $R/bench.py --dtype $DT --steps 2 --warmup 1 $B --serial-tasks --no-graph > $O/fetch_$DT.log 2>&1

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Micro-benchmark of m3_gemm_nt at the ViT-Base shapes of BASELINE configs[3] / configs[4] (K = 768 / 3072), 128 x 128
 tiles (M3 big = 0) against the 256 x 256-tile kernel (big = 1), with torch.mm (hipBLASLt) on the same operands as the
-yardstick for the dense and the per-expert products.  Random operands, HIP events, variants interleaved in one process.
+yardstick for the dense and the per-expert products.  Random operands STREAMED (a ring of activation sets larger than the
+256 MiB Infinity Cache: inside the training step a GEMM's input was written launches earlier; --resident re-reads one set),
+HIP events, variants interleaved in one process.
     python tools/vitb_gemm_bench.py [--iters 20] [--only NAME] [--no-mm]
 """
 import argparse
@@ -18,6 +20,7 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--only", default="")
 ap.add_argument("--no-mm", action="store_true")
+ap.add_argument("--resident", action="store_true")
 args = ap.parse_args()
 dt = torch.float16
 dev = torch.device("cuda:0")
@@ -51,66 +54,83 @@ def run(name, flops, variants):
     print(f"{name:44s} " + "  ".join(f"{k} {v:8.1f} us {flops / v / 1e6:7.1f} TF" for k, v in best.items()), flush=True)
 
 
-def with_big(mode, fn):
-    def f():
-        ops.gemm_set_big(mode)
-        fn()
-    return f
+def ring_of(nbytes):
+    return 1 if args.resident else int(max(2, min(8, -(-320e6 // nbytes))))
 
 
 def dense_case(name, M, N, K, **kw):
-    A, B = rnd(M, K), rnd(N, K, scale=0.05)
-    C = torch.empty(M, N, dtype=dt, device=dev)
+    n = ring_of(M * (K + N) * 2)
+    As = [rnd(M, K) for _ in range(n)]
+    B = rnd(N, K, scale=0.05)
+    Cs = [torch.empty(M, N, dtype=dt, device=dev) for _ in range(n)]
     extra = {}
     if kw.get("gelu"):
-        extra = dict(bias=rnd(N, dtype=torch.float32), act=ops.M3_ACT_GELU, pre_out=torch.empty_like(C))
-    v = {"t128": with_big(0, lambda: ops.gemm_nt(A, B, C, **extra)), "t256": with_big(1, lambda: ops.gemm_nt(A, B, C, **extra))}
+        extra = dict(bias=rnd(N, dtype=torch.float32), act=ops.M3_ACT_GELU)
+        pres = [torch.empty(M, N, dtype=dt, device=dev) for _ in range(n)]
+    st = [0]
+
+    def go(mode):
+        def f():
+            i = st[0] % n
+            st[0] += 1
+            ops.gemm_set_big(mode)
+            ops.gemm_nt(As[i], B, Cs[i], **(dict(extra, pre_out=pres[i]) if extra else {}))
+        return f
+    v = {"t128": go(0), "t256": go(1)}
     if not args.no_mm:
         Bt = B.t()
-        v["mm"] = lambda: torch.mm(A, Bt, out=C)
-    run(f"dense {name} M={M} N={N} K={K}", 2.0 * M * N * K, v)
+
+        def mm():
+            i = st[0] % n
+            st[0] += 1
+            torch.mm(As[i], Bt, out=Cs[i])
+        v["mm"] = mm
+    run(f"dense {name} M={M} N={N} K={K} (ring {n})", 2.0 * M * N * K, v)
 
 
 def grouped_case(name, T, E, k, D, H):
     R = T * k
-    x = rnd(T, D)
     idx = torch.stack([torch.randperm(E, generator=g)[:k] for _ in range(T)]).to(torch.int32).to(dev)
     r = ops.route_build(idx, E)
     W1, b1 = rnd(E, H, D, scale=0.05), rnd(E, H, dtype=torch.float32)
     W2, b2 = rnd(E, D, H, scale=0.05), rnd(E, D, dtype=torch.float32)
-    hid, pre = torch.empty(R, H, dtype=dt, device=dev), torch.empty(R, H, dtype=dt, device=dev)
-    y = torch.empty(R, D, dtype=dt, device=dev)
+    n = ring_of(R * (H + D) * 2)
+    xs = [rnd(T, D) for _ in range(n)]
+    hids = [rnd(R, H) for _ in range(n)]
+    pres = [torch.empty(R, H, dtype=dt, device=dev) for _ in range(n)]
+    ys = [rnd(R, D) for _ in range(n)]
+    st = [0]
 
-    def fc1():
-        ops.gemm_nt(x, W1, hid, M=R, bias=b1, act=ops.M3_ACT_GELU, pre_out=pre, a_row_idx=r.row_of_slot, a_row_div=k,
-                    group_offsets=r.offsets, tile_starts=r.tile_starts)
+    def nxt():
+        i = st[0] % n
+        st[0] += 1
+        return i
 
-    def fc2():
-        ops.gemm_nt(hid, W2, y, M=R, bias=b2, c_row_idx=r.row_of_slot, group_offsets=r.offsets, tile_starts=r.tile_starts)
+    def fc1(mode):
+        def f():
+            i = nxt()
+            ops.gemm_set_big(mode)
+            ops.gemm_nt(xs[i], W1, hids[i], M=R, bias=b1, act=ops.M3_ACT_GELU, pre_out=pres[i], a_row_idx=r.row_of_slot, a_row_div=k,
+                        group_offsets=r.offsets, tile_starts=r.tile_starts)
+        return f
 
-    def dgrad2():
-        ops.gemm_nt(y, W1, pre, M=R, gelu_grad_pre=hid, a_row_idx=r.row_of_slot, a_row_div=1, group_offsets=r.offsets,
-                    tile_starts=r.tile_starts)
-    off = r.offsets.cpu().tolist()
-    v1 = {"t128": with_big(0, fc1), "t256": with_big(1, fc1)}
-    v2 = {"t128": with_big(0, fc2), "t256": with_big(1, fc2)}
-    v3 = {"t128": with_big(0, dgrad2), "t256": with_big(1, dgrad2)}
-    if not args.no_mm:
-        xs = rnd(R, D)
-        W1t, W2t = W1.transpose(1, 2), W2.transpose(1, 2)
+    def fc2(mode):
+        def f():
+            i = nxt()
+            ops.gemm_set_big(mode)
+            ops.gemm_nt(hids[i], W2, ys[i], M=R, bias=b2, c_row_idx=r.row_of_slot, group_offsets=r.offsets, tile_starts=r.tile_starts)
+        return f
 
-        def mm1():
-            for e in range(E):
-                torch.mm(xs[off[e]:off[e + 1]], W1t[e], out=hid[off[e]:off[e + 1]])
-
-        def mm2():
-            for e in range(E):
-                torch.mm(hid[off[e]:off[e + 1]], W2t[e], out=y[off[e]:off[e + 1]])
-        v1["mm/expert"] = mm1
-        v2["mm/expert"] = mm2
-    run(f"grouped FC1 gather+gelu+pre {name}", 2.0 * R * D * H, v1)
-    run(f"grouped FC2 scatter {name}", 2.0 * R * D * H, v2)
-    run(f"grouped FC2 dgrad gather+gelu' {name}", 2.0 * R * D * H, v3)
+    def dgrad2(mode):
+        def f():
+            i = nxt()
+            ops.gemm_set_big(mode)
+            ops.gemm_nt(ys[i], W1, pres[i], M=R, gelu_grad_pre=hids[i], a_row_idx=r.row_of_slot, a_row_div=1, group_offsets=r.offsets,
+                        tile_starts=r.tile_starts)
+        return f
+    run(f"grouped FC1 gather+gelu+pre {name} (ring {n})", 2.0 * R * D * H, {"t128": fc1(0), "t256": fc1(1)})
+    run(f"grouped FC2 scatter {name} (ring {n})", 2.0 * R * D * H, {"t128": fc2(0), "t256": fc2(1)})
+    run(f"grouped FC2 dgrad gather+gelu' {name} (ring {n})", 2.0 * R * D * H, {"t128": dgrad2(0), "t256": dgrad2(1)})
 
 
 T4 = 8 * 1201

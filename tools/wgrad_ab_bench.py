@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """A/B of the weight-gradient (TN) kernels on every weight-gradient shape of BASELINE configs[1] / [3] / [4] (one task pass,
-single-GPU forms): register-staged (M3 dma = 0) against the LDS-DMA kernel (dma = 1), variants interleaved in ONE process,
-random operands, HIP events around m3_wgrad_tn + its slab reduction (as the engine's queue issues them: the reduce rides on
-the next launch, so a pair of calls is timed and halved).
+single-GPU forms): round 4's path (register-staged kernel, row splits for 512 slots, slabs + reduction always) against the
+LDS-DMA kernel with the splits sized for 512 / 1024 slots and direct accumulation where a launch has one part per group.
+Variants interleaved in ONE process, random operands STREAMED - a ring of (dC, A) sets larger than the 256 MiB Infinity
+Cache, as inside the training step, where a weight gradient's operands were written many launches earlier (the first
+version of this tool re-read one resident set and over-stated every variant, the DMA kernel most) - HIP events around
+m3_wgrad_tn with the slab reduction riding on the next launch, as the engine's queue issues them.
     python tools/wgrad_ab_bench.py [--config 1|3|4] [--iters 20] [--only NAME]
 """
 import argparse
@@ -47,43 +50,74 @@ def run(name, flops, mk):
         return
     best = {}
     import m3vit_amd.ops as O
-    fns = {"staged": (0, False, 512, mk()), "dma": (1, False, 512, mk()), "dma/1024": (1, False, 1024, mk()),
-           "dma+direct": (1, True, 512, mk())}
+    fns = {"r4": (0, False, 512, mk()), "dma/512": (2, True, 512, mk()), "dma/1024": (2, True, 1024, mk()), "default": (1, True, 0, mk())}
     for _ in range(args.rounds):
         for k_, (mode, direct, slots, fn) in fns.items():
             ops.wgrad_set_dma(mode)
             O._WGRAD_DIRECT, O._WGRAD_SLOTS = direct, slots
             best[k_] = min(best.get(k_, 1e30), time_us(fn))
-    O._WGRAD_DIRECT, O._WGRAD_SLOTS = True, 512
+    O._WGRAD_DIRECT, O._WGRAD_SLOTS = True, 0
     print(f"{name:50s} " + "  ".join(f"{k_} {v:7.1f} us {flops / v / 1e6:6.1f} TF" for k_, v in best.items()), flush=True)
 
 
-def dense(name, M, N, K):
-    dC, A = rnd(M, N), rnd(M, K)
+RING_BYTES = 320e6
+
+
+def ring_of(nbytes):
+    return int(max(2, min(8, -(-RING_BYTES // nbytes))))
+
+
+def dense(name, M, N, K, dtype=dt):
+    es = 2 if dtype != torch.float32 else 4
+    n = ring_of(M * (N + K) * es)
+    sets = [(rnd(M, N, dtype=dtype), rnd(M, K, dtype=dtype)) for _ in range(n)]
     dW, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
-    q = ops.WgradQueue(3 * ops.wgrad_ws_elems(M, N, K, 1, grouped=False, dtype=dt), dev)
+    q = ops.WgradQueue(3 * ops.wgrad_ws_elems(M, N, K, 1, grouped=False, dtype=dtype), dev)
 
     def mk():
-        return lambda: ops.wgrad_tn(dC, A, dW, beta=1, db=db, queue=q)
-    run(f"dense {name} M={M} N={N} K={K}", 2.0 * M * N * K, mk)
+        st = [0]
+
+        def fn():
+            dC, A = sets[st[0] % n]
+            st[0] += 1
+            ops.wgrad_tn(dC, A, dW, beta=1, db=db, queue=q)
+        return fn
+    run(f"dense {name} M={M} N={N} K={K}{' f32' if es == 4 else ''} (ring {n})", 2.0 * M * N * K, mk)
 
 
-def experts(name, T, E, k, D, H):
+def experts(name, T, E, k, D, H, dtype=dt):
     R = T * k
+    es = 2 if dtype != torch.float32 else 4
     idx = torch.stack([torch.randperm(E, generator=g)[:k] for _ in range(T)]).to(torch.int32).to(dev)
     r = ops.route_build(idx, E)
-    x, dhp, hid, dy = rnd(T, D), rnd(R, H), rnd(R, H), rnd(R, D)
+    n = ring_of(R * (H + D) * es)
+    sets = [(rnd(T, D, dtype=dtype), rnd(R, H, dtype=dtype), rnd(R, H, dtype=dtype), rnd(T, D, dtype=dtype)) for _ in range(n)]
+    score = torch.rand(R, generator=g).to(dev)
     dW1, db1 = torch.zeros(E, H, D, device=dev), torch.zeros(E, H, device=dev)
     dW2, db2 = torch.zeros(E, D, H, device=dev), torch.zeros(E, D, device=dev)
-    q = ops.WgradQueue(3 * max(ops.wgrad_ws_elems(R, H, D, E, grouped=True, dtype=dt), ops.wgrad_ws_elems(R, D, H, E, grouped=True, dtype=dt)), dev)
+    q = ops.WgradQueue(3 * max(ops.wgrad_ws_elems(R, H, D, E, grouped=True, dtype=dtype), ops.wgrad_ws_elems(R, D, H, E, grouped=True, dtype=dtype)), dev)
 
     def mk1():
-        return lambda: ops.wgrad_tn(dhp, x, dW1, M=R, beta=1, a_row_idx=r.row_of_slot, a_row_div=k, group_offsets=r.offsets, db=db1, queue=q)
+        st = [0]
+
+        def fn():
+            x, dhp, _, _ = sets[st[0] % n]
+            st[0] += 1
+            ops.wgrad_tn(dhp, x, dW1, M=R, beta=1, a_row_idx=r.row_of_slot, a_row_div=k, group_offsets=r.offsets, db=db1, queue=q)
+        return fn
 
     def mk2():
-        return lambda: ops.wgrad_tn(dy, hid, dW2, M=R, beta=1, c_row_idx=r.row_of_slot, group_offsets=r.offsets, db=db2, queue=q)
-    run(f"expert FC1 (gathered A) {name}", 2.0 * R * D * H, mk1)
-    run(f"expert FC2 (gathered dC, no score) {name}", 2.0 * R * D * H, mk2)
+        st = [0]
+
+        def fn():
+            _, _, hid, dout = sets[st[0] % n]
+            st[0] += 1
+            ops.wgrad_tn(dout, hid, dW2, M=R, beta=1, c_row_idx=r.row_of_slot, c_row_div=k, c_row_scale=score,
+                         group_offsets=r.offsets, db=db2, queue=q)
+        return fn
+    tag = f"{name}{' f32' if es == 4 else ''} (ring {n})"
+    run(f"expert FC1 (gathered A) {tag}", 2.0 * R * D * H, mk1)
+    run(f"expert FC2 (d out through the gate score) {tag}", 2.0 * R * D * H, mk2)
 
 
 if args.config in (0, 1):
@@ -91,6 +125,9 @@ if args.config in (0, 1):
     for n, N, K in (("qkv", 1152, 384), ("proj", 384, 384), ("fc1", 1536, 384), ("fc2", 384, 1536)):
         dense("cfg1 " + n, T, N, K)
     experts("cfg1 E=16 D=H=384", T, 16, 4, 384, 384)
+    for n, N, K in (("qkv", 1152, 384), ("fc1", 1536, 384), ("fc2", 384, 1536)):
+        dense("cfg1 " + n, T, N, K, dtype=torch.float32)
+    experts("cfg1 E=16 D=H=384", T, 16, 4, 384, 384, dtype=torch.float32)
 if args.config in (0, 3):
     T = 128 * 197
     for n, N, K in (("qkv", 2304, 768), ("proj", 768, 768), ("fc1", 3072, 768), ("fc2", 768, 3072)):

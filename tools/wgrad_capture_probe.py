@@ -14,14 +14,14 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from m3vit_amd.engine import BackboneEngine  # noqa: E402
-from oracle import ref_torch as R  # noqa: E402
+from m3vit_amd.config import BackboneConfig, init_params  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=4)
 a = ap.parse_args()
-cfg = R.BackboneCfg(img_size=(64, 64), embed_dim=64, depth=4, num_heads=2, mlp_ratio=4.0, moe_mlp_ratio=1.0,
+cfg = BackboneConfig(img_size=(64, 64), embed_dim=64, depth=4, num_heads=2, mlp_ratio=4.0, moe_mlp_ratio=1.0,
                     moe_experts=8, moe_top_k=2, gate_dim=66, multi_gate=True)
-P = R.init_backbone_params(cfg, seed=4)
+P = init_params(cfg, seed=4)
 torch.manual_seed(9)
 img = torch.randn(a.batch, 3, 64, 64).cuda()
 dtok = (torch.randn(a.batch, cfg.num_tokens, 64) * 0.1).cuda()
