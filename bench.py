@@ -98,6 +98,10 @@ def parse():
     ap.add_argument("--ep-chunks", type=int, default=2, help="N > 1: the third leg \"ep_overlap\" cuts every expert-parallel exchange "
                     "into this many chunks of local experts and overlaps them with the experts' GEMMs inside one pass (MultiTaskStep "
                     "ep_chunks; same results bit for bit); 1 = no such leg")
+    ap.add_argument("--ep-native", action="store_true", help="N > 1 over RCCL: one more leg \"ep_native\", LAST: the expert-parallel "
+                    "exchange through the library's own RCCL entry points (m3_ep_dispatch / m3_ep_return; m3vit_amd/ep_native.py) instead "
+                    "of torch.distributed, with --ep-chunks chunks.  Opt-in: those entry points have only ever run on a one-rank "
+                    "communicator (the build box has one GPU)")
     ap.add_argument("--dp-only", action="store_true", help="N > 1: time only the replicated-experts data-parallel form")
     ap.add_argument("--no-f32", action="store_true", help="N = 1: skip the fp32 run reported as the sub-object \"f32\"")
     ap.add_argument("--module-path", action="store_true", help="N = 1: time ONLY the drop-in module path (install_fmoe_shim() + "
@@ -139,7 +143,7 @@ class GemmTimer:
             for name, esz in (("pre_out", A.element_size()), ("gelu_grad_pre", A.element_size()), ("residual", 4)):
                 if kw.get(name) is not None:
                     byts += M * N * esz
-            self.records.append((s, e, 2.0 * M * N * K, kw.get("group_offsets") is not None, float(byts)))
+            self.records.append((s, e, 2.0 * M * N * K, kw.get("group_offsets") is not None, float(byts), int(K)))
             return r
         self.ops.gemm_nt = timed
         return self
@@ -149,17 +153,22 @@ class GemmTimer:
 
     def summary(self):
         tot_ms = tot_fl = g_ms = g_fl = tot_by = g_by = 0.0
-        for s, e, fl, grouped, byts in self.records:
+        by_k = {}
+        for s, e, fl, grouped, byts, K in self.records:
             ms = s.elapsed_time(e)
             tot_ms += ms; tot_fl += fl; tot_by += byts
             if grouped:
                 g_ms += ms; g_fl += fl; g_by += byts
+                a = by_k.setdefault(K, [0.0, 0.0, 0])
+                a[0] += ms; a[1] += fl; a[2] += 1
         n = len(self.records)
         return dict(launches=n, avg_us=1e3 * tot_ms / max(n, 1), tflops=tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0,
                     flops_per_launch=tot_fl / max(n, 1), bytes_per_launch=tot_by / max(n, 1),
                     gbps=tot_by / (tot_ms * 1e-3) / 1e9 if tot_ms else 0.0,
                     grouped_gbps=g_by / (g_ms * 1e-3) / 1e9 if g_ms else 0.0,
                     grouped_launches=sum(1 for r in self.records if r[3]),
+                    grouped_by_k={str(K): {"launches": a[2], "avg_us": round(1e3 * a[0] / a[2], 1),
+                                           "tflops": round(a[1] / (a[0] * 1e-3) / 1e12, 1)} for K, a in sorted(by_k.items()) if a[0] > 0},
                     grouped_tflops=g_fl / (g_ms * 1e-3) / 1e12 if g_ms else 0.0)
 
 
@@ -218,6 +227,11 @@ def main():
     # rehearsal knobs (tests only): M3_BENCH_BACKEND=gloo + M3_BENCH_ONE_DEVICE=1 run N ranks on ONE GPU
     backend = os.environ.get("M3_BENCH_BACKEND", "nccl")
     dev_index = 0 if (world == 1 or os.environ.get("M3_BENCH_ONE_DEVICE") == "1") else local_rank
+    if world > 1 and os.environ.get("M3_BENCH_ONE_DEVICE") == "1":
+        # several PROCESSES on one device share its hardware queues: with HIP's default of 4 per process the ranks' task /
+        # wgrad / exchange streams stall one another for seconds per step (profiles/r05_dp_two_rank_stream_count.txt);
+        # read by the HIP runtime when it initialises, so set before the first device call
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
@@ -246,7 +260,7 @@ def main():
     coll = {"nccl": "RCCL"}.get(backend, backend)
 
     def run_mode(dtype_name, expert_parallel, want_roofline, share_stem=False, workload=None, batch=None, skew=None, steps=None,
-                 warmup=None, ep_chunks=1):
+                 warmup=None, ep_chunks=1, ep_native=False):
         """One timed configuration: W untimed warm-up steps, exactly K timed steps between barriers, max over ranks.
         Returns the fields of the JSON line that depend on the mode."""
         wl = WORKLOADS[args.config if workload is None else workload]
@@ -265,7 +279,7 @@ def main():
                                expert_parallel=expert_parallel, wgrad_streams=args.wgrad_streams, dp_parts=args.dp_parts,
                                checkpoint=args.checkpoint, share_stem=share_stem,
                                ep_capacity=args.ep_capacity if expert_parallel else 0.0,
-                               ep_chunks=ep_chunks if expert_parallel else 1)
+                               ep_chunks=ep_chunks if expert_parallel else 1, ep_native=ep_native and expert_parallel)
         use_ep, par_tasks, ntasks = runner.use_ep, runner.par or runner.par_ep, len(runner.tasks)
         g = torch.Generator().manual_seed(1000 + rank)          # each rank its own images
         images = torch.randn(batch, 3, *cfg.img_size, generator=g).to(dev)
@@ -324,6 +338,8 @@ def main():
                                                          "GEMMs inside a pass" if runner.ep_chunks > 1 else
                                                          "exact a2a-v (2 W split sizes read per MoE layer and pass)") if not runner.ep_capacity
                                else f"fixed capacity {runner.ep_capacity} x R / W per pair, {runner.ep_repeats} step(s) repeated on the exact path")),
+               "ep_transport": (None if not use_ep else ("library RCCL entry points (m3_ep_dispatch / m3_ep_return: grouped ncclSend / ncclRecv)"
+                                                         if runner.eng.ep_native is not None else f"torch.distributed all_to_all_single ({coll})")),
                "parallelism": "single" if world == 1 else (f"dp{world}+ep{world} (experts sharded, {coll} all-to-all + all-reduce)"
                                                             if use_ep else f"dp{world} (replicated experts, {coll} all-reduce)")}
         if want_roofline:
@@ -399,6 +415,9 @@ def main():
                     "expert_grouped_gemm_tflops": round(g1["grouped_tflops"], 2),
                     "expert_grouped_gemm_frac": round(g1["grouped_tflops"] / peak, 4),
                     "expert_grouped_gemm_gbps": round(g1["grouped_gbps"], 1),
+                    # the expert grouped launches by contraction length K (FC1 / FC2 input gradient: K = D; FC2 / FC1 input
+                    # gradient over H: K = H): at ViT-Base width K = 3072 is where the 256 x 256-tile kernel runs
+                    "expert_grouped_gemm_by_k": {k_: dict(v, frac=round(v["tflops"] / peak, 4)) for k_, v in g1["grouped_by_k"].items()},
                     "launch_mode": "the step's launches on one stream (kernel by itself)"}
         if gs is not None:
             roofline["as_timed"] = {"launch_mode": f"{ntasks} concurrent task streams; event pairs include waiting for CU slots",
@@ -563,7 +582,7 @@ def main():
         want_ep = args.ep or (not args.dp_only and E % world == 0)
         want_dp = not args.ep
         results = {}
-        sub = ("value", "ms_per_step", "model_tflops", "launch", "parallelism", "ep_exchange")
+        sub = ("value", "ms_per_step", "model_tflops", "launch", "parallelism", "ep_exchange", "ep_transport")
         # The legs, in this order: data parallel first - it needs one collective (all-reduce) and its line must survive whatever
         # the expert-parallel leg (count all-to-all + uneven all-to-all-v on several streams) does at its first contact with
         # RCCL; the opt-in shared-stem data-parallel leg (--share-stem; the one-GPU gloo rehearsal stalls in it, DESIGN
@@ -579,6 +598,10 @@ def main():
             legs.append(("ep", True, lambda: run_mode(args.dtype, True, False), EP_WATCHDOG_S))
             if args.ep_chunks > 1 and not args.ep_capacity and (E // world) % args.ep_chunks == 0:
                 legs.append(("ep_overlap", "ep_overlap", lambda: run_mode(args.dtype, True, False, ep_chunks=args.ep_chunks), EP_WATCHDOG_S))
+        if want_ep and args.ep_native and backend == "nccl" and not args.ep_capacity:
+            nat_chunks = args.ep_chunks if (args.ep_chunks > 1 and (E // world) % args.ep_chunks == 0) else 1
+            legs.append(("ep_native", "ep_native", lambda: run_mode(args.dtype, True, False, ep_chunks=nat_chunks, ep_native=True),
+                         EP_WATCHDOG_S))
         if want_dp and args.share_stem and not args.serial_tasks:
             legs.append(("dp_shared_stem", "dp_shared_stem", lambda: run_mode(args.dtype, False, False, share_stem=True),
                          SHARED_WATCHDOG_S))
@@ -631,7 +654,7 @@ def main():
         # ~3.7 GB of routed rows per step and rank through the xGMI links (DESIGN.md section 6 has the predicted table) where
         # data parallelism moves one 172 MB gradient all-reduce - north_star asks for the all-to-all "only where experts shard"
         # (the shared-stem leg is reported, and eligible as the primary only with --share-stem: same policy as at N = 1)
-        ran = [r for r in (results.get(True), results.get("ep_overlap"), results.get(False),
+        ran = [r for r in (results.get(True), results.get("ep_overlap"), results.get("ep_native"), results.get(False),
                            results.get("dp_shared_stem") if args.share_stem else None) if r is not None]
         main_res = max(ran, key=lambda r: r["value"]) if ran else None
         if main_res is None:

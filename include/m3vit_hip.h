@@ -178,6 +178,31 @@ int m3_ep_plan_fixed(const int64_t *send_counts, const int64_t *recv_counts, int
                      int32_t *regroup, int32_t *offsets, int32_t *tile_starts, int32_t *pad_idx,
                      int32_t *unpad_idx, int32_t *overflow, void *stream);
 
+/* The exchange itself over RCCL (xGMI), for a caller that does not go through torch.distributed: what fastmoe's
+ * expert_exchange / global_scatter / global_gather do behind _fmoe_general_global_forward (custom_moe_layer.py:263-265,
+ * world_size > 1; experts sharded per utils/common_config.py:179-185).  The only state the library keeps: communicators.
+ *   m3_ep_unique_id        rank 0: 128 bytes (ncclUniqueId) to hand to every rank out of band (e.g. a broadcast over gloo)
+ *   m3_ep_init             collective over the `world` ranks -> *handle; one communicator per expert-parallel group
+ *   m3_ep_exchange_counts  all-to-all of e_loc int64 counts per peer (device buffers [world * e_loc], layout as m3_ep_plan takes)
+ *   m3_ep_dispatch         all-to-all-v of rows (row_bytes each): peer p gets in_splits[p] consecutive rows of send_rows and
+ *                          delivers out_splits[p] rows into recv_rows, in rank order; the split arrays are HOST arrays of
+ *                          `world` row counts - what m3_ep_plan returned in `splits`.  One grouped set of ncclSend / ncclRecv
+ *                          pairs on the caller's stream: a distinct peer per xGMI link, nothing chunked into ring steps
+ *   m3_ep_return           the way home: the same exchange with the two split vectors swapped
+ *   m3_ep_destroy          frees the communicator
+ * librccl is opened at the first m3_ep_unique_id / m3_ep_init call (dlopen): the library has no link-time dependency on it.
+ * Asynchronous on `stream` like every other entry point; errors of the collective library come back as M3_ERR_LAUNCH with
+ * its text in m3_last_error().  (The engine's default exchange is torch.distributed, backend nccl = RCCL, which the two-rank
+ * gloo rehearsals can test; BackboneEngine(ep_native=True) routes the row exchanges through these entry points instead.) */
+int m3_ep_unique_id(void *out128);
+int m3_ep_init(const void *unique_id128, int rank, int world, int *handle);
+int m3_ep_destroy(int handle);
+int m3_ep_exchange_counts(int handle, const int64_t *send_counts, int64_t *recv_counts, int e_loc, void *stream);
+int m3_ep_dispatch(int handle, const void *send_rows, const int64_t *in_splits, void *recv_rows, const int64_t *out_splits,
+                   int64_t row_bytes, void *stream);
+int m3_ep_return(int handle, const void *send_rows, const int64_t *out_splits, void *recv_rows, const int64_t *in_splits,
+                 int64_t row_bytes, void *stream);
+
 /* -------------------------------------------------- GEMM family (a6, a8, a10)
  * C[m, n] = epilogue( sum_k A[arow(m), k] * B[g(m)][n, k] )      ("NT": both K-contiguous)
  *   FMoELinear fwd/dgrad: custom_moe_layer.py:32-33,41,43; qkv/proj Linear:

@@ -135,6 +135,12 @@ SIGNATURES = {
     "m3_relu_up2x_fwd": (c_int, [_V, _I, _L, _I, _I, _I, _I, _V, _I, _V]),
     "m3_relu_up2x_bwd": (c_int, [_V, _I, _V, _I, _L, _I, _I, _I, _I, _V, _V]),
     "m3_ep_plan_fixed": (c_int, [_V, _V, _I, _I, _I, _V, _V, _L, _V, _V, _V, _V, _V, _V, _V, _V]),
+    "m3_ep_unique_id": (c_int, [_V]),
+    "m3_ep_init": (c_int, [_V, _I, _I, POINTER(c_int)]),
+    "m3_ep_destroy": (c_int, [_I]),
+    "m3_ep_exchange_counts": (c_int, [_I, _V, _V, _I, _V]),
+    "m3_ep_dispatch": (c_int, [_I, _V, _V, _V, _V, _L, _V]),
+    "m3_ep_return": (c_int, [_I, _V, _V, _V, _V, _L, _V]),
     "m3_gemm_nt": (c_int, [POINTER(GemmArgs), _V]),
     "m3_experimental": (c_int, []),
     "m3_gemm_set_variant": (c_int, [_I]),

@@ -44,7 +44,7 @@ class BackboneEngine:
     def __init__(self, cfg, params: Dict[str, torch.Tensor], batch: int, dtype=torch.float16,
                  device="cuda:0", ep_group=None, ep_world: int = 1, ep_rank: int = 0, share: "BackboneEngine" = None,
                  wgrad_stream: bool = False, checkpoint: bool = False, ep_capacity: float = 0.0,
-                 experts_are_local: bool = False, ep_chunks: int = 1):
+                 experts_are_local: bool = False, ep_chunks: int = 1, ep_native: bool = False):
         """params: GLOBAL parameters (all E experts).  With ep_world > 1 this rank keeps experts
         [ep_rank*E/W, (ep_rank+1)*E/W) (utils/common_config.py:179-185) and exchanges routed rows with
         the other ranks over torch.distributed (RCCL) - see _experts_fwd_ep.
@@ -70,6 +70,9 @@ class BackboneEngine:
         ep_chunks (with ep_world > 1, exact exchange; 1 = one all-to-all-v each way): cut every exchange into this many
         chunks of E_loc / ep_chunks local experts (on every destination) and overlap them with the experts' GEMMs inside ONE
         pass - see _experts_fwd_ep_chunked.  Same results bit for bit.
+        ep_native (with ep_world > 1; opt-in, never run on more than one rank on this build box): the count and row exchanges
+        go through the library's own RCCL entry points (m3vit_amd/ep_native.py: m3_ep_exchange_counts / m3_ep_dispatch /
+        m3_ep_return) instead of torch.distributed's all_to_all_single.
         experts_are_local (with ep_world > 1): the expert tensors in `params` are already this rank's slice [E / W, ..] (a
         module built the way utils/common_config.py:179-185 builds it: moe_experts // world_size experts per rank) and are
         taken as they are - in place - instead of being cut out of global tensors."""
@@ -101,6 +104,14 @@ class BackboneEngine:
         assert self.E % self.ep_world == 0, "experts must divide evenly over the EP ranks"
         self.E_loc = self.E // self.ep_world
         self.ep_chunks = int(ep_chunks) if (self.ep_world > 1 and int(ep_chunks) > 1) else 1
+        self.ep_native = None
+        if ep_native and self.ep_world > 1:
+            assert not ep_capacity, "ep_native carries the exact exchange only (the fixed-capacity form is one equal-split all-to-all)"
+            if share is not None and getattr(share, "ep_native", None) is not None:
+                self.ep_native = share.ep_native                   # one communicator per expert-parallel group and process
+            else:
+                from .ep_native import NativeExchange
+                self.ep_native = NativeExchange(self.ep_rank, self.ep_world, group=ep_group, device=device)
         assert self.E_loc % self.ep_chunks == 0, "ep_chunks must divide the experts per rank"
         is_exp = lambda n: ".mlp.experts." in n                                  # noqa: E731
         lo, hi = self.ep_rank * self.E_loc, (self.ep_rank + 1) * self.E_loc
@@ -522,6 +533,9 @@ class BackboneEngine:
     def _a2a(self, x, in_splits, out_splits):
         import torch.distributed as dist
         out = torch.empty((sum(out_splits),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        if self.ep_native is not None:
+            self.ep_native.dispatch_async(out, x.contiguous(), out_splits, in_splits).wait()
+            return out
         dist.all_to_all_single(out, x.contiguous(), output_split_sizes=out_splits, input_split_sizes=in_splits,
                                group=self.ep_group)
         return out
@@ -554,8 +568,11 @@ class BackboneEngine:
         a["route"] = r
         x_send = self._e(self.R, D)
         ops.gather_rows(a["h2"], r.row_of_slot, x_send, div=k)
-        recv = torch.empty_like(r.counts64)
-        dist.all_to_all_single(recv, r.counts64, group=self.ep_group)
+        if self.ep_native is not None:
+            recv = self.ep_native.exchange_counts(r.counts64)
+        else:
+            recv = torch.empty_like(r.counts64)
+            dist.all_to_all_single(recv, r.counts64, group=self.ep_group)
         # the plan (regroup index, expert-major offsets, tile prefix) is built on the device; the host reads the
         # 2 W split sizes the a2a-v API needs and nothing else
         plan = ops.ep_plan(r.counts64, recv, self.ep_world, self.E_loc, self.ep_regroup[i], splits_host=self.ep_splits_host)
@@ -582,6 +599,8 @@ class BackboneEngine:
     # ------------------------------------------------------------------ expert parallel, exchange overlapped inside ONE pass
     def _a2a_async(self, out, x, out_splits, in_splits):
         import torch.distributed as dist
+        if self.ep_native is not None:
+            return self.ep_native.dispatch_async(out, x, out_splits, in_splits)
         return dist.all_to_all_single(out, x, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.ep_group,
                                       async_op=True)
 
@@ -607,8 +626,11 @@ class BackboneEngine:
         ops.gather_rows(a["h2"], r.row_of_slot, x_send, div=k)
         send = r.counts64.view(C, W, Ec)
         snd_dm = send.permute(1, 0, 2).contiguous()                                         # destination-major for the count exchange
-        rcv_dm = torch.empty_like(snd_dm)
-        dist.all_to_all_single(rcv_dm.view(-1), snd_dm.view(-1), group=self.ep_group)
+        if self.ep_native is not None:
+            rcv_dm = self.ep_native.exchange_counts(snd_dm.view(-1)).view_as(snd_dm)
+        else:
+            rcv_dm = torch.empty_like(snd_dm)
+            dist.all_to_all_single(rcv_dm.view(-1), snd_dm.view(-1), group=self.ep_group)
         recv = rcv_dm.permute(1, 0, 2).contiguous()                                         # [C][source][expert of the chunk]
         plans = ops.ep_plan_chunks(send.contiguous(), recv, W, Ec, self.ep_regroup_c[i], self.ep_splits_host_c)
         ns = [sum(pl.in_splits) for pl in plans]

@@ -28,11 +28,13 @@ class MultiTaskStep:
     def __init__(self, cfg, params, batch: int, dtype=torch.float16, device="cuda:0", tasks=None, cv_weight: float = 0.01,
                  parallel_tasks: bool = True, graph: bool = True, world: int = 1, rank: int = 0, expert_parallel: bool = False,
                  wgrad_streams: bool = False, dp_parts: int = 6, checkpoint: bool = False, share_stem: bool = False,
-                 ep_capacity: float = 0.0, ep_chunks: int = 1):
+                 ep_capacity: float = 0.0, ep_chunks: int = 1, ep_native: bool = False):
         """ep_capacity (expert parallel only; 0 = the exact exchange): fixed row capacity of the exchange as a multiple of
         the uniform share R / W per (source, destination) pair (BackboneEngine ep_capacity).  The step then reads ONE flag
         on the host, at its end, instead of 2 W split sizes per MoE layer and pass, and repeats itself on the exact path
-        when some pair overflowed (same gradients either way: tests/test_ep_engine_gpu.py)."""
+        when some pair overflowed (same gradients either way: tests/test_ep_engine_gpu.py).
+        ep_native (expert parallel, exact exchange): the exchanges go through the library's RCCL entry points
+        (m3vit_amd/ep_native.py) instead of torch.distributed - opt-in, see BackboneEngine."""
         self.cfg, self.dev, self.world, self.cv_weight = cfg, torch.device(device), int(world), float(cv_weight)
         if tasks is None:
             tasks = list(range(cfg.num_tasks)) if (cfg.multi_gate or cfg.gate_task_specific_dim >= 0) else [None]
@@ -48,7 +50,8 @@ class MultiTaskStep:
         self.ep_repeats = 0                              # steps repeated on the exact path after a capacity overflow
         self.eng = BackboneEngine(cfg, params, batch=batch, dtype=dtype, device=str(self.dev),
                                   ep_world=self.world if self.use_ep else 1, ep_rank=rank if self.use_ep else 0,
-                                  wgrad_stream=wg, checkpoint=checkpoint, ep_capacity=self.ep_capacity, ep_chunks=self.ep_chunks)
+                                  wgrad_stream=wg, checkpoint=checkpoint, ep_capacity=self.ep_capacity, ep_chunks=self.ep_chunks,
+                                  ep_native=bool(ep_native) and self.use_ep)
         self.par = bool(parallel_tasks) and not self.use_ep and len(self.tasks) > 1
         # expert parallel: the task passes still get their own engine contexts and streams, but their blocks are
         # interleaved on the host (_ep_interleaved): each pass stops once per MoE layer to read its exchange's split
@@ -56,7 +59,8 @@ class MultiTaskStep:
         self.par_ep = bool(parallel_tasks) and self.use_ep and len(self.tasks) > 1
         self.engs = [self.eng] + ([BackboneEngine(cfg, None, batch=batch, dtype=dtype, device=str(self.dev), share=self.eng,
                                                    ep_world=self.world if self.use_ep else 1, ep_rank=rank if self.use_ep else 0,
-                                                   wgrad_stream=wg, checkpoint=checkpoint, ep_capacity=self.ep_capacity, ep_chunks=self.ep_chunks)
+                                                   wgrad_stream=wg, checkpoint=checkpoint, ep_capacity=self.ep_capacity, ep_chunks=self.ep_chunks,
+                                                   ep_native=bool(ep_native) and self.use_ep)
                                     for _ in self.tasks[1:]]
                                     if (self.par or self.par_ep) else [])
         # (measured and dropped in round 3, profiles/r03_stream_experiments.txt: a high-priority side stream serialises the
@@ -112,12 +116,14 @@ class MultiTaskStep:
         # side-by-side passes are captured as one linear graph per pass and stream (_capture_linear); the shared stem, whose
         # passes meet in the middle of a part, keeps the one-graph-per-part form with the fork inside the capture
         import os as _os
-        # (N > 1 keeps one graph per part unless M3_LINEAR_GRAPHS=1: the only multi-rank runs this build box allows - two
-        # PROCESSES on one GPU over gloo - stall for seconds per step with the per-pass graphs (71 -> 1 861 ms/step; the device
-        # stops executing both processes' queued work, profiles/r04_dp_shared_stem_stall.txt has the mechanism), so the form
-        # that has been rehearsed stays the default there until a one-rank-per-GPU run says otherwise)
+        # (also at N > 1 since round 5, one linear graph per (part, pass).  Round 4 turned this off there because the only
+        # multi-rank run this build box allows - two PROCESSES on one GPU over gloo - stalled for seconds per step with it;
+        # profiles/r05_dp_two_rank_stream_count.txt found the cause: the two processes' streams outnumber the hardware queues
+        # HIP maps them to by default (one task stream per step is slower still, 8 757 ms; GPU_MAX_HW_QUEUES=8 -> 103 ms per
+        # step against 130 for the one-graph-per-part form).  One rank per GPU never shares queues; the one-device rehearsals
+        # (bench.py M3_BENCH_ONE_DEVICE, tests) raise the queue count.  M3_LINEAR_GRAPHS=0 restores one graph per part.)
         lin = _os.environ.get("M3_LINEAR_GRAPHS", "auto")
-        self.linear_graphs = self.par and (lin == "1" or (lin == "auto" and self.world == 1)) and \
+        self.linear_graphs = self.par and lin != "0" and \
             not (self.share_stem and nparts > 1)            # (a shared stem cut into data-parallel parts keeps the old form)
         self.graphs = None
         self.capture_error = None

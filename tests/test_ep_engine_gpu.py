@@ -45,6 +45,7 @@ def _worker(rank, world, port, q, case="toy_f32"):
     the fp16 bound of tests/test_engine.py."""
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")       # two processes on one device (profiles/r05_dp_two_rank_stream_count.txt)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from m3vit_amd.config import BackboneConfig, init_params
@@ -121,6 +122,7 @@ def _dp_worker(rank, world, port, q):
     leave on EVERY rank the mean over the ranks of the serial per-rank gradients, eagerly and as replayed graphs"""
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")       # two processes on one device (profiles/r05_dp_two_rank_stream_count.txt)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from m3vit_amd.config import BackboneConfig, init_params
@@ -183,6 +185,7 @@ def _ep_step_worker(rank, world, port, q):
     (MultiTaskStep._ep_interleaved) must leave the gradients of the one-pass-after-the-other expert-parallel step"""
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")       # two processes on one device (profiles/r05_dp_two_rank_stream_count.txt)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from m3vit_amd.config import BackboneConfig, init_params
@@ -239,6 +242,7 @@ def _ep_fixed_worker(rank, world, port, q):
     the comparison is bit-exact except for the slab order of the grouped weight gradients (different M bound)."""
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")       # two processes on one device (profiles/r05_dp_two_rank_stream_count.txt)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from m3vit_amd.config import BackboneConfig, init_params
@@ -326,6 +330,7 @@ def _ep_ckpt_worker(rank, world, port, q):
     bit (same kernels on the same inputs)."""
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")       # two processes on one device (profiles/r05_dp_two_rank_stream_count.txt)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from m3vit_amd.config import BackboneConfig, init_params
@@ -394,6 +399,7 @@ def _chunk_worker(rank, world, port, q, case, chunks, checkpoint):
     carried it, and the weight gradients run on the same expert-major rows in the same launches)"""
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")       # two processes on one device (profiles/r05_dp_two_rank_stream_count.txt)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from m3vit_amd.config import BackboneConfig, init_params
@@ -437,6 +443,95 @@ def test_expert_parallel_exchange_overlapped_in_chunks_two_ranks_one_gpu(case, c
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_chunk_worker, args=(r, 2, port, q, case, chunks, checkpoint)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert all(r[1] == "ok" for r in res), res
+
+
+class _ExchangeDouble:
+    """m3vit_amd.ep_native.NativeExchange's interface over torch.distributed: RCCL refuses two ranks on one device, so on the
+    one-GPU build box the engine's ep_native hooks (which exchange goes where, argument order, the work objects' wait()) are
+    rehearsed with this stand-in; the entry points themselves run on a one-rank communicator in tests/test_ep_rccl_gpu.py"""
+    calls = 0
+
+    def __init__(self, rank, world, group=None, device=None):
+        self.rank, self.world, self.group = rank, world, group
+
+    def exchange_counts(self, send_counts):
+        import torch.distributed as dist
+        assert send_counts.dtype == torch.int64 and send_counts.numel() % self.world == 0
+        recv = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv, send_counts, group=self.group)
+        _ExchangeDouble.calls += 1
+        return recv
+
+    def dispatch_async(self, out, x, out_splits, in_splits):
+        import torch.distributed as dist
+        assert x.is_contiguous() and out.is_contiguous() and sum(in_splits) == x.shape[0] and sum(out_splits) == out.shape[0]
+        _ExchangeDouble.calls += 1
+        return dist.all_to_all_single(out, x, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits),
+                                      group=self.group, async_op=True)
+
+    return_async = dispatch_async
+
+    def close(self):
+        pass
+
+
+def _native_hook_worker(rank, world, port, q, chunks):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import m3vit_amd.ep_native as ep_native
+        from m3vit_amd.config import BackboneConfig, init_params
+        from m3vit_amd.engine import BackboneEngine
+        ep_native.NativeExchange = _ExchangeDouble
+        torch.cuda.set_device(0)
+        c = EP_CASES["toy_f32"]
+        cfg = BackboneConfig(**c["cfg"])
+        dtype, B = getattr(torch, c["dtype"]), c["B"]
+        P = init_params(cfg, seed=3, zero_bias=False)
+        g = torch.Generator().manual_seed(60 + rank)
+        img = torch.randn(B, 3, *cfg.img_size, generator=g).cuda()
+        dtok = (torch.randn(B, cfg.num_tokens, cfg.embed_dim, generator=g) * 0.1).cuda()
+        one = BackboneEngine(cfg, P, batch=B, dtype=dtype, ep_world=world, ep_rank=rank, ep_chunks=chunks)
+        nat = BackboneEngine(cfg, P, batch=B, dtype=dtype, ep_world=world, ep_rank=rank, ep_chunks=chunks, ep_native=True)
+        assert one.ep_native is None and isinstance(nat.ep_native, _ExchangeDouble)
+        for task in (0, 1):
+            t1, cv1 = one.forward(img, task)
+            before = _ExchangeDouble.calls
+            t2, cv2 = nat.forward(img, task)
+            assert _ExchangeDouble.calls > before, "the native hooks were not taken"
+            assert torch.equal(t1, t2) and torch.equal(cv1, cv2), ("forward", task)
+            one.backward(dtok, cv_weight=0.01)
+            nat.backward(dtok, cv_weight=0.01)
+        torch.cuda.synchronize()
+        bad = [n for n in one.grads if not torch.equal(one.grads[n], nat.grads[n])]
+        assert not bad, bad
+        q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("chunks", [1, 2])
+def test_engine_native_exchange_hooks_two_ranks_one_gpu(chunks):
+    """BackboneEngine(ep_native=True): every count / row exchange goes through the NativeExchange object and the results
+    are those of the torch.distributed exchange bit for bit (stand-in exchange: see _ExchangeDouble)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_native_hook_worker, args=(r, 2, port, q, chunks)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
