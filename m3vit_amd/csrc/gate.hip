@@ -54,14 +54,31 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
   constexpr int EPC = 16 / (int)sizeof(T);         // elements per chunk
   constexpr int NCH = GATE_TOK * CPR / NT;         // chunks per thread per step
   constexpr int NWE = (DC * EPAD + NT - 1) / NT;   // w_gate slice elements per thread per step
-  __shared__ __attribute__((aligned(16))) float sx[2][GATE_TOK * LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) float sw[2][DC * EPAD];   // w_gate rows of the step, zero-padded to EPAD
-  __shared__ float slog[NW > 1 ? GATE_TOK * (EPAD + 1) : 1];
-  // epilogue staging (round 5): the token-per-lane epilogue of wave 0 leaves the dense rows (clean, noisy, gates), the
-  // token's top-k mask and its two CDF thresholds here; ALL waves then store the rows coalesced and share the per-expert
-  // partial sums.  (Written from registers by lane = token, a dense [T, E] output was 64 four-byte stores to 64 different
-  // lines per instruction, E times per array, and the E butterfly sums ran in one wave: 213 us at E = 64, D = 768.)
-  __shared__ float sdense[3][GATE_TOK * (EPAD + 1)];
+  // w_gate rows by SCALAR loads (round 5, exact E only): every lane of a wave multiplies its token by the same EW weights,
+  // so the row slice w[d][e0 .. e0+EW) belongs in SGPRs (s_load_dwordx{4,8,16}, v_pk_fma with an SGPR-pair operand), not in
+  // LDS: read from LDS as wave-wide broadcasts it cost one 16-byte ds_read per two packed fmas, in four waves at once - the
+  // LDS pipe, not the fma chain, set the time (220 us at E = 64, D = 768).  The fma chain per logit is unchanged (over d in
+  // order), so the results are bit for bit the staged form's.
+  // Only where a wave owns 16 experts (E = 64): with 4 experts per wave the scalar loads are too small to pay (E = 16,
+  // D = 384: 28 us staged, 38 us scalar - the scalar cache misses per 64-byte line and nothing hides it).
+  constexpr bool SW = EXACT && EW >= 16;
+  // LDS: [sx: the step's token rows as fp32, double-buffered | sw: the step's w_gate rows (staged form only)] during the
+  // main loop; afterwards the noisy logits and gates of the epilogue lie over sx (every wave is past its last read of sx at
+  // the barrier behind the clean logits), the clean logits have a region of their own (written while other waves may
+  // still be in the main loop).  52 KiB at E = 64 (three workgroups per CU) where separate arrays took 132 KiB (one).
+  constexpr int SXF = 2 * GATE_TOK * LDS_STRIDE;                 // floats
+  constexpr int SWF = SW ? 0 : 2 * DC * EPAD;
+  constexpr int SDF = GATE_TOK * (EPAD + 1);                     // one dense [token][expert] array, +1: lane = token reads
+  constexpr int OVER = (2 * SDF > SXF + SWF) ? 2 * SDF : SXF + SWF;
+  __shared__ __attribute__((aligned(16))) float smem[OVER + SDF];
+  float (*sx)[GATE_TOK * LDS_STRIDE] = reinterpret_cast<float (*)[GATE_TOK * LDS_STRIDE]>(smem);
+  float (*sw)[DC * EPAD] = reinterpret_cast<float (*)[DC * EPAD]>(smem + SXF);
+  // epilogue staging: the token-per-lane epilogue of wave 0 leaves the dense rows (clean, noisy, gates), the token's
+  // top-k mask and its two CDF thresholds here; ALL waves then store the rows coalesced and share the per-expert partial
+  // sums.  (Written from registers by lane = token, a dense [T, E] output was 64 four-byte stores to 64 different lines
+  // per instruction, E times per array, and the E butterfly sums ran in one wave.)
+  float *const sdense[3] = {smem + OVER, smem, smem + SDF};      // [0] clean (also the waves' hand-over to wave 0)
+  float *const slog = sdense[0];
   __shared__ unsigned long long ssel[GATE_TOK];
   __shared__ float sthr[2][GATE_TOK];
 
@@ -82,6 +99,7 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
 
   // staging: chunk q = tid + NT*i -> row q / CPR, c = q % CPR; rows past T and bytes past D read as zero
   auto fetch_w = [&](int step, float (&prew)[NWE]) {
+    if constexpr (SW) return;
 #pragma unroll
     for (int i = 0; i < NWE; ++i) {
       const int q = tid + NT * i;                  // element (dd, e) of the slice
@@ -101,10 +119,12 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
     }
   };
   auto stash = [&](int buf, const u32x4 (&pre)[NCH], const float (&prew)[NWE]) {
+    if constexpr (!SW) {
 #pragma unroll
-    for (int i = 0; i < NWE; ++i) {
-      const int q = tid + NT * i;
-      if (q < DC * EPAD) sw[buf][q] = prew[i];
+      for (int i = 0; i < NWE; ++i) {
+        const int q = tid + NT * i;
+        if (q < DC * EPAD) sw[buf][q] = prew[i];
+      }
     }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -123,9 +143,10 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
   };
   // the step's w_gate rows come from LDS (all lanes read the same address: broadcast), x from the
   // lane's own LDS row; per logit the fma chain runs over d in order, as the oracle's
-  auto compute = [&](int buf, int dn) {
+  auto compute = [&](int buf, int d0, int dn) {
     const float *xs = &sx[buf][lane * LDS_STRIDE];
-    const float *ws = &sw[buf][e0];
+    // SW: the rows of the step straight from w_gate, wave-uniform addresses (scalar loads); else the staged copy
+    const float *ws = SW ? p.w + (int64_t)d0 * EPAD + e0 : &sw[buf][e0];
     // four d per 16-byte read of the lane's row (the fma chain per logit still runs over d in order)
     int dd = 0;
 #pragma unroll 4
@@ -157,7 +178,7 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
     for (int st = 0; st < NS; ++st) {
       stash(st & 1, px[st], pw[st]);
       __syncthreads();          // one barrier per step: the other buffer is only rewritten after the next one
-      compute(st & 1, DC);
+      compute(st & 1, st * DC, DC);
     }
   } else {
     u32x4 pre[NCH];
@@ -170,7 +191,7 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
       __syncthreads();            // one barrier per step: the other buffer is only rewritten after the next one
       if (step + 1 < nsteps) { fetch_w(step + 1, prew); fetch_x(step + 1, pre); }
       const int d0 = step * DC;
-      compute(buf, (D - d0 < DC) ? (D - d0) : DC);
+      compute(buf, d0, (D - d0 < DC) ? (D - d0) : DC);
     }
   }
 
@@ -251,7 +272,7 @@ __global__ __launch_bounds__(GATE_TOK *(EPAD / EW)) void gate_fwd_kernel(const G
   for (int e = 0; e < EPAD; ++e) {
     const bool sel = (sel_k >> e) & 1ull;
     const float pr = q[e] / s;
-    sdense[0][lane * (EPAD + 1) + e] = cl[e];
+    if constexpr (NW == 1) sdense[0][lane * (EPAD + 1) + e] = cl[e];       // (NW > 1: the waves' hand-over already lies there)
     sdense[1][lane * (EPAD + 1) + e] = nz[e];
     sdense[2][lane * (EPAD + 1) + e] = ((EXACT || e < E) && sel && tok_ok) ? pr : 0.f;
   }
