@@ -355,6 +355,11 @@ int m3_wgrad_set_wide(int on);
  * fp32 summation order (64 instead of 32 contraction rows per accumulation step in 16 bit). */
 int m3_wgrad_set_dma(int on);
 int m3_wgrad_tile(int N, int K, int dtype, int *tn, int *tk);
+/* 1 when m3_wgrad_tn runs a plain call of this shape (one group, no gathers / factor / bias / balanced units / direct mode) with
+ * the streaming kernel for K = 16 / 32 - the router's weight, dW_gate = h^T d_logits (custom_moe_layer.py:213-217) - instead of
+ * a 128 x 128 MFMA tile padded eightfold: the caller then sizes `splits` for a stream over dC (ops.default_wgrad_splits:
+ * at least 64 rows per part, at most 256 parts).  Slab layout and reduction are unchanged.  M3_WGRAD_SKINNY=0 switches it off. */
+int m3_wgrad_skinny(int N, int K, int G);
 /* balanced mode: dW[g] (+)= sum over group g's units of ws[u] (elems = N*K per group), unit order; optionally the
  * same for the bias slabs (bias_elems = N per group) */
 int m3_wgrad_reduce_grouped(const float *ws, const int32_t *group_offsets, int G, int chunk_rows, int64_t elems,

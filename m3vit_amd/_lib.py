@@ -148,6 +148,7 @@ SIGNATURES = {
     "m3_ffn_fwd": (c_int, [POINTER(FfnArgs), _V]),
     "m3_wgrad_tn": (c_int, [POINTER(WgradArgs), _V]),
     "m3_wgrad_tile": (c_int, [_I, _I, _I, POINTER(c_int), POINTER(c_int)]),
+    "m3_wgrad_skinny": (c_int, [_I, _I, _I]),
     "m3_wgrad_set_wide": (c_int, [_I]),
     "m3_wgrad_set_dma": (c_int, [_I]),
     "m3_wgrad_reduce": (c_int, [_V, _I, _L, _V, _I, _V, _L, _V, _I, _V]),

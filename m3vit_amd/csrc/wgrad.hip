@@ -42,6 +42,7 @@ struct WgradDev {
   // (m3_wgrad_args.prev): rd_blocks > 0 switches it on; layouts as m3_wgrad_reduce / m3_wgrad_reduce_grouped take them
   int32_t rd_blocks, rd_zslices;   // reduce blocks (flattened x, group) and the grid z slices they occupy
   int32_t rd_nbx, rd_nbw;          // blocks per group (weight + bias part), of those for the weight elements
+  int32_t rd_cols;                 // 16-byte columns per reduce block: 256, or 64 with four threads per column (dense, many slabs)
   const float *rd_ws; int32_t rd_splits; int64_t rd_e4;
   const int32_t *rd_off; int32_t rd_G, rd_chunk;
   float *rd_dW; int32_t rd_beta;
@@ -175,7 +176,8 @@ __device__ __forceinline__ f32x4 read_tr_frag<float>(const char *base, int rb, i
 }
 
 __device__ __forceinline__ void wgrad_reduce_block(int64_t blk, int tid, const float *ws, int splits, int64_t elems4, float *dW,
-                                                   int beta, int nb_w, const float *bias_ws, int64_t belems4, float *db, int beta_db);
+                                                   int beta, int nb_w, const float *bias_ws, int64_t belems4, float *db, int beta_db,
+                                                   int cols);
 __device__ __forceinline__ void wgrad_reduce_grouped_block(int64_t blk, int g, int tid, const float *ws, const int32_t *off, int G,
                                                            int chunk, int64_t elems4, float *dW, int beta, int nb_w,
                                                            const float *bias_ws, int64_t belems4, float *db, int beta_db);
@@ -195,7 +197,7 @@ __device__ __forceinline__ bool wgrad_ride_along(const WgradDev &p, int tid, int
                                    p.rd_bws, p.rd_b4, p.rd_db, p.rd_beta_db);
       else
         wgrad_reduce_block(bx, tid, p.rd_ws, p.rd_splits, p.rd_e4, p.rd_dW, p.rd_beta, p.rd_nbw, p.rd_bws, p.rd_b4, p.rd_db,
-                           p.rd_beta_db);
+                           p.rd_beta_db, p.rd_cols);
     }
     return true;
   }
@@ -702,6 +704,93 @@ __global__ __launch_bounds__(WG_THREADS, SC ? 3 : 4) void wgrad_dma_kernel(const
   wgrad_store_tile(p, acc, slab_id, g, n0, k0, wr, wc, li, lg);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Skinny weight gradient: dW [N, K] with K = 16 or 32 - the router's w_gate (custom_moe_layer.py:213-217:
+// dW_gate = h^T d_logits, K = num_experts), no gathers, no bias, one group.  A 128 x 128 MFMA tile pads K to 128: seven of
+// eight MFMAs multiply zeros and every A-side DMA piece takes the clamped tail path (25 us fp16 / 112 us fp32 per launch at
+// M = 25 216, N = 384 for 0.3 GFLOP).  Here the call is what it is, a stream over dC: lane = two columns n of a 128-wide
+// column tile, the 16 k of the wave's slice in registers (32 fp32 accumulators), the A row - the same for every lane - read
+// by scalar loads, one fma per (row, n, k).  The four waves of a workgroup take interleaved rows (K = 16) or two k slices x
+// two row phases (K = 32) and add up through LDS; a workgroup's [128, K] block goes to its slab exactly like a 128 x 128
+// kernel's (same layout, same reduction riding on the next launch).
+template <typename T, int KP>
+__global__ __launch_bounds__(WG_THREADS) void wgrad_skinny_kernel(const WgradDev p) {
+  constexpr int KS = KP / 16, PH = 4 / KS, UNR = 16;
+  constexpr int ES = (int)sizeof(T);
+  __shared__ float sred[4][64][2][16];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bz, gz;
+  if (wgrad_ride_along(p, tid, bz, gz)) return;
+  const int ks = wave % KS, ph = wave / KS;
+  const int n0 = blockIdx.x * WG_T;
+  int n = n0 + 2 * lane;
+  if (n > p.N - 2) n = p.N - 2;                       // clamped columns are computed and never stored
+  const int64_t per = (p.M + p.splits - 1) / p.splits;
+  const int64_t r0 = (int64_t)bz * per, r1 = (r0 + per < p.M) ? r0 + per : p.M;
+  typedef T t2 __attribute__((ext_vector_type(2)));
+  typedef T t16 __attribute__((ext_vector_type(16)));
+  float acc[2][16];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[j][k] = 0.f;
+  const char *cb = p.dC + (int64_t)n * ES;
+  const char *ab = p.A + (int64_t)ks * 16 * ES;
+  // batches of 16 rows (row u of a batch: m + u * PH), every load of a batch issued before its first use.  The A rows - the
+  // same for every lane - are loaded by lanes 0..15 (lane u: row u of the batch, converted to fp32 there) and handed out by
+  // v_readlane: 16 scalar operands per row.  Addresses: one 64-bit base per batch + 32-bit row offsets; the last, partial
+  // batch clamps its rows to the last valid one and zeroes their dC values.
+  const uint32_t ldc = (uint32_t)p.lddc_b, lda = (uint32_t)p.lda_b;
+  auto batch = [&](const char *cm, const char *am, int cnt, auto full) {
+    constexpr bool FULL = decltype(full)::value;
+    t2 c[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int uu = FULL ? u : (u < cnt ? u : cnt - 1);
+      c[u] = *(const t2 *)(cm + (uint32_t)(uu * PH) * ldc);
+    }
+    const int ua = FULL ? (lane & 15) : ((lane & 15) < cnt ? (lane & 15) : cnt - 1);
+    const t16 ar = *(const t16 *)(am + (uint32_t)(ua * PH) * lda);
+    float af[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) af[k] = (float)ar[k];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const bool ok = FULL || u < cnt;                                   // wave-uniform
+      const float c0 = ok ? (float)c[u][0] : 0.f, c1 = ok ? (float)c[u][1] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, af[k]), u));
+        acc[0][k] = __builtin_fmaf(c0, a, acc[0][k]);
+        acc[1][k] = __builtin_fmaf(c1, a, acc[1][k]);
+      }
+    }
+  };
+  int64_t m = r0 + ph;
+  const char *cm = cb + m * p.lddc_b, *am = ab + m * p.lda_b;
+  for (; m + (int64_t)(UNR - 1) * PH < r1; m += (int64_t)UNR * PH) {
+    batch(cm, am, UNR, std::true_type{});
+    cm += (int64_t)UNR * PH * p.lddc_b; am += (int64_t)UNR * PH * p.lda_b;
+  }
+  if (m < r1) batch(cm, am, (int)((r1 - m + PH - 1) / PH), std::false_type{});
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sred[wave][lane][j][k] = acc[j][k];
+  __syncthreads();
+  float *out = p.ws + (int64_t)bz * p.N * p.K;
+  for (int i = tid; i < WG_T * KP; i += WG_THREADS) {
+    const int nl = i / KP, k = i - nl * KP;
+    if (n0 + nl >= p.N) continue;
+    const int sl = k >> 4, kk = k & 15;
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < PH; ++q) v += sred[q * KS + sl][nl >> 1][nl & 1][kk];
+    out[(int64_t)(n0 + nl) * p.K + k] = v;
+  }
+}
+
 #ifdef M3_EXPERIMENTAL      // the wide-tile kernel: built only by `make EXPERIMENTAL=1` (measured no faster in the step; the engine never takes it)
 // ------------------------------------------------------------------------------------------------
 // Wide tiles (fp16): 128(n) x 384(k) for the K = 384 weights (qkv, fc1, expert FC1) and 384(n) x 128(k) for the
@@ -954,31 +1043,56 @@ __global__ __launch_bounds__(WW_THREADS, 2) void wgrad_wide_kernel(const WgradDe
 #endif  // M3_EXPERIMENTAL
 
 // slabs -> dW (blocks [0, nb_w)) and, in the same launch, bias slabs -> db (blocks [nb_w, ...)); splits in order
-__device__ __forceinline__ void wgrad_reduce_block(int64_t blk, int tid, const float *ws, int splits, int64_t elems4, float *dW,
-                                                   int beta, int nb_w, const float *bias_ws, int64_t belems4, float *db, int beta_db) {
-  if (blk >= nb_w) {
-    blk -= nb_w; ws = bias_ws; elems4 = belems4; dW = db; beta = beta_db;
-  }
-  const int64_t i = blk * 256 + tid;
-  if (i >= elems4) return;
-  f32x4 s = beta ? ((const f32x4 *)dW)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-  // eight slabs' loads in flight before the first add (a thread owns ONE 16-byte column of up to 32 slabs: issued one
-  // dependent load at a time the launch was latency-bound); the summation order is unchanged: slab 0, 1, 2 ...
-  const f32x4 *w = (const f32x4 *)ws + i;
-  int sp = 0;
-  for (; sp + 8 <= splits; sp += 8) {
+__device__ __forceinline__ f32x4 wgrad_sum_slabs(const f32x4 *w, int64_t elems4, int lo, int hi, f32x4 s) {
+  // eight slabs' loads in flight before the first add (a thread owns ONE 16-byte column of its slabs: issued one dependent
+  // load at a time the reduction was latency-bound); slabs are added in index order
+  int sp = lo;
+  for (; sp + 8 <= hi; sp += 8) {
     f32x4 v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = w[(int64_t)(sp + j) * elems4];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s += v[j];
   }
-  for (; sp < splits; ++sp) s += w[(int64_t)sp * elems4];
-  ((f32x4 *)dW)[i] = s;
+  for (; sp < hi; ++sp) s += w[(int64_t)sp * elems4];
+  return s;
+}
+// cols = 256: a thread per 16-byte column, the slabs one after the other.  cols = 64 (many slabs - m3_wgrad_reduce_cols: a
+// column's chain of dependent load batches was the whole duration of a launch with 100+ parts): four threads per column,
+// each sums a quarter of the slabs (contiguous ranges), the quarters are added in order by the first; deterministic, another
+// association than cols = 256.  Every thread of the block must call (a barrier inside).
+__device__ __forceinline__ void wgrad_reduce_block(int64_t blk, int tid, const float *ws, int splits, int64_t elems4, float *dW,
+                                                   int beta, int nb_w, const float *bias_ws, int64_t belems4, float *db, int beta_db,
+                                                   int cols) {
+  if (blk >= nb_w) {
+    blk -= nb_w; ws = bias_ws; elems4 = belems4; dW = db; beta = beta_db;
+  }
+  if (cols == 256) {
+    const int64_t i = blk * 256 + tid;
+    if (i >= elems4) return;
+    f32x4 s = beta ? ((const f32x4 *)dW)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    ((f32x4 *)dW)[i] = wgrad_sum_slabs((const f32x4 *)ws + i, elems4, 0, splits, s);
+    return;
+  }
+  __shared__ f32x4 spart[3][64];
+  const int col = tid & 63, part = tid >> 6;
+  const int64_t i = blk * 64 + col;
+  const bool in = i < elems4;
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (in) {
+    if (part == 0 && beta) s = ((const f32x4 *)dW)[i];
+    s = wgrad_sum_slabs((const f32x4 *)ws + i, elems4, splits * part / 4, splits * (part + 1) / 4, s);
+  }
+  if (part > 0) spart[part - 1][col] = s;
+  __syncthreads();
+  if (part == 0 && in) {
+    s += spart[0][col]; s += spart[1][col]; s += spart[2][col];
+    ((f32x4 *)dW)[i] = s;
+  }
 }
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *ws, int splits, int64_t elems4, float *dW, int beta, int nb_w,
-                                                           const float *bias_ws, int64_t belems4, float *db, int beta_db) {
-  wgrad_reduce_block(blockIdx.x, threadIdx.x, ws, splits, elems4, dW, beta, nb_w, bias_ws, belems4, db, beta_db);
+                                                           const float *bias_ws, int64_t belems4, float *db, int beta_db, int cols) {
+  wgrad_reduce_block(blockIdx.x, threadIdx.x, ws, splits, elems4, dW, beta, nb_w, bias_ws, belems4, db, beta_db, cols);
 }
 
 // balanced grouped mode: dW[g] (+)= sum of the slabs of group g's units, in unit order; g = group,
@@ -996,7 +1110,31 @@ __device__ __forceinline__ void wgrad_reduce_grouped_block(int64_t blk, int g, i
   if (i >= elems4) return;
   f32x4 *out = (f32x4 *)dW + (int64_t)g * elems4 + i;
   f32x4 s = beta ? *out : f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int u = first; u < first + n; ++u) s += ((const f32x4 *)ws)[(int64_t)u * elems4 + i];
+  // as in wgrad_reduce_block: up to eight slabs' loads in flight before the first add (one dependent load per unit made the
+  // reduction riding on a short launch - the router's weight gradient - the longest part of it); same summation order
+  const f32x4 *w = (const f32x4 *)ws + (int64_t)first * elems4 + i;
+  int u = 0;
+  for (; u + 8 <= n; u += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = w[(int64_t)(u + j) * elems4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  if (u + 4 <= n) {
+    f32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = w[(int64_t)(u + j) * elems4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += v[j];
+    u += 4;
+  }
+  if (u + 2 <= n) {
+    const f32x4 v0 = w[(int64_t)u * elems4], v1 = w[(int64_t)(u + 1) * elems4];
+    s += v0; s += v1;
+    u += 2;
+  }
+  if (u < n) s += w[(int64_t)u * elems4];
   *out = s;
 }
 __global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const float *ws, const int32_t *off, int G, int chunk, int64_t elems4,
@@ -1101,6 +1239,16 @@ extern "C" int m3_wgrad_tile(int N, int K, int dtype, int *tn, int *tk) {
   return M3_OK;
 }
 
+// 16-byte columns per block of the dense slab reduction: four threads per column from 32 slabs on
+static inline int m3_wgrad_reduce_cols(int splits) { return splits >= 32 ? 64 : 256; }
+static inline bool sc_any(const m3_wgrad_args *a) { return a->c_row_scale != nullptr; }
+
+extern "C" int m3_wgrad_skinny(int N, int K, int G) {
+  static int on = -1;
+  if (on < 0) { const char *e = getenv("M3_WGRAD_SKINNY"); on = e ? (atoi(e) ? 1 : 0) : 1; }
+  return on && G == 1 && (K == 16 || K == 32) && N % 2 == 0 && N >= 2;
+}
+
 extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   M3_REQUIRE(a && a->dC && a->A && (a->ws || a->direct_dW), "m3_wgrad_tn: null operand");
   M3_REQUIRE(dtype_ok(a->dtype), "m3_wgrad_tn: bad dtype");
@@ -1139,7 +1287,7 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   const bool wide = (tn_w != WG_T || tk_w != WG_T) && (d.a_row_div & (d.a_row_div - 1)) == 0 && !d.c_row_scale && d.c_row_div == 1 &&
                     !d.direct_dW;
   // the previous call's slab reduction (a->prev): in front of this launch (128 x 128 kernel), or as its own launch
-  d.rd_blocks = 0; d.rd_zslices = 0;
+  d.rd_blocks = 0; d.rd_zslices = 0; d.rd_cols = 256;
   if (a->prev) {
     const m3_wgrad_reduce_desc *r = a->prev;
     M3_REQUIRE(r->ws && r->dW && r->elems >= 0 && r->elems % 4 == 0 && (r->chunk_rows == 0 ? r->splits >= 1 : (r->group_offsets && r->G >= 1 && r->G <= 64)),
@@ -1154,8 +1302,10 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
         if (rc) return rc;
       } else {
         const int64_t e4 = r->elems / 4, b4 = r->bias_ws ? r->bias_elems / 4 : 0;
-        d.rd_nbw = (int)((e4 + 255) / 256);
-        d.rd_nbx = d.rd_nbw + (int)((b4 + 255) / 256);
+        const int rc_ = r->chunk_rows ? 256 : m3_wgrad_reduce_cols(r->splits);
+        d.rd_cols = rc_;
+        d.rd_nbw = (int)((e4 + rc_ - 1) / rc_);
+        d.rd_nbx = d.rd_nbw + (int)((b4 + rc_ - 1) / rc_);
         d.rd_blocks = d.rd_nbx * (r->chunk_rows ? r->G : 1);
         d.rd_ws = r->ws; d.rd_splits = r->splits; d.rd_e4 = e4; d.rd_off = r->group_offsets; d.rd_G = r->G; d.rd_chunk = r->chunk_rows;
         d.rd_dW = r->dW; d.rd_beta = r->beta; d.rd_bws = r->bias_ws; d.rd_b4 = b4; d.rd_db = r->db; d.rd_beta_db = r->beta_db;
@@ -1192,6 +1342,20 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
     const int per_slice = (int)(grid.x * grid.y);
     d.rd_zslices = (d.rd_blocks + per_slice - 1) / per_slice;
     grid.z += d.rd_zslices;
+  }
+  // the router's weight (K = 16 / 32, plain rows): the streaming kernel (m3_wgrad_skinny reports the rule to the caller,
+  // who sizes `splits` for it)
+  if (m3_wgrad_skinny(a->N, a->K, a->G) && !gc && !ga && !sc_any(a) && !a->bias_ws && !a->chunk_rows && !a->direct_dW) {
+#define M3_WSK(TT)                                                                                  \
+    do {                                                                                            \
+      if (a->K == 16) hipLaunchKernelGGL((wgrad_skinny_kernel<TT, 16>), grid, block, 0, s, d);      \
+      else hipLaunchKernelGGL((wgrad_skinny_kernel<TT, 32>), grid, block, 0, s, d);                 \
+    } while (0)
+    if (a->dtype == M3_F16) M3_WSK(half_t);
+    else if (a->dtype == M3_BF16) M3_WSK(bf16_t);
+    else M3_WSK(float);
+#undef M3_WSK
+    return check_launch("m3_wgrad_tn");
   }
   M3_REQUIRE(a->N * es >= 16 && a->K * es >= 16, "m3_wgrad_tn: N, K too small");
   const size_t lds16 = 4 * WgLds<half_t>::ROWS * WgLds<half_t>::STRIDE, lds32 = 4 * WgLds<float>::ROWS * WgLds<float>::STRIDE;
@@ -1271,9 +1435,10 @@ extern "C" int m3_wgrad_reduce(const float *ws, int splits, int64_t elems, float
              "m3_wgrad_reduce: bias slabs need db, 16-byte alignment and a multiple of 4 elements");
   if (elems == 0) return M3_OK;
   const int64_t e4 = elems / 4, b4 = bias_ws ? bias_elems / 4 : 0;
-  const int nb_w = (int)((e4 + 255) / 256), nb_b = (int)((b4 + 255) / 256);
+  const int cols = m3_wgrad_reduce_cols(splits);
+  const int nb_w = (int)((e4 + cols - 1) / cols), nb_b = (int)((b4 + cols - 1) / cols);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nb_w + nb_b)), dim3(256), 0, (hipStream_t)stream, ws,
-                     splits, e4, dW, beta, nb_w, bias_ws, b4, db, beta_db);
+                     splits, e4, dW, beta, nb_w, bias_ws, b4, db, beta_db, cols);
   return check_launch("m3_wgrad_reduce");
 }
 

@@ -581,19 +581,29 @@ def wgrad_tile(N, K, dtype=None):
     return tn.value, tk.value
 
 
+def wgrad_skinny(N, K, G=1) -> bool:
+    """m3_wgrad_tn takes plain calls of this shape (K = 16 / 32, one group) with the streaming kernel (m3_wgrad_skinny)"""
+    return bool(lib().m3_wgrad_skinny(int(N), int(K), int(G)))
+
+
 def default_wgrad_splits(M, N, K, G, dtype=None):
     """Row splits of the TN GEMM.  128 x 128 tiles: fill the 512 resident workgroup slots (2 per CU) exactly once - more
     splits only add slab traffic and a ragged second wave of workgroups - but keep at least _WGRAD_MIN_STEPS 32-row
     steps per split, so that short contractions (few tokens) do not pay a 64 KiB slab write + reduce per handful of
     steps.  Wide tiles (one 512-thread workgroup per CU, 256 slots): as many splits as fill the slots once; with more
     tiles than a third of the slots (grouped experts) the split count whose workgroups come closest to whole rounds."""
+    if wgrad_skinny(N, K, G):                       # the router's weight: a stream over dC, 64+ rows per part (16 per wave)
+        return int(max(1, min(256, M // 64)))
     tn, tk = wgrad_tile(N, K, dtype)
     tiles = ((N + tn - 1) // tn) * ((K + tk - 1) // tk) * G
     steps = max(1, (M // max(G, 1) + 31) // 32)
     cap = max(1, steps // _WGRAD_MIN_STEPS)
     if (tn, tk) == (128, 128):
         nslots = _wgrad_slots(dtype, N, K, G, tiles)
-        return int(max(1, min(cap, 32, nslots // tiles if tiles <= nslots else 1)))
+        # fp32 is MFMA-bound (1/16 of the fp16 rate): its workgroup slots matter more than its slab bytes, so small weights
+        # (proj: 9 tiles) may be cut into as many parts as fill them; 16-bit stays at 32 (slab traffic)
+        most = 128 if dtype == torch.float32 else 32
+        return int(max(1, min(cap, most, nslots // tiles if tiles <= nslots else 1)))
     slots = 256
     if 3 * tiles <= slots:
         return int(max(1, min(cap, slots // tiles)))
