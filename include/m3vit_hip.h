@@ -354,6 +354,11 @@ int m3_wgrad_set_wide(int on);
  * >= 1024 (one part per group: the ViT-Base experts) or N * K >= 1.5 M elements.  -1 = re-read M3_WGRAD_DMA.  Same results up to
  * fp32 summation order (64 instead of 32 contraction rows per accumulation step in 16 bit). */
 int m3_wgrad_set_dma(int on);
+/* Tuning knob, no reference counterpart: 256 x 256 output tiles (wgrad_big_kernel, csrc/wgrad.hip: eight waves, one workgroup
+ * per CU, two LDS stages filled by LDS-DMA) for 16-bit weights whose N and K are multiples of 256 - the ViT-Base shapes (768,
+ * 2304, 3072).  1 = on (default), 0 = 128 x 128 everywhere, -1 = re-read M3_WGRAD_BIG.  m3_wgrad_tile reports (256, 256) for the
+ * shapes it takes; switch before sizing workspaces.  Same results up to fp32 summation order. */
+int m3_wgrad_set_big(int on);
 int m3_wgrad_tile(int N, int K, int dtype, int *tn, int *tk);
 /* 1 when m3_wgrad_tn runs a plain call of this shape (one group, no gathers / factor / bias / balanced units / direct mode) with
  * the streaming kernel for K = 16 / 32 - the router's weight, dW_gate = h^T d_logits (custom_moe_layer.py:213-217) - instead of

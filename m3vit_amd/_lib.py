@@ -151,6 +151,7 @@ SIGNATURES = {
     "m3_wgrad_skinny": (c_int, [_I, _I, _I]),
     "m3_wgrad_set_wide": (c_int, [_I]),
     "m3_wgrad_set_dma": (c_int, [_I]),
+    "m3_wgrad_set_big": (c_int, [_I]),
     "m3_wgrad_reduce": (c_int, [_V, _I, _L, _V, _I, _V, _L, _V, _I, _V]),
     "m3_wgrad_reduce_grouped": (c_int, [_V, _V, _I, _I, _L, _V, _I, _V, _L, _V, _I, _V]),
     "m3_wgrad_bias_reduce": (c_int, [_V, _I, _L, _V, _I, _V]),

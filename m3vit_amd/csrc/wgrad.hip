@@ -705,6 +705,262 @@ __global__ __launch_bounds__(WG_THREADS, SC ? 3 : 4) void wgrad_dma_kernel(const
 }
 
 // ------------------------------------------------------------------------------------------------
+// 256 x 256 tiles for the ViT-Base weights (16-bit; N and K multiples of 256: 768, 2304, 3072): the 128 x 128 kernels bring
+// 64 FLOP per operand byte into LDS and, with every byte of dC / A needed by K / 128 resp. N / 128 workgroups, run at what
+// that path delivers (configs[3]'s experts: 1.86 GB per launch, 5.3 TB/s, 340 TFLOP/s).  This tile doubles the FLOP per
+// byte: eight waves (wave (wr, wc) owns 128 k x 64 n: 8 x 4 MFMA tiles, 128 accumulator registers), one workgroup per
+// CU, 64 contraction rows per step in two LDS stages of [dC image | A image] (64 rows x 512 B each): the rows of step
+// t + 1 are in flight (LDS-DMA) while step t's fragments are read (ds_read_b64_tr_b16, issued as inline assembly - the
+// compiler would otherwise drain the DMA before every LDS read it knows of) and multiplied.  One barrier per step.
+// Image geometry: a DMA piece (1 KiB) is two rows; lane l -> row + (l >> 5), physical 16-byte chunk l & 31, which holds
+// logical chunk (l & 31) ^ ((row & 7) << 1): the same 8-row XOR as the 128-wide 16-bit image, so the transposed reads
+// (16 rows x 32 bytes per instruction) meet the same banks as there.  Gathers, per-row factor, fused bias sums, slabs or
+// direct accumulation: as wgrad_dma_kernel.  The previous call's reduction does not ride here (512 threads): own launch.
+constexpr int BG_T = 256, BG_THREADS = 512, BG_RS = 512;
+#ifndef M3_WGRAD_BIG_ROWS
+// contraction rows per step: 64 (two stages, one step in flight ahead of the one multiplied) or 32 (four stages, three in
+// flight).  Measured level to 3 % slower with 32 (profiles/r05_wgrad_big.txt): the step is not waiting for its DMA - what
+// paces it is LDS traffic (48 transposed reads per wave and step next to the 64 KiB the DMA writes), as in the 128-wide kernels
+#define M3_WGRAD_BIG_ROWS 64
+#endif
+constexpr int BG_ROWS = M3_WGRAD_BIG_ROWS;
+constexpr int BG_NSTAGE = 128 / BG_ROWS;             // 128 KiB of operand stages either way
+constexpr int BG_OPB = BG_ROWS * BG_RS;              // one operand image: 16 / 32 KiB
+constexpr int BG_STAGE = 2 * BG_OPB;                 // [dC | A]
+constexpr int BG_LDS = BG_NSTAGE * (BG_STAGE + 256); // the stages + every stage's per-row factors
+
+template <typename T, bool GC, bool GA, bool SC = false>
+__global__ __launch_bounds__(BG_THREADS, 1) void wgrad_big_kernel(const WgradDev p) {
+  typedef Mma<T> MM;
+  typedef typename MM::frag frag;
+  static_assert(sizeof(T) == 2, "16-bit operands");
+  static_assert(!SC || (GC && std::is_same<T, half_t>::value), "per-row factors: gathered dC rows, fp16");
+  constexpr int ROWS = BG_ROWS, RS = BG_RS, NPC = ROWS / 16, NS = BG_NSTAGE, PD = NS - 1;      // PD: steps in flight ahead of the one multiplied
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int tiles = gridDim.x;
+  const int lin = blockIdx.x + tiles * (blockIdx.y + gridDim.y * blockIdx.z);
+  int tile, gs, g, sp, nst;
+  int64_t r0, r1, s_begin;
+  if (p.chunk_rows) {
+    if (!wgrad_unit(p.group_offsets, p.G, p.chunk_rows, lin, tiles, lane, tile, gs, g, r0, r1)) return;
+    sp = gs; s_begin = 0;
+    nst = (int)((r1 - r0 + ROWS - 1) / ROWS);
+  } else {
+    const int log_id = xcd_remap(lin, tiles * gridDim.y * gridDim.z);
+    tile = log_id % tiles; gs = log_id / tiles;
+    g = gs % (int)gridDim.y; sp = gs / (int)gridDim.y;
+    if (p.group_offsets) { r0 = p.group_offsets[g]; r1 = p.group_offsets[g + 1]; }
+    else { r0 = 0; r1 = p.M; }
+    const int64_t nsteps_all = (r1 - r0 + ROWS - 1) / ROWS;
+    const int64_t per = (nsteps_all + p.splits - 1) / p.splits;
+    s_begin = (int64_t)sp * per;
+    int64_t s_end = s_begin + per;
+    if (s_end > nsteps_all) s_end = nsteps_all;
+    nst = (int)(s_end > s_begin ? s_end - s_begin : 0);
+  }
+  const int tn = tile / p.tiles_k, tk = tile - tn * p.tiles_k;
+  const int n0 = tn * BG_T, k0 = tk * BG_T;
+  const int64_t slab_id = p.chunk_rows ? (int64_t)sp : (int64_t)sp * p.G + g;
+
+  f32x4 acc[8][4];   // [ki][ni]: MFMA rows = k, cols = n
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // DMA: wave w, piece j fills image rows 2 (NPC w + j) + (lane >> 5) of both operands
+  const int prow = lane >> 5;
+  uint32_t colC[NPC], colA[NPC];
+#pragma unroll
+  for (int j = 0; j < NPC; ++j) {
+    const int irow = 2 * (NPC * wave + j) + prow;
+    const int c = (lane & 31) ^ ((irow & 7) << 1);
+    colC[j] = (uint32_t)(n0 + c * 8) * 2; colA[j] = (uint32_t)(k0 + c * 8) * 2;
+  }
+  const int rbase = (int)(r0 + s_begin * ROWS) + 2 * NPC * wave + prow;
+  const int rlast = (int)r1 - 1;
+  const uint32_t ldc = (uint32_t)p.lddc_b, lda = (uint32_t)p.lda_b;
+  int32_t ic[NPC], ia[NPC];
+  auto load_index = [&](int step) {
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int m = min(rbase + step * ROWS + 2 * j, rlast);
+      if (GC) ic[j] = p.c_row_idx[m];
+      if (GA) ia[j] = p.a_row_idx[m];
+    }
+  };
+  char *const s_sc = smem + NS * BG_STAGE;                        // [stage][64 floats]
+  int32_t sc_ix = 0;
+  auto load_sc_index = [&](int step) {
+    if (SC && wave == 0) sc_ix = p.c_row_idx[min((int)(r0 + s_begin * ROWS) + step * ROWS + lane, rlast)];
+  };
+  auto dma = [&](int step, int stage, auto tail_c) {
+    constexpr bool TAIL = decltype(tail_c)::value;
+    char *const dst = smem + stage * BG_STAGE + (NPC * wave) * 1024;
+    const uint64_t zero_row = (uint64_t)(uintptr_t)g_wgrad_zero_row + (lane & 15) * 16;
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int m = rbase + step * ROWS + 2 * j;
+      const uint32_t cr = GC ? (uint32_t)(ic[j] >> p.c_row_sh) : (uint32_t)(TAIL ? min(m, rlast) : m);
+      const uint32_t ar = GA ? (uint32_t)(ia[j] >> p.a_row_sh) : (uint32_t)(TAIL ? min(m, rlast) : m);
+      if constexpr (!TAIL) {
+        __builtin_amdgcn_global_load_lds((glb_void *)(p.dC + (cr * ldc + colC[j])), (lds_void *)(dst + j * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void *)(p.A + (ar * lda + colA[j])), (lds_void *)(dst + j * 1024 + BG_OPB), 16, 0, 0);
+      } else {                                        // rows past the unit's end read the zero row (bit-mask select: no branches)
+        const uint64_t ok = m <= rlast ? ~(uint64_t)0 : (uint64_t)0;
+        const uint64_t sc_ = (((uint64_t)(uintptr_t)p.dC + (cr * ldc + colC[j])) & ok) | (zero_row & ~ok);
+        const uint64_t sa_ = (((uint64_t)(uintptr_t)p.A + (ar * lda + colA[j])) & ok) | (zero_row & ~ok);
+        __builtin_amdgcn_global_load_lds((glb_void *)(uintptr_t)sc_, (lds_void *)(dst + j * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void *)(uintptr_t)sa_, (lds_void *)(dst + j * 1024 + BG_OPB), 16, 0, 0);
+      }
+    }
+    if (SC && wave == 0)
+      __builtin_amdgcn_global_load_lds((glb_void *)(p.c_row_scale + sc_ix), (lds_void *)(s_sc + stage * 256), 4, 0, 0);
+  };
+
+  // transposed fragment reads: lane (li, lg) supplies row 4 lg + (li >> 2) (+ 16: second half of a fragment, + 32: second
+  // chunk of a 64-row step), 8 bytes at columns 4 (li & 3) .. + 3 of the 16-column tile
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void *)smem;
+  const int s3 = (4 * (lg & 1) + (li >> 2)) & 7;
+  const uint32_t frow = lds0 + (uint32_t)((4 * lg + (li >> 2)) * RS + 8 * (li & 1));
+  uint32_t adK[8], adN[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) adK[i] = frow + BG_OPB + (uint32_t)(((wr * 16 + 2 * i + ((li & 3) >> 1)) ^ (s3 << 1)) * 16);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) adN[i] = frow + (uint32_t)(((wc * 8 + 2 * i + ((li & 3) >> 1)) ^ (s3 << 1)) * 16);
+  const uint32_t ad_sc = lds0 + NS * BG_STAGE + 16 * lg;
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#define BG_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+
+  const bool do_bias = (p.bias_ws || p.direct_db) && tk == 0 && wr == 0;
+  float acc_b[4] = {0.f, 0.f, 0.f, 0.f};
+  typedef T t2 __attribute__((ext_vector_type(2)));
+  auto colsum8 = [&](const frag &f, float a) -> float {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const t2 pr = t2{f[2 * j], f[2 * j + 1]};
+      if constexpr (std::is_same<T, half_t>::value) a = __builtin_amdgcn_fdot2(pr, t2{(T)1, (T)1}, a, false);
+      else a = __builtin_amdgcn_fdot2_f32_bf16(pr, t2{(T)1.f, (T)1.f}, a, false);
+    }
+    return a;
+  };
+
+  auto compute = [&](int stage) {
+    const uint32_t so = (uint32_t)stage * BG_STAGE;
+#pragma unroll
+    for (int kc = 0; kc < ROWS / 32; ++kc) {
+      u32x2 rk[8][2], rn[4][2];
+      f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (kc == 0) { BG_TR(rn[i][0], adN[i] + so, 0); BG_TR(rn[i][1], adN[i] + so, 16 * RS); }
+        else { BG_TR(rn[i][0], adN[i] + so, 32 * RS); BG_TR(rn[i][1], adN[i] + so, 48 * RS); }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (kc == 0) { BG_TR(rk[i][0], adK[i] + so, 0); BG_TR(rk[i][1], adK[i] + so, 16 * RS); }
+        else { BG_TR(rk[i][0], adK[i] + so, 32 * RS); BG_TR(rk[i][1], adK[i] + so, 48 * RS); }
+      }
+      if constexpr (SC) {
+        const uint32_t a_ = ad_sc + (uint32_t)stage * 256;
+        if (kc == 0) {
+          asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(s0) : "v"(a_));
+          asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(s1) : "v"(a_));
+        } else {
+          asm volatile("ds_read_b128 %0, %1 offset:128" : "=v"(s0) : "v"(a_));
+          asm volatile("ds_read_b128 %0, %1 offset:192" : "=v"(s1) : "v"(a_));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      frag fk[8], fn[4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fk[i] = __builtin_bit_cast(frag, u32x4{rk[i][0][0], rk[i][0][1], rk[i][1][0], rk[i][1][1]});
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fn[i] = __builtin_bit_cast(frag, u32x4{rn[i][0][0], rn[i][0][1], rn[i][1][0], rn[i][1][1]});
+      if constexpr (SC) {
+        const f16x8 sh = f16x8{(half_t)s0[0], (half_t)s0[1], (half_t)s0[2], (half_t)s0[3],
+                               (half_t)s1[0], (half_t)s1[1], (half_t)s1[2], (half_t)s1[3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fn[i] = __builtin_bit_cast(frag, __builtin_bit_cast(f16x8, fn[i]) * sh);
+      }
+#pragma unroll
+      for (int ki = 0; ki < 8; ++ki)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[ki][ni] = MM::mma(fk[ki], fn[ni], acc[ki][ni]);
+      if (do_bias) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc_b[ni] = colsum8(fn[ni], acc_b[ni]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+#undef BG_TR
+
+  // Pipeline: steps t + 1 .. t + PD are in flight (or landed) while step t is multiplied.  A step's issue slot is
+  // [its 2 NPC DMA pieces, the gather indices of the step after it]; VMEM operations retire in order, so "at most
+  // (PD - 1) issue slots + one index batch outstanding" means step t + 1 has landed.  Wave 0's extra per-row-factor
+  // operations only make its wait stricter; the last PD steps wait for everything.
+  constexpr int IDX = NPC * ((GC ? 1 : 0) + (GA ? 1 : 0));
+  constexpr int KEEP = (PD - 1) * (2 * NPC + IDX) + IDX;
+  const std::true_type is_tail; const std::false_type not_tail;
+  auto issue = [&](int step) {                 // the DMA of `step` (its indices are in registers), then the indices of step + 1
+    if (step < nst) {
+      if (step + 1 == nst) dma(step, step % NS, is_tail); else dma(step, step % NS, not_tail);
+      if (step + 1 < nst) { if (GC || GA) load_index(step + 1); load_sc_index(step + 1); }
+    }
+  };
+  if (nst > 0) {
+    if (GC || GA) load_index(0);
+    load_sc_index(0);
+#pragma unroll
+    for (int q = 0; q < PD; ++q) issue(q);
+    if (PD > 1 && nst > PD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();               // step 0 has landed for every wave
+    for (int t = 0; t < nst; ++t) {
+      issue(t + PD);                            // into the stage step t - 1 was multiplied from
+      compute(t % NS);
+      if (PD > 1 && t + PD + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();            // step t + 1 has landed for every wave, and every wave is done reading step t
+    }
+  }
+
+  if (do_bias) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      float v = acc_b[ni];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int n = n0 + wc * 64 + ni * 16 + li;
+      if (lg == 0) wgrad_store_bias(p, v, slab_id, g, n);
+    }
+  }
+  float *out = p.direct_dW ? p.direct_dW + (int64_t)g * p.N * p.K : p.ws + slab_id * (int64_t)p.N * p.K;
+  const bool add = p.direct_dW && p.direct_beta;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    float *row = out + (int64_t)(n0 + wc * 64 + ni * 16 + li) * p.K + k0 + wr * 128 + 4 * lg;
+    f32x4 old[8];
+    if (add) {
+#pragma unroll
+      for (int ki = 0; ki < 8; ++ki) old[ki] = *(const f32x4 *)(row + ki * 16);
+    }
+#pragma unroll
+    for (int ki = 0; ki < 8; ++ki) *(f32x4 *)(row + ki * 16) = add ? acc[ki][ni] + old[ki] : acc[ki][ni];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Skinny weight gradient: dW [N, K] with K = 16 or 32 - the router's w_gate (custom_moe_layer.py:213-217:
 // dW_gate = h^T d_logits, K = num_experts), no gathers, no bias, one group.  A 128 x 128 MFMA tile pads K to 128: seven of
 // eight MFMAs multiply zeros and every A-side DMA piece takes the clamped tail path (25 us fp16 / 112 us fp32 per launch at
@@ -1225,8 +1481,20 @@ extern "C" int m3_wgrad_set_wide(int on) {
   return M3_OK;
 }
 
+static int g_wgrad_big = -1;
+extern "C" int m3_wgrad_set_big(int on) {
+  M3_REQUIRE(on >= -1 && on <= 1, "m3_wgrad_set_big: %d", on);
+  g_wgrad_big = on;
+  return M3_OK;
+}
+static bool wgrad_big_shape(int N, int K, int dtype) {
+  if (g_wgrad_big < 0) { const char *e = getenv("M3_WGRAD_BIG"); g_wgrad_big = e ? (atoi(e) ? 1 : 0) : 1; }
+  return g_wgrad_big && dtype != M3_F32 && N % BG_T == 0 && K % BG_T == 0;
+}
+
 extern "C" int m3_wgrad_tile(int N, int K, int dtype, int *tn, int *tk) {
   M3_REQUIRE(tn && tk, "m3_wgrad_tile: null output");
+  if (wgrad_big_shape(N, K, dtype)) { *tn = BG_T; *tk = BG_T; return M3_OK; }
   if (g_wgrad_wide < 0) { const char *e = getenv("M3_WGRAD_WIDE"); g_wgrad_wide = e ? (atoi(e) ? 1 : 0) : 0; }
   *tn = WG_T; *tk = WG_T;
 #ifndef M3_EXPERIMENTAL
@@ -1284,7 +1552,13 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
   // wide tiles (fp16): the shapes m3_wgrad_tile() names; the caller sized `splits` / `units` for that tile count
   int tn_w = 0, tk_w = 0;
   m3_wgrad_tile(a->N, a->K, a->dtype, &tn_w, &tk_w);
-  const bool wide = (tn_w != WG_T || tk_w != WG_T) && (d.a_row_div & (d.a_row_div - 1)) == 0 && !d.c_row_scale && d.c_row_div == 1 &&
+  // 256 x 256 tiles (16-bit ViT-Base weights): needs what the LDS-DMA form needs - power-of-two gather divisors, 32-bit lane
+  // offsets, a per-row factor only on gathered fp16 rows; a call the tile rule names but the kernel cannot run falls through
+  // to the 128 x 128 kernels (any kernel works with the caller's `splits`)
+  const bool big_tile = tn_w == BG_T && tk_w == BG_T;
+  const bool big = big_tile && d.a_row_sh >= 0 && d.c_row_sh >= 0 && (!a->c_row_scale || (a->c_row_idx && a->dtype == M3_F16)) &&
+                   (a->M + 1) * d.lddc_b < ((int64_t)1 << 32) && (a->M + 1) * d.lda_b < ((int64_t)1 << 32);
+  const bool wide = !big_tile && (tn_w != WG_T || tk_w != WG_T) && (d.a_row_div & (d.a_row_div - 1)) == 0 && !d.c_row_scale && d.c_row_div == 1 &&
                     !d.direct_dW;
   // the previous call's slab reduction (a->prev): in front of this launch (128 x 128 kernel), or as its own launch
   d.rd_blocks = 0; d.rd_zslices = 0; d.rd_cols = 256;
@@ -1295,7 +1569,7 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
     M3_REQUIRE(!r->bias_ws || (r->db && r->bias_elems > 0 && r->bias_elems % 4 == 0), "m3_wgrad_tn: prev bias slabs need db");
     M3_REQUIRE(r->ws != a->ws, "m3_wgrad_tn: prev slabs and this call's slabs must be different buffers");
     if (r->elems > 0) {
-      if (wide || a->M == 0) {
+      if (wide || big || a->M == 0) {
         int rc = r->chunk_rows ? m3_wgrad_reduce_grouped(r->ws, r->group_offsets, r->G, r->chunk_rows, r->elems, r->dW, r->beta, r->bias_ws,
                                                          r->bias_elems, r->db, r->beta_db, stream)
                                : m3_wgrad_reduce(r->ws, r->splits, r->elems, r->dW, r->beta, r->bias_ws, r->bias_elems, r->db, r->beta_db, stream);
@@ -1335,6 +1609,29 @@ extern "C" int m3_wgrad_tn(const m3_wgrad_args *a, void *stream) {
     return check_launch("m3_wgrad_tn");
   }
 #endif
+  if (big) {
+    d.tiles_k = a->K / BG_T;
+    const dim3 bgrid((a->N / BG_T) * d.tiles_k, a->chunk_rows ? a->units : a->G, a->chunk_rows ? 1 : a->splits), bblock(BG_THREADS);
+    const bool bsc = a->c_row_scale != nullptr;
+    static bool battr = false;
+#define M3_BG_ALL(F) F(half_t, true, true, false) F(half_t, true, false, false) F(half_t, false, true, false) F(half_t, false, false, false) \
+                     F(bf16_t, true, true, false) F(bf16_t, true, false, false) F(bf16_t, false, true, false) F(bf16_t, false, false, false) \
+                     F(half_t, true, true, true) F(half_t, true, false, true)
+    if (!battr) {
+#define M3_BG_ATTR(TT, GC_, GA_, SC_) (void)hipFuncSetAttribute((const void *)wgrad_big_kernel<TT, GC_, GA_, SC_>, hipFuncAttributeMaxDynamicSharedMemorySize, BG_LDS);
+      M3_BG_ALL(M3_BG_ATTR)
+#undef M3_BG_ATTR
+      battr = true;
+    }
+    const bool f16 = a->dtype == M3_F16;
+#define M3_BG_LAUNCH(TT, GC_, GA_, SC_)                                                                          \
+    if (f16 == std::is_same<TT, half_t>::value && gc == GC_ && ga == GA_ && bsc == SC_)                          \
+      hipLaunchKernelGGL((wgrad_big_kernel<TT, GC_, GA_, SC_>), bgrid, bblock, BG_LDS, s, d);
+    M3_BG_ALL(M3_BG_LAUNCH)
+#undef M3_BG_LAUNCH
+#undef M3_BG_ALL
+    return check_launch("m3_wgrad_tn");
+  }
   const int tiles_n = (a->N + WG_T - 1) / WG_T;
   d.tiles_k = (a->K + WG_T - 1) / WG_T;
   dim3 grid(tiles_n * d.tiles_k, a->chunk_rows ? a->units : a->G, a->chunk_rows ? 1 : a->splits), block(WG_THREADS);

@@ -435,7 +435,7 @@ def wgrad_tn(dC, A, dW, *, M=None, beta=0, splits=None, ws=None, c_row_idx=None,
     # direct mode (include/m3vit_hip.h: m3_wgrad_args.direct_dW): with ONE part per group every (group, tile) belongs to one
     # workgroup, which adds its tile into dW itself - no slabs, no reduction.  The default split rule says 1 exactly when the
     # tiles alone fill the chip (the ViT-Base experts: 2304 tiles, 151 MB of gradient per layer)
-    direct = _WGRAD_DIRECT and splits == 1 and wgrad_tile(N, K, dC.dtype) == (128, 128) and dW.data_ptr() % 16 == 0
+    direct = _WGRAD_DIRECT and splits == 1 and wgrad_tile(N, K, dC.dtype) in ((128, 128), (256, 256)) and dW.data_ptr() % 16 == 0
     balanced = group_offsets is not None and not direct
     chunk, units = wgrad_plan(M, G, splits, balanced)
     balanced = chunk > 0
@@ -563,6 +563,12 @@ def wgrad_set_wide(on: int):
     check(lib().m3_wgrad_set_wide(int(on)), "m3_wgrad_set_wide")
 
 
+def wgrad_set_big(on: int):
+    """256 x 256 weight-gradient tiles for the 16-bit ViT-Base shapes: 1 on (default) / 0 off / -1 from M3_WGRAD_BIG
+    (include/m3vit_hip.h: m3_wgrad_set_big); switch before sizing workspaces"""
+    check(lib().m3_wgrad_set_big(int(on)), "m3_wgrad_set_big")
+
+
 def wgrad_set_dma(on: int):
     """LDS-DMA weight-gradient kernel: 0 never / 1 where it pays (default) / 2 wherever it can run / -1 from M3_WGRAD_DMA
     (include/m3vit_hip.h: m3_wgrad_set_dma);
@@ -605,6 +611,10 @@ def default_wgrad_splits(M, N, K, G, dtype=None):
         most = 128 if dtype == torch.float32 else 32
         return int(max(1, min(cap, most, nslots // tiles if tiles <= nslots else 1)))
     slots = 256
+    if (tn, tk) == (256, 256):
+        # one 8-wave workgroup per CU: fill the 256 slots once; with more tiles than slots (grouped experts) one part per
+        # group - the kernel then accumulates into dW itself (direct mode), no slabs
+        return int(max(1, min(cap, 32, slots // tiles))) if tiles < slots else 1
     if 3 * tiles <= slots:
         return int(max(1, min(cap, slots // tiles)))
     best, best_cost = 1, None

@@ -76,13 +76,20 @@ def test_wide_wgrad_tile_rule_and_splits_on_the_host():
     # the default split rule follows the kernel that takes the launch (m3_wgrad_set_dma's rule): 1024 slots where the LDS-DMA
     # kernel runs (fp32; 16-bit weights of >= 1.5 M elements or launches whose tiles fill the chip), 512 for the register-staged one
     assert ops.default_wgrad_splits(25216, 1536, 384, 1, h) == 14 and ops.default_wgrad_splits(25216, 1536, 384, 1, torch.float32) == 28
-    assert ops.default_wgrad_splits(25216, 3072, 768, 1, h) == 7                    # ViT-Base fc1: 144 tiles on 1024 slots
-    ops.wgrad_set_dma(0)
+    assert ops.wgrad_tile(3072, 768, h) == (256, 256) and ops.default_wgrad_splits(25216, 3072, 768, 1, h) == 7   # ViT-Base fc1: 36 big tiles on 256 slots
+    ops.wgrad_set_big(0)
     try:
-        assert ops.default_wgrad_splits(25216, 3072, 768, 1, h) == 3 and ops.default_wgrad_splits(25216, 1536, 384, 1, torch.float32) == 14
+        assert ops.wgrad_tile(3072, 768, h) == (128, 128)
+        assert ops.default_wgrad_splits(25216, 3072, 768, 1, h) == 7                # 144 tiles on 1024 slots
+        ops.wgrad_set_dma(0)
+        try:
+            assert ops.default_wgrad_splits(25216, 3072, 768, 1, h) == 3 and ops.default_wgrad_splits(25216, 1536, 384, 1, torch.float32) == 14
+        finally:
+            ops.wgrad_set_dma(-1)
+        assert ops.default_wgrad_splits(38432, 3072, 768, 16, h) == 1              # the ViT-Base experts: tiles fill the chip -> direct mode
     finally:
-        ops.wgrad_set_dma(-1)
-    assert ops.default_wgrad_splits(38432, 3072, 768, 16, h) == 1                  # the ViT-Base experts: tiles fill the chip -> direct mode
+        ops.wgrad_set_big(-1)
+    assert ops.default_wgrad_splits(38432, 3072, 768, 16, h) == 1                  # (and with the big tile: 576 tiles on 256 slots)
     if not _lib.lib().m3_experimental():
         with pytest.raises(_lib.M3Error):
             ops.wgrad_set_wide(1)                                                   # the wide kernel is not in a default build

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B of the weight-gradient (TN) kernels on every weight-gradient shape of BASELINE configs[1] / [3] / [4] (one task pass,
 single-GPU forms): round 4's path (register-staged kernel, row splits for 512 slots, slabs + reduction always) against the
-LDS-DMA kernel with the splits sized for 512 / 1024 slots and direct accumulation where a launch has one part per group.
+LDS-DMA kernel with the splits sized for 512 / 1024 slots and direct accumulation where a launch has one part per group,
+and the library's default (which adds the 256 x 256 tiles for the 16-bit ViT-Base shapes).
 Variants interleaved in ONE process, random operands STREAMED - a ring of (dC, A) sets larger than the 256 MiB Infinity
 Cache, as inside the training step, where a weight gradient's operands were written many launches earlier (the first
 version of this tool re-read one resident set and over-stated every variant, the DMA kernel most) - HIP events around
@@ -50,13 +51,17 @@ def run(name, flops, mk):
         return
     best = {}
     import m3vit_amd.ops as O
-    fns = {"r4": (0, False, 512, mk()), "dma/512": (2, True, 512, mk()), "dma/1024": (2, True, 1024, mk()), "default": (1, True, 0, mk())}
+    # (mode of m3_wgrad_set_dma, direct accumulation, slots the splits are sized for, 256 x 256 tiles)
+    fns = {"r4": (0, False, 512, 0, mk()), "dma/512": (2, True, 512, 0, mk()), "dma/1024": (2, True, 1024, 0, mk()),
+           "default": (1, True, 0, 1, mk())}
     for _ in range(args.rounds):
-        for k_, (mode, direct, slots, fn) in fns.items():
+        for k_, (mode, direct, slots, big, fn) in fns.items():
             ops.wgrad_set_dma(mode)
+            ops.wgrad_set_big(big)
             O._WGRAD_DIRECT, O._WGRAD_SLOTS = direct, slots
             best[k_] = min(best.get(k_, 1e30), time_us(fn))
     O._WGRAD_DIRECT, O._WGRAD_SLOTS = True, 0
+    ops.wgrad_set_big(-1)
     print(f"{name:50s} " + "  ".join(f"{k_} {v:7.1f} us {flops / v / 1e6:6.1f} TF" for k_, v in best.items()), flush=True)
 
 
