@@ -42,15 +42,19 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <typename T, bool KTAIL>
+// MI: 16-row MFMA tiles per wave along m - 4 (a 128 x 128 tile) or 5 (160 x 128: dense fp32 launches whose 128-row tiles
+// leave the chip a ragged last round, e.g. M = 25 216, N = 384: 591 tiles on 256 CUs = 3 per CU for 79 of them, 474 tiles
+// of 160 rows = 2 per CU at most; fp32 is MFMA-bound, so the busiest CU's rows set the time: 384 -> 320)
+template <typename T, bool KTAIL, int MI = 4>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev p) {
+  constexpr int BMT = 32 * MI;                     // rows of the tile
   typedef Mma<T> MM;
   typedef typename MM::frag frag;
   constexpr int BK = ROWB / (int)sizeof(T);
   constexpr int CHUNKS = ROWB / 64;   // 64-byte fragments groups per row slice = 2
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // [buf][A|B][128 rows * 128 B]
+  // [buf][A: BMT rows | B: 128 rows] * 128 B
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
     const TileOwner ow = grouped_tile_owner(p.tile_starts, p.group_offsets, p.G, mt, lane, ts_lane);
     g = ow.g; m_begin = ow.m_begin; m_end = ow.m_end;
   } else {
-    m_begin = (int64_t)mt * BM;
+    m_begin = (int64_t)mt * BMT;
     m_end = p.M;
     if (m_begin >= m_end) return;
   }
@@ -84,17 +88,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
   // stored, so the loads can be unconditional (no branches -> hipcc keeps counted vmcnt waits).
   // Addresses are (wave-uniform 64-bit base that advances with k) + (32-bit per-lane byte offset):
   // the loads take the SGPR-base form and cost no per-step VALU address arithmetic.
-  uint32_t a_off[4], b_off[4];
+  uint32_t a_off[MI], b_off[4];
   const int c_stage = tid & 7;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MI; ++i) {
     const int row = (tid >> 3) + 32 * i;
     int64_t m = m_begin + row;
     if (m >= m_end) m = m_end - 1;
     int64_t src = m;
     if (p.a_row_idx) src = (int64_t)div_by(p.a_row_idx[m], p.a_row_div, p.a_row_sh);
     a_off[i] = (uint32_t)(src * p.lda_b) + c_stage * 16;
-    int n = n0 + row;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int n = n0 + (tid >> 3) + 32 * i;
     if (n >= p.N) n = p.N - 1;
     b_off[i] = (uint32_t)((int64_t)n * p.ldb_b) + c_stage * 16;
   }
@@ -107,55 +114,53 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
   // multiples of 16 / 32), so one base per (operand, k-chunk) plus compile-time offsets is enough.
   const int st_base = (tid >> 3) * ROWB + ((c_stage ^ ((tid >> 4) & 7)) << 4);      // + i*4096
   const int sw = (li >> 1) & 7;
-  const int rdA0 = (wr * 64 + li) * ROWB + ((lg ^ sw) << 4);                        // + i*2048
-  const int rdA1 = (wr * 64 + li) * ROWB + (((4 + lg) ^ sw) << 4);
-  const int rdB0 = (wc * 64 + li) * ROWB + ((lg ^ sw) << 4) + BM * ROWB;
-  const int rdB1 = (wc * 64 + li) * ROWB + (((4 + lg) ^ sw) << 4) + BM * ROWB;
+  const int rdA0 = (wr * 16 * MI + li) * ROWB + ((lg ^ sw) << 4);                   // + i*2048
+  const int rdA1 = (wr * 16 * MI + li) * ROWB + (((4 + lg) ^ sw) << 4);
+  const int rdB0 = (wc * 64 + li) * ROWB + ((lg ^ sw) << 4) + BMT * ROWB;
+  const int rdB1 = (wc * 64 + li) * ROWB + (((4 + lg) ^ sw) << 4) + BMT * ROWB;
 
   // Two register sets: tile t+1 waits in one set while tile t+2 is being fetched into the other,
   // so every global load has two compute phases to land (prefetch distance 2).
-  u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
-  auto load_global = [&](int ks, u32x4(&ra)[4], u32x4(&rb)[4]) {
+  u32x4 ra0[MI], rb0[4], ra1[MI], rb1[4];
+  auto load_global = [&](int ks, u32x4(&ra)[MI], u32x4(&rb)[4]) {
     int kb = ks * ROWB;
     if (KTAIL && kb + c_stage * 16 >= kbytes) kb = -c_stage * 16;   // K tail: a valid chunk, zeroed at store
     const char *pa = a_base + kb, *pb = b_base + kb;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = *(const u32x4 *)(pa + a_off[i]);
-      rb[i] = *(const u32x4 *)(pb + b_off[i]);
-    }
-  };
-  auto store_lds = [&](int buf, const u32x4(&ra)[4], const u32x4(&rb)[4], int ks) {
-    const bool kin = !KTAIL || (ks * ROWB + c_stage * 16) < kbytes;
-    char *base = smem + buf * (2 * BM * ROWB) + st_base;
+    for (int i = 0; i < MI; ++i) ra[i] = *(const u32x4 *)(pa + a_off[i]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *(u32x4 *)(base + i * 32 * ROWB) = kin ? ra[i] : u32x4{0u, 0u, 0u, 0u};
-      *(u32x4 *)(base + i * 32 * ROWB + BM * ROWB) = kin ? rb[i] : u32x4{0u, 0u, 0u, 0u};
-    }
+    for (int i = 0; i < 4; ++i) rb[i] = *(const u32x4 *)(pb + b_off[i]);
+  };
+  constexpr int BUFB = (BMT + BN) * ROWB;           // one buffer: both operand images
+  auto store_lds = [&](int buf, const u32x4(&ra)[MI], const u32x4(&rb)[4], int ks) {
+    const bool kin = !KTAIL || (ks * ROWB + c_stage * 16) < kbytes;
+    char *base = smem + buf * BUFB + st_base;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) *(u32x4 *)(base + i * 32 * ROWB) = kin ? ra[i] : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(u32x4 *)(base + i * 32 * ROWB + BMT * ROWB) = kin ? rb[i] : u32x4{0u, 0u, 0u, 0u};
   };
 
-  f32x4 acc[4][4];   // [ni][mi]: rows of the MFMA tile = n, cols = m
+  f32x4 acc[4][MI];   // [ni][mi]: rows of the MFMA tile = n, cols = m
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto compute = [&](int buf) {
-    const char *sb = smem + buf * (2 * BM * ROWB);
+    const char *sb = smem + buf * BUFB;
 #pragma unroll
     for (int kc = 0; kc < CHUNKS; ++kc) {
-      frag fa[4], fb[4];
+      frag fa[MI], fb[4];
       const char *pa = sb + (kc ? rdA1 : rdA0), *pb = sb + (kc ? rdB1 : rdB0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = *(const frag *)(pa + i * 16 * ROWB);
-        fb[i] = *(const frag *)(pb + i * 16 * ROWB);
-      }
+      for (int i = 0; i < MI; ++i) fa[i] = *(const frag *)(pa + i * 16 * ROWB);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fb[i] = *(const frag *)(pb + i * 16 * ROWB);
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = MM::mma(fb[ni], fa[mi], acc[ni][mi]);
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = MM::mma(fb[ni], fa[mi], acc[ni][mi]);
     }
   };
 
@@ -206,56 +211,64 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
   // the scattered token-major store of the expert FC2 and for the two-output FC1).
   const float *bias = p.bias ? p.bias + (int64_t)g * p.N : nullptr;
   if (p.vec8) {
-    __syncthreads();                         // all waves are done with the operand buffers
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int row = wr * 64 + mi * 16 + li;
-        const int chunk = wc * 16 + ni * 4 + lg;
-        *(f32x4 *)(smem + row * 512 + ((chunk ^ (row & 31)) << 4)) = acc[ni][mi];
-      }
-    __syncthreads();
+    // MI = 4: the whole tile at once (64 KiB).  MI = 5: 80 KiB would not fit the operand buffers' 72 KiB - the two 80-row
+    // halves (wave rows wr = 0, 1) go through one after the other
+    constexpr int NH = MI == 4 ? 1 : 2, HR = BMT / NH;      // passes, rows per pass
     const int cg = tid & 15, r16 = tid >> 4;
     const int n = n0 + cg * 8;
-    if (n < p.N) {
-      f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
-      if (bias) { b0 = *(const f32x4 *)(bias + n); b1 = *(const f32x4 *)(bias + n + 4); }
+    f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (bias && n < p.N) { b0 = *(const f32x4 *)(bias + n); b1 = *(const f32x4 *)(bias + n + 4); }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      __syncthreads();                       // all waves are done with the operand buffers / the previous half
+      if (NH == 1 || wr == h) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const int row = (NH == 1 ? wr * 64 : 0) + mi * 16 + li;
+            const int chunk = wc * 16 + ni * 4 + lg;
+            *(f32x4 *)(smem + row * 512 + ((chunk ^ (row & 31)) << 4)) = acc[ni][mi];
+          }
+      }
+      __syncthreads();
+      if (n < p.N) {
 #pragma unroll 2
-      for (int ps = 0; ps < 8; ++ps) {
-        const int row = ps * 16 + r16;
-        const int64_t m = m_begin + row;
-        if (m >= m_end) break;
-        const int64_t crow = p.c_row_idx ? (int64_t)p.c_row_idx[m] : m;
-        const int sw = row & 31;
-        f32x4 v0 = *(const f32x4 *)(smem + row * 512 + (((2 * cg) ^ sw) << 4));
-        f32x4 v1 = *(const f32x4 *)(smem + row * 512 + (((2 * cg + 1) ^ sw) << 4));
-        v0 += b0; v1 += b1;
-        if (p.pre_out) Vec8<T>::store((T *)p.pre_out + crow * p.ld_pre + n, v0, v1);
-        if (p.act == M3_ACT_GELU) {
+        for (int ps = 0; ps < HR / 16; ++ps) {
+          const int row = ps * 16 + r16;
+          const int64_t m = m_begin + h * HR + row;
+          if (m >= m_end) break;
+          const int64_t crow = p.c_row_idx ? (int64_t)p.c_row_idx[m] : m;
+          const int sw = row & 31;
+          f32x4 v0 = *(const f32x4 *)(smem + row * 512 + (((2 * cg) ^ sw) << 4));
+          f32x4 v1 = *(const f32x4 *)(smem + row * 512 + (((2 * cg + 1) ^ sw) << 4));
+          v0 += b0; v1 += b1;
+          if (p.pre_out) Vec8<T>::store((T *)p.pre_out + crow * p.ld_pre + n, v0, v1);
+          if (p.act == M3_ACT_GELU) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { v0[j] = gelu_f(v0[j]); v1[j] = gelu_f(v1[j]); }
-        }
-        if (p.gpre) {
-          f32x4 p0, p1;
-          Vec8<T>::load((const T *)p.gpre + crow * p.ld_gpre + n, p0, p1);
+            for (int j = 0; j < 4; ++j) { v0[j] = gelu_f(v0[j]); v1[j] = gelu_f(v1[j]); }
+          }
+          if (p.gpre) {
+            f32x4 p0, p1;
+            Vec8<T>::load((const T *)p.gpre + crow * p.ld_gpre + n, p0, p1);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { v0[j] *= gelu_grad_f(p0[j]); v1[j] *= gelu_grad_f(p1[j]); }
-        }
-        if (p.row_scale) {
-          const int64_t srow = p.row_scale_idx ? (int64_t)p.row_scale_idx[m] : crow;
-          const float sc = p.row_scale[srow / p.row_scale_div];
-          v0 *= sc; v1 *= sc;
-        }
-        if (p.residual) {
-          v0 += *(const f32x4 *)(p.residual + crow * p.ld_res + n);
-          v1 += *(const f32x4 *)(p.residual + crow * p.ld_res + n + 4);
-        }
-        if (p.c_f32) {
-          *(f32x4 *)((float *)p.C + crow * p.ldc + n) = v0;
-          *(f32x4 *)((float *)p.C + crow * p.ldc + n + 4) = v1;
-        } else {
-          Vec8<T>::store((T *)p.C + crow * p.ldc + n, v0, v1);
+            for (int j = 0; j < 4; ++j) { v0[j] *= gelu_grad_f(p0[j]); v1[j] *= gelu_grad_f(p1[j]); }
+          }
+          if (p.row_scale) {
+            const int64_t srow = p.row_scale_idx ? (int64_t)p.row_scale_idx[m] : crow;
+            const float sc = p.row_scale[srow / p.row_scale_div];
+            v0 *= sc; v1 *= sc;
+          }
+          if (p.residual) {
+            v0 += *(const f32x4 *)(p.residual + crow * p.ld_res + n);
+            v1 += *(const f32x4 *)(p.residual + crow * p.ld_res + n + 4);
+          }
+          if (p.c_f32) {
+            *(f32x4 *)((float *)p.C + crow * p.ldc + n) = v0;
+            *(f32x4 *)((float *)p.C + crow * p.ldc + n + 4) = v1;
+          } else {
+            Vec8<T>::store((T *)p.C + crow * p.ldc + n, v0, v1);
+          }
         }
       }
     }
@@ -264,8 +277,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
   // Generic path (N or a leading dimension not a multiple of 8): lane holds for tile (ni, mi)
   // n = nb + 4*lg + r (r = 0..3), m = mb + li.
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int64_t m = m_begin + wr * 64 + mi * 16 + li;
+  for (int mi = 0; mi < MI; ++mi) {
+    const int64_t m = m_begin + wr * 16 * MI + mi * 16 + li;
     if (m >= m_end) continue;
     const int64_t crow = p.c_row_idx ? (int64_t)p.c_row_idx[m] : m;
 #pragma unroll
@@ -721,6 +734,25 @@ extern "C" int m3_gemm_nt(const m3_gemm_args *a, void *stream) {
     return check_launch("m3_gemm_nt");
   }
   const bool ktail = (a->K * es) % ROWB != 0;
+  // fp32, dense: 160-row tiles where they even out the last round (gemm_nt_kernel's MI = 5).  The busiest CU's share of the
+  // rows - ceil(tiles / 256 CUs) x tile rows - decides an MFMA-bound launch; M3_GEMM_F32_TALL=0 switches it off
+  if (a->dtype == M3_F32 && !ktail && !a->group_offsets) {
+    static int tall = -1;
+    if (tall < 0) { const char *e = getenv("M3_GEMM_F32_TALL"); tall = e ? atoi(e) : 1; }
+    const int64_t t128 = (a->M + 127) / 128 * d.n_tiles, t160 = (a->M + 159) / 160 * d.n_tiles;
+    const int64_t cost128 = (t128 + 255) / 256 * 128, cost160 = (t160 + 255) / 256 * 160;
+    if (tall && cost160 < cost128) {
+      const size_t lds5 = 2 * (160 + BN) * ROWB;          // 72 KiB: two workgroups per CU
+      static bool attr5 = false;
+      if (!attr5) {
+        (void)hipFuncSetAttribute((const void *)gemm_nt_kernel<float, false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
+        attr5 = true;
+      }
+      d.m_tiles_max = (int)((a->M + 159) / 160);
+      hipLaunchKernelGGL((gemm_nt_kernel<float, false, 5>), dim3((unsigned)t160), block, lds5, s, d);
+      return check_launch("m3_gemm_nt");
+    }
+  }
   if (a->dtype == M3_F16) {
     if (ktail) hipLaunchKernelGGL((gemm_nt_kernel<half_t, true>), grid, block, lds, s, d);
     else hipLaunchKernelGGL((gemm_nt_kernel<half_t, false>), grid, block, lds, s, d);

@@ -82,6 +82,31 @@ def test_gemm_epilogues(ops, dtype):
     assert rel(C2, (A.double() @ B.double().t()) * gelu_grad64(gpre.double())) < TOL[dtype]
 
 
+@pytest.mark.parametrize("M,N,K", [(33000, 128, 64), (25216, 384, 96), (32931, 136, 160)])
+def test_gemm_f32_tall_tiles(ops, M, N, K):
+    """fp32, dense, shapes where 160-row tiles even out the last round (gemm_nt_kernel's MI = 5: m3_gemm_nt picks them when
+    ceil(tiles / 256) x tile rows comes out smaller than with 128 rows): every epilogue, a ragged last tile, a partial column
+    tile, the two-pass transposed store - the fp32 arithmetic train_fastmoe.py runs (custom_moe_layer.py:32-33)"""
+    dtype = torch.float32
+    A, B = rnd(M, K, dtype=dtype, seed=3), rnd(N, K, dtype=dtype, scale=0.08, seed=4)
+    bias = rnd(N, seed=5, scale=0.1)
+    res = rnd(M, N, seed=6)
+    gpre = rnd(M, N, dtype=dtype, seed=7)
+    lin = A.double() @ B.double().t() + bias.double()
+    C = torch.full((M, N), float("nan"), dtype=dtype, device=dev())
+    ops.gemm_nt(A, B, C)
+    assert rel(C, lin - bias.double()) < TOL[dtype] and bool(torch.isfinite(C).all())
+    C = torch.empty(M, N, dtype=dtype, device=dev()); pre = torch.empty_like(C)
+    ops.gemm_nt(A, B, C, bias=bias, act=ops.M3_ACT_GELU, pre_out=pre)
+    assert rel(pre, lin) < TOL[dtype] and rel(C, gelu64(lin)) < TOL[dtype]
+    C32 = res.clone()
+    ops.gemm_nt(A, B, C32, bias=bias, residual=C32)                                    # residual in place, as the engine's proj / fc2
+    assert rel(C32, lin + res.double()) < TOL[dtype]
+    C2 = torch.empty(M, N, dtype=dtype, device=dev())
+    ops.gemm_nt(A, B, C2, gelu_grad_pre=gpre)
+    assert rel(C2, (lin - bias.double()) * gelu_grad64(gpre.double())) < TOL[dtype]
+
+
 def _golden(name):
     from conftest import GOLDEN
     return dict(np.load(os.path.join(GOLDEN, name + ".npz")))

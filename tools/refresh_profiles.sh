@@ -21,6 +21,13 @@ cp $(find $O/prof1f32 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_seria
 python $R/tools/prof_by_launch.py $(find $O/prof1 -name "*kernel_trace.csv" | head -1) --steps 14 > $O/by_launch_shape_serial.txt
 python $R/tools/prof_by_launch.py $(find $O/prof1f32 -name "*kernel_trace.csv" | head -1) --steps 9 > $O/by_launch_shape_serial_f32.txt
 rm -rf $O/prof1 $O/prof2 $O/prof1f32
+# per-SHAPE tables of the two GEMM entry points (HIP events around every launch of a serial eager step)
+cd $R
+for spec in "f16 1" "f32 1" "f16 3"; do
+  set -- $spec
+  timeout -k 10 300 python tools/shape_times.py --dtype $1 --config $2 > $O/shape_times_$1_cfg$2.txt 2>&1
+done
+cd /tmp
 # the ViT-Base configurations (single-GPU forms): serial traces
 $R/tools/prof_config.sh 3 gpurun_out/final && $R/tools/prof_config.sh 4 gpurun_out/final
 cd /tmp
