@@ -24,6 +24,17 @@ from . import ops
 from .engine import BackboneEngine
 
 
+_STREAMS = {}
+
+
+def _shared_stream(dev, key):
+    """one HIP stream per (device, role) for the life of the process - see MultiTaskStep.__init__"""
+    k = (str(dev), key)
+    if k not in _STREAMS:
+        _STREAMS[k] = torch.cuda.Stream(device=dev)
+    return _STREAMS[k]
+
+
 class MultiTaskStep:
     def __init__(self, cfg, params, batch: int, dtype=torch.float16, device="cuda:0", tasks=None, cv_weight: float = 0.01,
                  parallel_tasks: bool = True, graph: bool = True, world: int = 1, rank: int = 0, expert_parallel: bool = False,
@@ -65,7 +76,12 @@ class MultiTaskStep:
                                     if (self.par or self.par_ep) else [])
         # (measured and dropped in round 3, profiles/r03_stream_experiments.txt: a high-priority side stream serialises the
         # passes - 18.6 -> 24 ms - and starting pass 1 a few forward blocks behind pass 0 only lengthens the step)
-        self.streams = [torch.cuda.Stream(device=self.dev) for _ in self.engs[1:]]
+        # The task streams are shared by every runner of the process (one step runs at a time): HIP deals a process's streams
+        # round-robin onto a handful of hardware queues (GPU_MAX_HW_QUEUES, default 4), and a runner built after a few others had
+        # consumed streams could get a task stream on the SAME queue as the stream it forks from - its passes then ran one after the
+        # other (bench.py's configs[4] sub-run behind the shared-stem sub-run: 42.6 ms per step, the serial time, against 37.8
+        # alone).  The first streams of the process are the ones every measurement of the two-stream step has used.
+        self.streams = [_shared_stream(self.dev, i) for i in range(len(self.engs) - 1)]
         self.flat = self.eng.flat_grads
         # cutting the step only makes sense when there is a collective to hide and the passes run side by side
         depth = self.eng.depth
@@ -407,7 +423,7 @@ class MultiTaskStep:
             self.capture_error = self.capture_refused
             return False
         try:
-            side = torch.cuda.Stream(device=self.dev)
+            side = _shared_stream(self.dev, "capture")
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 self.compute()
