@@ -540,6 +540,7 @@ _WGRAD_DIRECT = _os.environ.get("M3_WGRAD_DIRECT", "1") != "0"      # splits == 
 # workgroup slots a weight-gradient launch is split to fill: the LDS-DMA kernel runs four workgroups per CU, the
 # register-staged one two; which kernel takes a launch is m3_wgrad_tn's rule (include/m3vit_hip.h: m3_wgrad_set_dma),
 # mirrored in _wgrad_uses_dma (measured with streamed operands: tools/wgrad_ab_bench.py, profiles/r05_wgrad_ab_streamed.txt)
+_WGRAD_MOST16 = int(_os.environ.get("M3_WGRAD_MOST16", "32"))       # most row parts of a 16-bit weight gradient (A/B knob; 44 / 56 measured level to +0.5 % at configs[1])
 _WGRAD_SLOTS = int(_os.environ.get("M3_WGRAD_SLOTS", "0"))         # 0: by kernel (1024 / 512)
 _WGRAD_DMA = int(_os.environ.get("M3_WGRAD_DMA", "1"))              # 0 never, 1 where it pays (default), 2 wherever it can run
 
@@ -608,7 +609,7 @@ def default_wgrad_splits(M, N, K, G, dtype=None):
         nslots = _wgrad_slots(dtype, N, K, G, tiles)
         # fp32 is MFMA-bound (1/16 of the fp16 rate): its workgroup slots matter more than its slab bytes, so small weights
         # (proj: 9 tiles) may be cut into as many parts as fill them; 16-bit stays at 32 (slab traffic)
-        most = 128 if dtype == torch.float32 else 32
+        most = 128 if dtype == torch.float32 else _WGRAD_MOST16
         return int(max(1, min(cap, most, nslots // tiles if tiles <= nslots else 1)))
     slots = 256
     if (tn, tk) == (256, 256):
