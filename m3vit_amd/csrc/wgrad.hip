@@ -740,8 +740,28 @@ __global__ __launch_bounds__(WG_THREADS, SC ? 3 : 4) void wgrad_dma_kernel(const
 // logical chunk (l & 31) ^ ((row & 7) << 1): the same 8-row XOR as the 128-wide 16-bit image, so the transposed reads
 // (16 rows x 32 bytes per instruction) meet the same banks as there.  Gathers, per-row factor, fused bias sums, slabs or
 // direct accumulation: as wgrad_dma_kernel.  The previous call's reduction does not ride here (512 threads): own launch.
+// Diagnostic build only (make CXXFLAGS+=-DM3_WGRAD_STAMPS, tools/wgrad_big_stamps.py): lane 0 of waves 0 and 4 of the first
+// workgroups of wgrad_big_kernel record s_memtime per step - after the DMA issue, after the MFMAs, after the vmcnt wait, after
+// the barrier.  No stamp executes in the shipped kernel.
+#ifdef M3_WGRAD_STAMPS
+constexpr int WSTAMP_WGS = 512, WSTAMP_N = 2 * (2 + 4 * 24);
+__device__ unsigned long long g_wbig_stamps[WSTAMP_WGS][WSTAMP_N];
+#define WB_STAMP(i)                                                                                                   \
+  do {                                                                                                                \
+    if ((threadIdx.x & 255) == 0 && blockIdx.x < WSTAMP_WGS && blockIdx.y == 0 && blockIdx.z == 0 && (i) < WSTAMP_N / 2)   \
+      g_wbig_stamps[blockIdx.x][(threadIdx.x >> 8) * (WSTAMP_N / 2) + (i)] = __builtin_amdgcn_s_memtime();             \
+  } while (0)
+#else
+#define WB_STAMP(i) do { } while (0)
+#endif
 constexpr int BG_T = 256, BG_THREADS = 512, BG_RS = 512;
 #ifndef M3_WGRAD_BIG_ROWS
+// What a 64-row step spends (in-kernel stamps, tools/wgrad_big_stamps.py, profiles/r05_wgrad_big_stamps.txt): ~800-1 550 cycles in
+// which the waves sit in the ISSUE of their eight DMA instructions (a wave is held there until the CU's load path has taken
+// them: the step's 64 KiB pass while nobody multiplies), ~1 800-2 300 of fragment reads + 64 MFMAs (1 024 of them MFMA), then
+// the wait and the barrier: 4 250 in all, transfer and MFMA time adding up instead of overlapping.  Three re-arrangements were
+// built and measured on the dense shapes, all within +-4 % of this one: a DMA instruction behind every eight MFMAs, waves 4-7
+// sending theirs after multiplying instead of before, and the DMA issued in the shadow of the fragment reads.
 // contraction rows per step: 64 (two stages, one step in flight ahead of the one multiplied) or 32 (four stages, three in
 // flight).  Measured level to 3 % slower with 32 (profiles/r05_wgrad_big.txt): the step is not waiting for its DMA - what
 // paces it is LDS traffic (48 transposed reads per wave and step next to the 64 KiB the DMA writes), as in the 128-wide kernels
@@ -943,6 +963,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void wgrad_big_kernel(const WgradDev
       if (step + 1 < nst) { if (GC || GA) load_index(step + 1); load_sc_index(step + 1); }
     }
   };
+  WB_STAMP(0);
   if (nst > 0) {
     if (GC || GA) load_index(0);
     load_sc_index(0);
@@ -951,12 +972,17 @@ __global__ __launch_bounds__(BG_THREADS, 1) void wgrad_big_kernel(const WgradDev
     if (PD > 1 && nst > PD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();               // step 0 has landed for every wave
+    WB_STAMP(1);
     for (int t = 0; t < nst; ++t) {
       issue(t + PD);                            // into the stage step t - 1 was multiplied from
+      WB_STAMP(2 + 4 * t);
       compute(t % NS);
+      WB_STAMP(3 + 4 * t);
       if (PD > 1 && t + PD + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      WB_STAMP(4 + 4 * t);
       __builtin_amdgcn_s_barrier();            // step t + 1 has landed for every wave, and every wave is done reading step t
+      WB_STAMP(5 + 4 * t);
     }
   }
 
@@ -1535,6 +1561,12 @@ extern "C" int m3_wgrad_tile(int N, int K, int dtype, int *tn, int *tk) {
 
 // 16-byte columns per block of the dense slab reduction: four threads per column from 32 slabs on
 static inline int m3_wgrad_reduce_cols(int splits) { return splits >= 32 ? 64 : 256; }
+#ifdef M3_WGRAD_STAMPS
+extern "C" int m3_debug_wbig_stamps(unsigned long long *dst, int wgs) {
+  if (wgs > WSTAMP_WGS) wgs = WSTAMP_WGS;
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wbig_stamps), (size_t)wgs * WSTAMP_N * sizeof(unsigned long long)) == hipSuccess ? M3_OK : M3_ERR_LAUNCH;
+}
+#endif
 static inline bool sc_any(const m3_wgrad_args *a) { return a->c_row_scale != nullptr; }
 
 extern "C" int m3_wgrad_skinny(int N, int K, int G) {
