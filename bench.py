@@ -344,13 +344,14 @@ def main():
                                                             if use_ep else f"dp{world} (replicated experts, {coll} all-reduce)")}
         if want_roofline:
             res["roofline"] = roofline_of(ops, runner, dtype_name, step, serial_step, par_tasks, ntasks,
-                                          replay_traffic=(wl is WORKLOADS[1] and batch == 128 and not skew and not args.noisy))
+                                          replay_traffic=(batch == wl["batch"] and not skew and not args.noisy),
+                                          traffic_cfg=next(k for k, v in WORKLOADS.items() if v is wl))
         res["workload"], res["batch"], res["steps"], res["warmup"] = wl["name"], batch, steps, warmup
         del runner
         torch.cuda.empty_cache()
         return res
 
-    def roofline_of(ops, runner, dtype_name, step, serial_step, par_tasks, ntasks, replay_traffic=True):
+    def roofline_of(ops, runner, dtype_name, step, serial_step, par_tasks, ntasks, replay_traffic=True, traffic_cfg=1):
         # ---- roofline of the dominant kernel (m3_gemm_nt: every Linear / FMoELinear forward + input-gradient GEMM;
         # two device kernels behind it, gemm_nt_dma_kernel for short K and gemm_nt_kernel), measured with HIP events
         # around each launch, on the launch stream, in a few extra instrumented steps.  Primary figures: the launches
@@ -379,7 +380,9 @@ def main():
         try:
             import glob
             from m3vit_amd._lib import csrc_sha16
-            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
+            # (the metric's configuration: r*_pmc_traffic*.json; the ViT-Base configurations: r*_cfgN_hbm_bytes_per_launch.json)
+            pat = "r*_pmc_traffic*.json" if traffic_cfg == 1 else f"r*_cfg{traffic_cfg}_hbm_bytes_per_launch.json"
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pat)), reverse=True):
                 with open(f) as fh:
                     pm = json.load(fh)
                 if pm.get("dtype") != dtype_name or not replay_traffic:
@@ -390,7 +393,13 @@ def main():
                     # measured on other kernels than the ones in this tree: say so instead of replaying it
                     traffic_source = where + "): STALE - the kernel sources changed since; traffic withheld"
                 else:
-                    traffic = round(pm["kernels"]["gemm_nt_all"]["hbm_bytes_per_launch"])
+                    ks = pm["kernels"]
+                    if "gemm_nt_all" in ks:
+                        traffic = round(ks["gemm_nt_all"]["hbm_bytes_per_launch"])
+                    else:                      # every kernel behind m3_gemm_nt, weighted by its launches
+                        parts = [v for k_, v in ks.items() if k_.startswith("gemm_nt")]
+                        traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in parts) /
+                                        max(1, sum(v["launches_sampled"] for v in parts)))
                     traffic_source = where + "; not measured in this run)"
                 break
         except Exception:
