@@ -68,7 +68,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmDev 
   const int nwg = p.tile_starts ? grouped_live_tiles(p.tile_starts, p.G, lane, ts_lane) * p.n_tiles : (int)gridDim.x;
   if ((int)blockIdx.x >= nwg) return;
   const int t = xcd_remap(blockIdx.x, nwg);
-  const int mt = t / p.n_tiles, nt = t - mt * p.n_tiles;
+  int mt, nt;
+  tile_of(t, p.n_tiles, p.m_band, nwg / p.n_tiles, mt, nt);
   int g = 0;
   int64_t m_begin, m_end;
   if (p.tile_starts) {
@@ -375,7 +376,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_nt_dma_kernel(const Gemm
   const int nwg = p.tile_starts ? grouped_live_tiles(p.tile_starts, p.G, lane, ts_lane) * p.n_tiles : (int)gridDim.x;     // live workgroups (see above)
   if ((int)blockIdx.x >= nwg) return;
   const int t = xcd_remap(blockIdx.x, nwg);
-  const int mt = t / p.n_tiles, nt = t - mt * p.n_tiles;
+  int mt, nt;
+  tile_of(t, p.n_tiles, p.m_band, nwg / p.n_tiles, mt, nt);
   int g = 0;
   int64_t m_begin, m_end;
   if (p.tile_starts) {
@@ -679,6 +681,11 @@ extern "C" int m3_gemm_nt(const m3_gemm_args *a, void *stream) {
   d.M = a->M; d.N = a->N; d.K = a->K; d.G = a->G;
   d.group_offsets = a->group_offsets; d.tile_starts = a->tile_starts;
   d.n_tiles = (a->N + BN - 1) / BN;
+  // tile order (gemm_dev.h: tile_of): bands of four row tiles when a group's weight does not fit an XCD's L2 beside the rows
+  // (> 2 MB: the ViT-Base N = 2304 / 3072 launches and K = 3072); M3_GEMM_BAND=n forces n (1 = row-tile major everywhere)
+  static int band_env = -1;
+  if (band_env < 0) { const char *e = getenv("M3_GEMM_BAND"); band_env = e ? atoi(e) : 0; }
+  d.m_band = band_env > 0 ? band_env : ((int64_t)a->N * a->K * es > ((int64_t)2 << 20) ? 4 : 1);
   const int64_t mt = (a->M + BM - 1) / BM + (a->group_offsets ? a->G : 0);
   M3_REQUIRE(mt * d.n_tiles < (int64_t)1 << 30, "m3_gemm_nt: grid too large");
   d.m_tiles_max = (int)mt;

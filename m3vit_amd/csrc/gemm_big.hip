@@ -78,7 +78,8 @@ __global__ __launch_bounds__(XT, 2) void gemm_nt_big_kernel(const GemmDev p) {
   }
   if ((int)blockIdx.x >= nwg) return;
   const int t = xcd_remap(blockIdx.x, nwg);
-  const int mt = t / p.n_tiles, nt = t - mt * p.n_tiles;
+  int mt, nt;
+  tile_of(t, p.n_tiles, p.m_band, nwg / p.n_tiles, mt, nt);
   if (p.group_offsets) {
     g = __popcll(__ballot(incl <= mt));
     int t0 = g ? __shfl(incl, g - 1, 64) : 0;
@@ -378,6 +379,7 @@ bool gemm_big_eligible(const GemmDev &d, int es, bool force) {
 int launch_gemm_big(const GemmDev &d0, int dtype, int epi, hipStream_t s) {
   GemmDev d = d0;
   d.n_tiles = (d.N + XB - 1) / XB;
+  d.m_band = 1;             // row-tile major: a 256-row tile's A rows at K >= 2048 are 1 MB and more - four of them do not sit in an L2 (counters: banded +13 % fetch)
   const int64_t mt = (d.M + XB - 1) / XB + (d.group_offsets ? d.G : 0);
   static bool attr_done = false;
   if (!attr_done) {

@@ -26,6 +26,7 @@ struct GemmDev {
   const int32_t *group_offsets;
   const int32_t *tile_starts;
   int32_t n_tiles;
+  int32_t m_band;                  // row tiles per band of the tile order (tile_of): 1 = row-tile major
   int32_t m_tiles_max;
   int32_t vec8;                                 // N and all leading dims multiples of 8: staged epilogue
 };
@@ -78,4 +79,19 @@ int launch_gemm_big(const GemmDev &d, int dtype, int epi, hipStream_t s);
 // gemm_ws.hip (EXPERIMENTAL builds): 0 launched, 1 not a call it takes, < 0 error
 int launch_gemm_ws(const GemmDev &d, const m3_gemm_args *a, int64_t mt, int ws_mode, hipStream_t s);
 
+
+// Logical tile id -> (row tile, column tile).  Row-tile major (band 1): the n_tiles column tiles of a row tile are neighbours
+// (one XCD, one moment: the A rows come from HBM once).  When a column-tile's weight panel set does not fit the XCD's L2
+// (the ViT-Base N = 2304 / 3072 launches: 18-24 panels of 196 KB), that order re-fetches every panel for every row tile; in
+// bands of m_band row tiles - column tile major inside a band - the 32 workgroups an XCD runs at a time cover m_band row
+// tiles x 32 / m_band panels, so a panel is fetched once per band and the band's A rows stay resident while its column tiles
+// go by.  live_m: live row tiles of the launch.
+__device__ __forceinline__ void tile_of(int t, int n_tiles, int m_band, int live_m, int &mt, int &nt) {
+  if (m_band <= 1) { mt = t / n_tiles; nt = t - mt * n_tiles; return; }
+  const int per = m_band * n_tiles;
+  const int band = t / per, r = t - band * per;
+  const int rows = min(m_band, live_m - band * m_band);
+  nt = r / rows;
+  mt = band * m_band + (r - nt * rows);
+}
 }  // namespace m3
