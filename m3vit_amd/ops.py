@@ -541,6 +541,7 @@ _WGRAD_DIRECT = _os.environ.get("M3_WGRAD_DIRECT", "1") != "0"      # splits == 
 # register-staged one two; which kernel takes a launch is m3_wgrad_tn's rule (include/m3vit_hip.h: m3_wgrad_set_dma),
 # mirrored in _wgrad_uses_dma (measured with streamed operands: tools/wgrad_ab_bench.py, profiles/r05_wgrad_ab_streamed.txt)
 _WGRAD_MOST16 = int(_os.environ.get("M3_WGRAD_MOST16", "32"))       # most row parts of a 16-bit weight gradient (A/B knob; 44 / 56 measured level to +0.5 % at configs[1])
+_WGRAD_XCD_ALIGN = _os.environ.get("M3_WGRAD_XCD_ALIGN", "1") != "0"
 _WGRAD_SLOTS = int(_os.environ.get("M3_WGRAD_SLOTS", "0"))         # 0: by kernel (1024 / 512)
 _WGRAD_DMA = int(_os.environ.get("M3_WGRAD_DMA", "1"))              # 0 never, 1 where it pays (default), 2 wherever it can run
 
@@ -593,6 +594,16 @@ def wgrad_skinny(N, K, G=1) -> bool:
     return bool(lib().m3_wgrad_skinny(int(N), int(K), int(G)))
 
 
+def _xcd_aligned(splits):
+    """Row parts of a dense call in whole multiples of the 8 XCDs where that costs at most 1/8 of the parts: the tiles of a part
+    read the same rows, and the XCD remap hands every XCD an equal run of consecutive workgroups - with a multiple of 8 parts no
+    part straddles two XCDs (its rows then come into one L2, not two).  M3_WGRAD_XCD_ALIGN=0 switches it off."""
+    if not _WGRAD_XCD_ALIGN or splits < 8:
+        return splits
+    down = splits - splits % 8
+    return down if 8 * down >= 7 * splits else splits
+
+
 def default_wgrad_splits(M, N, K, G, dtype=None):
     """Row splits of the TN GEMM.  128 x 128 tiles: fill the 512 resident workgroup slots (2 per CU) exactly once - more
     splits only add slab traffic and a ragged second wave of workgroups - but keep at least _WGRAD_MIN_STEPS 32-row
@@ -610,12 +621,14 @@ def default_wgrad_splits(M, N, K, G, dtype=None):
         # fp32 is MFMA-bound (1/16 of the fp16 rate): its workgroup slots matter more than its slab bytes, so small weights
         # (proj: 9 tiles) may be cut into as many parts as fill them; 16-bit stays at 32 (slab traffic)
         most = 128 if dtype == torch.float32 else _WGRAD_MOST16
-        return int(max(1, min(cap, most, nslots // tiles if tiles <= nslots else 1)))
+        sp = int(max(1, min(cap, most, nslots // tiles if tiles <= nslots else 1)))
+        return _xcd_aligned(sp) if G == 1 else sp
     slots = 256
     if (tn, tk) == (256, 256):
         # one 8-wave workgroup per CU: fill the 256 slots once; with more tiles than slots (grouped experts) one part per
         # group - the kernel then accumulates into dW itself (direct mode), no slabs
-        return int(max(1, min(cap, 32, slots // tiles))) if tiles < slots else 1
+        sp = int(max(1, min(cap, 32, slots // tiles))) if tiles < slots else 1
+        return _xcd_aligned(sp) if G == 1 else sp
     if 3 * tiles <= slots:
         return int(max(1, min(cap, slots // tiles)))
     best, best_cost = 1, None

@@ -47,7 +47,7 @@ def test_tile_rule(ops):
     h, b, f = torch.float16, torch.bfloat16, torch.float32
     assert ops.wgrad_tile(768, 768, h) == (256, 256) and ops.wgrad_tile(3072, 768, b) == (256, 256) and ops.wgrad_tile(2304, 768, h) == (256, 256)
     assert ops.wgrad_tile(768, 768, f) == (128, 128) and ops.wgrad_tile(384, 768, h) == (128, 128) and ops.wgrad_tile(768, 1152, h) == (128, 128)
-    assert ops.default_wgrad_splits(25216, 2304, 768, 1, h) == 9 and ops.default_wgrad_splits(25216, 768, 768, 1, h) == 28
+    assert ops.default_wgrad_splits(25216, 2304, 768, 1, h) == 8 and ops.default_wgrad_splits(25216, 768, 768, 1, h) == 28    # (9 -> 8: whole parts per XCD)
     assert ops.default_wgrad_splits(100864, 768, 768, 64, h) == 1 and ops.default_wgrad_splits(38432, 3072, 768, 16, h) == 1
     assert small(ops, lambda: ops.wgrad_tile(768, 768, h)) == (128, 128)
 
