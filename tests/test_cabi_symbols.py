@@ -90,6 +90,9 @@ def test_wide_wgrad_tile_rule_and_splits_on_the_host():
     finally:
         ops.wgrad_set_big(-1)
     assert ops.default_wgrad_splits(38432, 3072, 768, 16, h) == 1                  # (and with the big tile: 576 tiles on 256 slots)
+    # dense row parts come in whole multiples of the 8 XCDs where that costs at most an eighth of them (ops._xcd_aligned)
+    assert [ops._xcd_aligned(n) for n in (1, 7, 8, 9, 14, 18, 28, 32, 37)] == [1, 7, 8, 8, 14, 16, 28, 32, 37]
+    assert ops.default_wgrad_splits(25216, 1152, 384, 1, h) == 16 and ops.default_wgrad_splits(25216, 2304, 768, 1, h) == 8
     if not _lib.lib().m3_experimental():
         with pytest.raises(_lib.M3Error):
             ops.wgrad_set_wide(1)                                                   # the wide kernel is not in a default build
