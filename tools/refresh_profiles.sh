@@ -40,5 +40,10 @@ for DT in f16 f32; do
   # the databases are large: keep only the summaries in what gpurun copies back
   rm -rf $O/fetch_$DT $O/write_$DT
 done
+# the ViT-Base configurations' counters (bench.py replays them as configs3 / configs4 .roofline.traffic:
+# copy to profiles/rNN_cfg3_hbm_bytes_per_launch.json / rNN_cfg4_hbm_bytes_per_launch.json)
+cd $R
+tools/pmc_config.sh 3 gpurun_out/final $HEAD
+tools/pmc_config.sh 4 gpurun_out/final $HEAD
 ls -la $O
 echo refresh done
