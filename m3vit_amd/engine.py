@@ -295,12 +295,15 @@ class BackboneEngine:
                 self.ep_overflow = torch.zeros(1, dtype=torch.int32, device=self.dev)
                 n = W * self.ep_cap
                 # static buffers of the padded exchange, per MoE block (a captured step replays on fixed addresses)
-                self.ep_fx = {i: dict(x_send=self._e(n, D), x_recv=self._e(n, D), hid_pre=self._e(n, self.Hm),
-                                      hid=self._e(n, self.Hm), y_recv=self._e(n, D), y_back=self._e(n, D),
-                                      recv_counts=torch.empty(self.E, dtype=torch.int64, device=self.dev), plan=None)
+                # (zeroed once: the rows of a pair's share that no routed row fills travel over the wire as they are - never read
+                # back, unpad_idx does not select them, but they should not be whatever the allocator left there)
+                z = lambda *shape: torch.zeros(*shape, dtype=self.dt, device=self.dev)                   # noqa: E731
+                self.ep_fx = {i: dict(x_send=z(n, D), x_recv=z(n, D), hid_pre=z(n, self.Hm),
+                                      hid=z(n, self.Hm), y_recv=z(n, D), y_back=z(n, D),
+                                      recv_counts=torch.zeros(self.E, dtype=torch.int64, device=self.dev), plan=None)
                               for i in range(self.depth) if self.is_moe[i]}
-                self.ep_fx_bwd = dict(dy_send=self._e(n, D), dy_recv=self._e(n, D), dhp=self._e(n, self.Hm),
-                                      dx_recv=self._e(n, D), dx_back=self._e(n, D))
+                self.ep_fx_bwd = dict(dy_send=z(n, D), dy_recv=z(n, D), dhp=z(n, self.Hm),
+                                      dx_recv=z(n, D), dx_back=z(n, D))
 
     def cfg_d_gate(self):
         g = self.cfg.gate_task_specific_dim
